@@ -1,0 +1,177 @@
+/*
+ * pintron_gpu.h -- C-ABI of the MI355X (gfx950) est-fact accelerator library, libpintron_gpu.so.
+ *
+ * This is the drop-in boundary for PIntron's est-fact hot path: plain C, pointers and sizes only.
+ * Each entry point names the reference routine(s) it replaces (paths relative to the AlgoLab/PIntron
+ * tree).  The library has NO CPU fallback: every call fails with PGPU_EDEVICE when no gfx950
+ * device is usable.
+ *
+ * Threading: a pgpu_ctx owns one HIP stream; calls on one context must be serialised by the
+ * caller, different contexts are independent.  All functions return 0 (PGPU_OK) or a negative
+ * errno-style code and never abort.
+ */
+#ifndef PINTRON_GPU_H
+#define PINTRON_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PGPU_OK       0
+#define PGPU_EDEVICE (-5)    /* HIP runtime error / no device (EIO) */
+#define PGPU_ENOMEM  (-12)
+#define PGPU_EINVAL  (-22)
+#define PGPU_ENOSPC  (-28)   /* caller's output buffer too small */
+#define PGPU_ERANGE  (-34)   /* a job exceeds the supported dimensions (per-job status) */
+#define PGPU_ENOSYS  (-38)   /* entry point not implemented in this build */
+
+typedef struct pgpu_ctx pgpu_ctx;
+typedef struct pgpu_index pgpu_index;
+typedef struct pgpu_dp_plan pgpu_dp_plan;
+
+/* ------------------------------------------------------------------------------------------ */
+/* context                                                                                    */
+/* ------------------------------------------------------------------------------------------ */
+int pgpu_init(int device, pgpu_ctx** ctx);
+int pgpu_destroy(pgpu_ctx* ctx);
+/* human-readable text of the last error on this context (never NULL) */
+const char* pgpu_last_error(const pgpu_ctx* ctx);
+/* ABI version of the loaded library */
+int pgpu_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------ */
+/* genomic index -- replaces lst_stree_new (stree_src/lst_stree.c:816) + preprocess_text /     */
+/* stree_preprocess (src/aug_suffix_tree.c:68,247), called at src/main-est-fact.c:224-239.    */
+/* The genomic sequence (after Ntails_removal) is copied to HBM once, with its suffix array.  */
+/* ------------------------------------------------------------------------------------------ */
+int pgpu_index_build(pgpu_ctx* ctx, const char* genomic, size_t len, pgpu_index** idx);
+int pgpu_index_destroy(pgpu_ctx* ctx, pgpu_index* idx);
+/* copies the suffix array (len entries) back to the host; for tests and diagnostics */
+int pgpu_index_suffix_array(pgpu_ctx* ctx, const pgpu_index* idx, uint32_t* sa_out, size_t cap);
+
+/* ------------------------------------------------------------------------------------------ */
+/* pairings -- replaces build_vertex_set (src/max-emb-graph.c:218-392): for every position p   */
+/* of every pattern, the maximal pairings (p, t, l) of the pattern with the genomic, after the  */
+/* two low-complexity filters, in the order of the reference's per-position lists.            */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct {
+  uint32_t min_factor_len;         /* config->min_factor_len (+ inc_pairing_len)  */
+  uint32_t reserved;
+  double   min_string_depth_rate;  /* config->min_string_depth_rate               */
+} pgpu_pairing_params;
+
+typedef struct { int32_t p, t, l; } pgpu_pairing;
+
+/* patterns: concatenated pattern bytes; pat_off[i]..pat_off[i+1] delimits pattern i (n_pat+1
+ * offsets).  out/out_cap: caller buffer for pairings; out_first[i]..out_first[i+1] delimits the
+ * pairings of pattern i (n_pat+1 entries), sorted by (p, t, l) as pairing_compare orders them
+ * (src/types.c:391-411).  Returns PGPU_ENOSPC (and the needed count in *n_out) when out_cap is
+ * too small. */
+int pgpu_pairings(pgpu_ctx* ctx, const pgpu_index* idx,
+                  const char* patterns, const uint64_t* pat_off, size_t n_pat,
+                  const pgpu_pairing_params* params,
+                  pgpu_pairing* out, size_t out_cap, uint64_t* out_first, size_t* n_out);
+
+/* ------------------------------------------------------------------------------------------ */
+/* batched dynamic programs                                                                   */
+/* ------------------------------------------------------------------------------------------ */
+enum pgpu_dp_kind {
+  /* compute_alignment (src/compute-alignments.c:39-207): a = EST string, b = genomic string.
+   * v[0]=score v[1]=alignment_dim v[2]=offset of EST_alignment, v[3]=offset of GEN_alignment in
+   * the output string buffer (both NUL-terminated). */
+  PGPU_DP_ALIGN = 0,
+  /* compute_gap_alignment (src/refine-intron.c:560-890): a = EST window, b = genomic window.
+   * v[0]=gap_alignment_dim v[1]=factor_cut v[2]=intron_start v[3]=intron_end
+   * v[4]=intron_start_on_align v[5]=intron_end_on_align; strings at str[0], str[1] offsets. */
+  PGPU_DP_GAP = 1,
+  /* Levenshtein distance without N wildcard = last cell of edit_distance (src/refine.c:50-83)
+   * = compute_edit_distance (src/compute-alignments.c:240-249).  v[0]=distance. */
+  PGPU_DP_ED = 2,
+  /* K_band_edit_distance (src/compute-alignments.c:319-453): p0 = upper_bound.
+   * v[0]=returned bool, v[1]=*edit. */
+  PGPU_DP_KBAND = 3,
+  /* find_longest_common_factor_dp (src/factorization-refinement.c:255-316): a = s1, b = s2.
+   * v[0]=len v[1]=occ1 v[2]=occ2. */
+  PGPU_DP_LCF = 4,
+  /* general_refine_borders (src/refine.c:105-192): a = p, b = t, p0=min_p_cut p1=max_p_cut
+   * p2=max_errs, tail = number (0..2) of valid bytes that follow t in its buffer (the reference
+   * reads t[len_t], t[len_t+1] in getBursetFrequency_adaptor).
+   * v[0]=returned bool v[1]=out_offset_p v[2]=out_offset_t1 v[3]=out_offset_t2 v[4]=edit. */
+  PGPU_DP_BORDERS = 5,
+  /* find_longest_affix (src/factorization-refinement.c:1136-1173): a = est, b = genomic.
+   * v[0]=valid_cut v[1]=est cut v[2]=genomic cut. */
+  PGPU_DP_AFFIX = 6,
+  PGPU_DP_NKINDS = 7
+};
+
+#define PGPU_JOB_A_GENOMIC 1u   /* a_off indexes the resident genomic of the index, not the arena */
+#define PGPU_JOB_B_GENOMIC 2u   /* same for b_off */
+
+typedef struct {
+  uint32_t kind;            /* enum pgpu_dp_kind */
+  uint32_t flags;           /* PGPU_JOB_* */
+  uint64_t a_off, b_off;    /* byte offsets of the operands (arena or genomic) */
+  uint32_t a_len, b_len;
+  uint32_t p0, p1, p2;      /* kind-specific parameters */
+  uint32_t tail;            /* BORDERS only */
+} pgpu_dp_job;              /* 48 bytes */
+
+typedef struct {
+  int32_t status;           /* PGPU_OK or PGPU_ERANGE for this job */
+  int32_t v[6];             /* kind-specific, see enum */
+  int32_t pad;
+  uint64_t str[2];          /* ALIGN/GAP: offsets of the two alignment strings */
+} pgpu_dp_result;           /* 48 bytes */
+
+/* limits (per job); larger jobs get status PGPU_ERANGE */
+#define PGPU_MAX_ROWS_LEV  4096u   /* ALIGN: a_len; ED: min(a_len,b_len); BORDERS/AFFIX: a_len */
+#define PGPU_MAX_ROWS_GAP  2048u   /* GAP: a_len */
+#define PGPU_MAX_COLS      1048576u
+
+/* A plan holds a batch of jobs resident in HBM: operands, sorted job table, workspaces, results.
+ * create = sort by kernel/size + upload; launch = enqueue every kernel of the batch on the
+ * context's stream (asynchronous); sync = wait; fetch = copy results (and alignment strings)
+ * back in the caller's job order.  idx may be NULL when no job uses PGPU_JOB_*_GENOMIC. */
+int pgpu_dp_plan_create(pgpu_ctx* ctx, const pgpu_index* idx,
+                        const pgpu_dp_job* jobs, size_t n_jobs,
+                        const char* arena, size_t arena_len, pgpu_dp_plan** plan);
+int pgpu_dp_plan_launch(pgpu_ctx* ctx, pgpu_dp_plan* plan);
+int pgpu_dp_plan_sync(pgpu_ctx* ctx, pgpu_dp_plan* plan);
+/* bytes the alignment strings of this plan need in fetch's `strings` buffer */
+size_t pgpu_dp_plan_string_bytes(const pgpu_dp_plan* plan);
+int pgpu_dp_plan_fetch(pgpu_ctx* ctx, pgpu_dp_plan* plan, pgpu_dp_result* results,
+                       char* strings, size_t strings_cap);
+int pgpu_dp_plan_destroy(pgpu_ctx* ctx, pgpu_dp_plan* plan);
+
+/* measurement hooks (bench.py): DP cells of the plan per kind with the reference's own loop
+ * bounds, algorithmic HBM bytes per kind, and the duration of the last
+ * launch of each kind's kernels measured with HIP events on the context's stream. */
+uint64_t pgpu_dp_plan_cells(const pgpu_dp_plan* plan, int kind);
+uint64_t pgpu_dp_plan_algo_bytes(const pgpu_dp_plan* plan, int kind);
+double   pgpu_dp_plan_kernel_ms(const pgpu_dp_plan* plan, int kind);
+uint64_t pgpu_dp_plan_launches(const pgpu_dp_plan* plan, int kind);
+
+/* per-kernel-launch view of the same numbers: one group = one kernel launch of the plan */
+typedef struct {
+  char     name[48];        /* e.g. "lev_wave<ALIGN,R=4>", "align_traceback", "lcf" */
+  int32_t  kind;            /* enum pgpu_dp_kind */
+  int32_t  pad;
+  uint64_t jobs, cells, algo_bytes;
+  double   ms;              /* HIP-event duration of the last launch */
+} pgpu_group_info;
+int pgpu_dp_plan_n_groups(const pgpu_dp_plan* plan);
+int pgpu_dp_plan_group_info(const pgpu_dp_plan* plan, int i, pgpu_group_info* out);
+
+/* one-shot convenience: create + launch + sync + fetch + destroy */
+int pgpu_dp_batch(pgpu_ctx* ctx, const pgpu_index* idx,
+                  const pgpu_dp_job* jobs, size_t n_jobs, const char* arena, size_t arena_len,
+                  pgpu_dp_result* results, char* strings, size_t strings_cap,
+                  size_t* strings_used);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,262 @@
+"""ctypes binding of include/pintron_gpu.h (the C-ABI of libpintron_gpu.so)."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpintron_gpu.so")
+
+PGPU_OK, PGPU_EDEVICE, PGPU_ENOMEM, PGPU_EINVAL, PGPU_ENOSPC, PGPU_ERANGE, PGPU_ENOSYS = \
+    0, -5, -12, -22, -28, -34, -38
+ALIGN, GAP, ED, KBAND, LCF, BORDERS, AFFIX = range(7)
+KIND_NAMES = ["ALIGN", "GAP", "ED", "KBAND", "LCF", "BORDERS", "AFFIX"]
+JOB_A_GENOMIC, JOB_B_GENOMIC = 1, 2
+
+
+class DpJob(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("flags", C.c_uint32), ("a_off", C.c_uint64),
+                ("b_off", C.c_uint64), ("a_len", C.c_uint32), ("b_len", C.c_uint32),
+                ("p0", C.c_uint32), ("p1", C.c_uint32), ("p2", C.c_uint32), ("tail", C.c_uint32)]
+
+
+class DpResult(C.Structure):
+    _fields_ = [("status", C.c_int32), ("v", C.c_int32 * 6), ("pad", C.c_int32),
+                ("str", C.c_uint64 * 2)]
+
+
+class GroupInfo(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("kind", C.c_int32), ("pad", C.c_int32),
+                ("jobs", C.c_uint64), ("cells", C.c_uint64), ("algo_bytes", C.c_uint64),
+                ("ms", C.c_double)]
+
+
+class PairingParams(C.Structure):
+    _fields_ = [("min_factor_len", C.c_uint32), ("reserved", C.c_uint32),
+                ("min_string_depth_rate", C.c_double)]
+
+
+class Pairing(C.Structure):
+    _fields_ = [("p", C.c_int32), ("t", C.c_int32), ("l", C.c_int32)]
+
+
+assert C.sizeof(DpJob) == 48 and C.sizeof(DpResult) == 48
+
+# every symbol include/pintron_gpu.h declares
+EXPORTS = [
+    "pgpu_init", "pgpu_destroy", "pgpu_last_error", "pgpu_abi_version",
+    "pgpu_index_build", "pgpu_index_destroy", "pgpu_index_suffix_array", "pgpu_pairings",
+    "pgpu_dp_plan_create", "pgpu_dp_plan_launch", "pgpu_dp_plan_sync",
+    "pgpu_dp_plan_string_bytes", "pgpu_dp_plan_fetch", "pgpu_dp_plan_destroy",
+    "pgpu_dp_plan_cells", "pgpu_dp_plan_algo_bytes", "pgpu_dp_plan_kernel_ms",
+    "pgpu_dp_plan_launches", "pgpu_dp_plan_n_groups", "pgpu_dp_plan_group_info", "pgpu_dp_batch",
+]
+
+_lib = None
+
+
+class PgpuError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("pgpu error %d: %s" % (code, msg))
+        self.code = code
+
+
+def lib():
+    """Load libpintron_gpu.so (no fallback: a missing library is an error)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("%s is missing: run `python -c 'import __graft_entry__ as g; "
+                              "g.build()'` (hipcc --offload-arch=gfx950)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        vp, u64, sz = C.c_void_p, C.c_uint64, C.c_size_t
+        L.pgpu_init.argtypes = [C.c_int, C.POINTER(vp)]
+        L.pgpu_destroy.argtypes = [vp]
+        L.pgpu_last_error.argtypes = [vp]
+        L.pgpu_last_error.restype = C.c_char_p
+        L.pgpu_index_build.argtypes = [vp, C.c_char_p, sz, C.POINTER(vp)]
+        L.pgpu_index_destroy.argtypes = [vp, vp]
+        L.pgpu_index_suffix_array.argtypes = [vp, vp, C.POINTER(C.c_uint32), sz]
+        L.pgpu_pairings.argtypes = [vp, vp, C.c_char_p, C.POINTER(u64), sz,
+                                    C.POINTER(PairingParams), C.POINTER(Pairing), sz,
+                                    C.POINTER(u64), C.POINTER(sz)]
+        L.pgpu_dp_plan_create.argtypes = [vp, vp, C.POINTER(DpJob), sz, C.c_char_p, sz,
+                                          C.POINTER(vp)]
+        L.pgpu_dp_plan_launch.argtypes = [vp, vp]
+        L.pgpu_dp_plan_sync.argtypes = [vp, vp]
+        L.pgpu_dp_plan_string_bytes.argtypes = [vp]
+        L.pgpu_dp_plan_string_bytes.restype = sz
+        L.pgpu_dp_plan_fetch.argtypes = [vp, vp, C.POINTER(DpResult), C.c_char_p, sz]
+        L.pgpu_dp_plan_destroy.argtypes = [vp, vp]
+        for nm in ("pgpu_dp_plan_cells", "pgpu_dp_plan_algo_bytes", "pgpu_dp_plan_launches"):
+            getattr(L, nm).argtypes = [vp, C.c_int]
+            getattr(L, nm).restype = u64
+        L.pgpu_dp_plan_kernel_ms.argtypes = [vp, C.c_int]
+        L.pgpu_dp_plan_kernel_ms.restype = C.c_double
+        L.pgpu_dp_plan_n_groups.argtypes = [vp]
+        L.pgpu_dp_plan_group_info.argtypes = [vp, C.c_int, C.POINTER(GroupInfo)]
+        L.pgpu_dp_batch.argtypes = [vp, vp, C.POINTER(DpJob), sz, C.c_char_p, sz,
+                                    C.POINTER(DpResult), C.c_char_p, sz, C.POINTER(sz)]
+        _lib = L
+    return _lib
+
+
+class Context:
+    """One pgpu_ctx (one HIP stream on one device)."""
+
+    def __init__(self, device=0):
+        self.L = lib()
+        self.h = C.c_void_p()
+        rc = self.L.pgpu_init(device, C.byref(self.h))
+        if rc != PGPU_OK:
+            raise PgpuError(rc, "pgpu_init(%d) failed (no usable gfx950 device?)" % device)
+
+    def check(self, rc):
+        if rc != PGPU_OK:
+            raise PgpuError(rc, self.L.pgpu_last_error(self.h).decode())
+
+    def close(self):
+        if self.h:
+            self.L.pgpu_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+class Index:
+    def __init__(self, ctx: Context, genomic: bytes):
+        self.ctx = ctx
+        self.h = C.c_void_p()
+        self.n = len(genomic)
+        ctx.check(ctx.L.pgpu_index_build(ctx.h, genomic, len(genomic), C.byref(self.h)))
+
+    def suffix_array(self):
+        import numpy as np
+        sa = np.empty(self.n, dtype=np.uint32)
+        self.ctx.check(self.ctx.L.pgpu_index_suffix_array(
+            self.ctx.h, self.h, sa.ctypes.data_as(C.POINTER(C.c_uint32)), self.n))
+        return sa
+
+    def close(self):
+        if self.h:
+            self.ctx.L.pgpu_index_destroy(self.ctx.h, self.h)
+            self.h = C.c_void_p()
+
+
+class JobList:
+    """Accumulates DP jobs and their operand bytes (the arena)."""
+
+    def __init__(self):
+        self.jobs = []
+        self.chunks = []
+        self.size = 0
+
+    def _put(self, b: bytes) -> int:
+        off = self.size
+        self.chunks.append(b)
+        self.size += len(b)
+        return off
+
+    def add(self, kind, a: bytes, b: bytes, p0=0, p1=0, p2=0, b_tail: bytes = b"",
+            a_gen_off=None, b_gen_off=None):
+        """a/b are operand bytes; with *_gen_off the operand is the slice [off, off+len) of the
+        resident genomic instead (a/b then only supply the length)."""
+        flags = 0
+        if a_gen_off is None:
+            a_off = self._put(a)
+        else:
+            a_off, flags = a_gen_off, flags | JOB_A_GENOMIC
+        if b_gen_off is None:
+            b_off = self._put(b + b_tail)
+        else:
+            b_off, flags = b_gen_off, flags | JOB_B_GENOMIC
+        self.jobs.append(DpJob(kind, flags, a_off, b_off, len(a), len(b), p0, p1, p2,
+                               len(b_tail)))
+        return len(self.jobs) - 1
+
+    def arrays(self):
+        arr = (DpJob * max(len(self.jobs), 1))(*self.jobs)
+        return arr, b"".join(self.chunks)
+
+
+class Plan:
+    def __init__(self, ctx: Context, joblist: JobList, index: Index = None):
+        self.ctx = ctx
+        self.n = len(joblist.jobs)
+        self._jobs, self._arena = joblist.arrays()
+        self.h = C.c_void_p()
+        ctx.check(ctx.L.pgpu_dp_plan_create(ctx.h, index.h if index else None, self._jobs, self.n,
+                                            self._arena, len(self._arena), C.byref(self.h)))
+
+    def launch(self):
+        self.ctx.check(self.ctx.L.pgpu_dp_plan_launch(self.ctx.h, self.h))
+
+    def sync(self):
+        self.ctx.check(self.ctx.L.pgpu_dp_plan_sync(self.ctx.h, self.h))
+
+    def fetch(self):
+        L = self.ctx.L
+        nbytes = L.pgpu_dp_plan_string_bytes(self.h)
+        res = (DpResult * max(self.n, 1))()
+        sbuf = C.create_string_buffer(max(nbytes, 1))
+        self.ctx.check(L.pgpu_dp_plan_fetch(self.ctx.h, self.h, res, sbuf, nbytes))
+        return res, sbuf.raw
+
+    def groups(self):
+        L = self.ctx.L
+        out = []
+        for i in range(L.pgpu_dp_plan_n_groups(self.h)):
+            g = GroupInfo()
+            L.pgpu_dp_plan_group_info(self.h, i, C.byref(g))
+            out.append(dict(name=g.name.decode(), kind=g.kind, jobs=g.jobs, cells=g.cells,
+                            algo_bytes=g.algo_bytes, ms=g.ms))
+        return out
+
+    def close(self):
+        if self.h:
+            self.ctx.L.pgpu_dp_plan_destroy(self.ctx.h, self.h)
+            self.h = C.c_void_p()
+
+
+def cstr(buf: bytes, off: int) -> bytes:
+    end = buf.index(b"\0", off)
+    return buf[off:end]
+
+
+def decode(kind, r: DpResult, strings: bytes):
+    """DpResult -> dict with the field names the oracle wrappers (tests/oracle_lib.py) use."""
+    v = r.v
+    if r.status != PGPU_OK:
+        return dict(status=r.status)
+    if kind == ALIGN:
+        return dict(status=0, score=v[0], dim=v[1], ea=cstr(strings, r.str[0]),
+                    ga=cstr(strings, r.str[1]))
+    if kind == GAP:
+        return dict(status=0, dim=v[0], factor_cut=v[1], intron_start=v[2], intron_end=v[3],
+                    intron_start_on_align=v[4], intron_end_on_align=v[5],
+                    ea=cstr(strings, r.str[0]), ga=cstr(strings, r.str[1]))
+    if kind == ED:
+        return dict(status=0, score=v[0])
+    if kind == KBAND:
+        return dict(status=0, ok=v[0], edit=v[1])
+    if kind == LCF:
+        return dict(status=0, len=v[0], occ1=v[1], occ2=v[2])
+    if kind == BORDERS:
+        return dict(status=0, ok=v[0], off_p=v[1], off_t1=v[2], off_t2=v[3], ed=v[4])
+    if kind == AFFIX:
+        return dict(status=0, valid=v[0], ecut=v[1], gcut=v[2])
+    raise ValueError(kind)
+
+
+def run_jobs(ctx: Context, joblist: JobList, index: Index = None):
+    """create + launch + sync + fetch + destroy; returns a list of decoded dicts."""
+    plan = Plan(ctx, joblist, index)
+    try:
+        plan.launch()
+        plan.sync()
+        res, strings = plan.fetch()
+        return [decode(joblist.jobs[i].kind, res[i], strings) for i in range(plan.n)]
+    finally:
+        plan.close()

@@ -1,0 +1,423 @@
+// Host side of libpintron_gpu.so: contexts, batched DP plans, C-ABI entry points.
+// (C++ inside, extern "C" at the boundary; see include/pintron_gpu.h for the contract.)
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "pgpu_internal.h"
+#include "pgpu_index.h"
+
+struct pgpu_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  char err[512] = {0};
+};
+
+static int set_err(pgpu_ctx* ctx, int code, const char* fmt, ...) {
+  if (ctx) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(ctx->err, sizeof(ctx->err), fmt, ap);
+    va_end(ap);
+  }
+  return code;
+}
+
+#define HIP_TRY(ctx, call)                                                                  \
+  do {                                                                                      \
+    hipError_t e_ = (call);                                                                 \
+    if (e_ != hipSuccess)                                                                   \
+      return set_err(ctx, e_ == hipErrorOutOfMemory ? PGPU_ENOMEM : PGPU_EDEVICE,           \
+                     "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+hipStream_t pgpu_ctx_stream(pgpu_ctx* ctx) { return ctx->stream; }
+int pgpu_ctx_fail(pgpu_ctx* ctx, int code, const char* msg) { return set_err(ctx, code, "%s", msg); }
+
+extern "C" int pgpu_abi_version(void) { return 1; }
+
+extern "C" int pgpu_init(int device, pgpu_ctx** out) {
+  if (!out) return PGPU_EINVAL;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return PGPU_EDEVICE;
+  if (device < 0 || device >= n) return PGPU_EINVAL;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return PGPU_EDEVICE;
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return PGPU_EDEVICE;   // gfx950 code objects only
+  if (hipSetDevice(device) != hipSuccess) return PGPU_EDEVICE;
+  pgpu_ctx* ctx = new (std::nothrow) pgpu_ctx();
+  if (!ctx) return PGPU_ENOMEM;
+  ctx->device = device;
+  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete ctx;
+    return PGPU_EDEVICE;
+  }
+  *out = ctx;
+  return PGPU_OK;
+}
+
+extern "C" int pgpu_destroy(pgpu_ctx* ctx) {
+  if (!ctx) return PGPU_EINVAL;
+  hipSetDevice(ctx->device);
+  hipStreamSynchronize(ctx->stream);
+  hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return PGPU_OK;
+}
+
+extern "C" const char* pgpu_last_error(const pgpu_ctx* ctx) { return ctx ? ctx->err : "null context"; }
+
+// ---------------------------------------------------------------------------------------------
+// DP plans
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct Group {
+  int family;            // KernelFamily
+  int kind;              // pgpu_dp_kind the jobs came from
+  int R;                 // row class (0 when not applicable)
+  size_t first, count;   // slice of the sorted device job table
+  uint32_t max_chunks = 0, max_l2 = 0;
+  bool traceback = false;      // this group is the traceback pass of (family)
+  uint64_t cells = 0, algo_bytes = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  float ms = 0.f;
+  std::string name;
+};
+
+uint32_t row_class(uint32_t rows) {         // smallest R in {1,2,4,...,64} with 64*R >= rows
+  uint32_t R = 1;
+  while (64u * R < rows) R <<= 1;
+  return R;
+}
+
+}  // namespace
+
+struct pgpu_dp_plan {
+  size_t n_jobs = 0;
+  std::vector<Group> groups;
+  std::vector<pgpu_dp_result> prefill;       // status for jobs that never reach the device
+  DevJob* d_jobs = nullptr;
+  DevResult* d_results = nullptr;
+  uint8_t* d_arena = nullptr;
+  uint8_t* d_ws = nullptr;
+  uint8_t* d_strs = nullptr;
+  unsigned long long* d_keys = nullptr;
+  size_t n_dev_jobs = 0, ws_bytes = 0, strs_bytes = 0, n_keys = 0;
+  uint64_t cells[PGPU_DP_NKINDS] = {0}, algo_bytes[PGPU_DP_NKINDS] = {0};
+  double ms[PGPU_DP_NKINDS] = {0};
+  uint64_t launches[PGPU_DP_NKINDS] = {0};
+  bool launched = false;
+};
+
+static void plan_free(pgpu_dp_plan* p) {
+  if (!p) return;
+  for (auto& g : p->groups) {
+    if (g.ev0) hipEventDestroy(g.ev0);
+    if (g.ev1) hipEventDestroy(g.ev1);
+  }
+  hipFree(p->d_jobs); hipFree(p->d_results); hipFree(p->d_arena);
+  hipFree(p->d_ws); hipFree(p->d_strs); hipFree(p->d_keys);
+  delete p;
+}
+
+extern "C" int pgpu_dp_plan_create(pgpu_ctx* ctx, const pgpu_index* idx, const pgpu_dp_job* jobs,
+                                   size_t n_jobs, const char* arena, size_t arena_len,
+                                   pgpu_dp_plan** out) {
+  if (!ctx || !out || (n_jobs && !jobs) || (arena_len && !arena)) return set_err(ctx, PGPU_EINVAL, "bad argument");
+  *out = nullptr;
+  if (n_jobs > 0x7fffffffu) return set_err(ctx, PGPU_EINVAL, "too many jobs");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  pgpu_dp_plan* p = new (std::nothrow) pgpu_dp_plan();
+  if (!p) return set_err(ctx, PGPU_ENOMEM, "out of host memory");
+  p->n_jobs = n_jobs;
+  p->prefill.assign(n_jobs, pgpu_dp_result{});
+
+  const uint8_t* d_gen = idx ? pgpu_index_genomic(idx) : nullptr;
+  const size_t gen_len = idx ? pgpu_index_length(idx) : 0;
+
+  // operands live in one HBM arena; resolve every job to device pointers once the arena exists
+  const size_t arena_alloc = arena_len + 16;
+  if (hipMalloc(&p->d_arena, arena_alloc) != hipSuccess) { plan_free(p); return set_err(ctx, PGPU_ENOMEM, "hipMalloc arena (%zu B)", arena_alloc); }
+
+  struct Keyed { DevJob j; int family; int kind; uint32_t R; uint64_t size; };
+  std::vector<Keyed> v;
+  v.reserve(n_jobs);
+  for (size_t i = 0; i < n_jobs; ++i) {
+    const pgpu_dp_job& in = jobs[i];
+    pgpu_dp_result& pre = p->prefill[i];
+    pre.status = PGPU_EINVAL;
+    if (in.kind >= PGPU_DP_NKINDS) continue;
+    const bool ag = in.flags & PGPU_JOB_A_GENOMIC, bg = in.flags & PGPU_JOB_B_GENOMIC;
+    if ((ag || bg) && !d_gen) continue;
+    const size_t a_space = ag ? gen_len : arena_len, b_space = bg ? gen_len : arena_len;
+    if (in.a_off > a_space || in.a_len > a_space - in.a_off) continue;
+    if (in.b_off > b_space || in.b_len > b_space - in.b_off) continue;
+    Keyed k{};
+    k.j.a = (ag ? d_gen : p->d_arena) + in.a_off;
+    k.j.b = (bg ? d_gen : p->d_arena) + in.b_off;
+    k.j.la = in.a_len; k.j.lb = in.b_len;
+    k.j.p0 = in.p0; k.j.p1 = in.p1; k.j.p2 = in.p2; k.j.tail = in.tail;
+    k.j.out_idx = (uint32_t)i;
+    k.kind = (int)in.kind;
+    pre.status = PGPU_ERANGE;
+    const uint32_t la = in.a_len, lb = in.b_len;
+    switch (in.kind) {
+      case PGPU_DP_ALIGN:
+        if (la > PGPU_MAX_ROWS_LEV || lb > PGPU_MAX_COLS) continue;
+        k.family = KF_ALIGN; k.R = row_class(la); k.size = (uint64_t)la * lb; break;
+      case PGPU_DP_GAP:
+        if (la > PGPU_MAX_ROWS_GAP || lb > 16000u || la > 16000u) continue;
+        k.family = KF_GAP; k.R = row_class(la); k.size = (uint64_t)la * lb; break;
+      case PGPU_DP_ED:
+        if (std::min(la, lb) > PGPU_MAX_ROWS_LEV || std::max(la, lb) > PGPU_MAX_COLS) continue;
+        k.family = KF_ED; k.R = row_class(std::min(la, lb)); k.size = (uint64_t)la * lb; break;
+      case PGPU_DP_KBAND: {
+        const uint32_t n = std::max(la, lb), m = std::min(la, lb), ub = in.p0;
+        if (n > PGPU_MAX_COLS) continue;
+        if (ub > 0 && n - m <= ub && 2ull * ub + 1 >= n) {      // full-matrix fallback of the reference
+          if (m > PGPU_MAX_ROWS_LEV) continue;
+          k.family = KF_KBAND_FULL; k.R = row_class(m); k.size = (uint64_t)la * lb;
+        } else {
+          k.family = KF_KBAND; k.R = 0; k.size = (uint64_t)m * (2ull * ub + 1);
+        }
+        break;
+      }
+      case PGPU_DP_LCF:
+        if (lb > 65535u || la >= (1u << 28)) continue;
+        k.family = KF_LCF; k.R = 0; k.size = (uint64_t)la * lb; break;
+      case PGPU_DP_BORDERS:
+        if (la > PGPU_MAX_ROWS_LEV || lb > PGPU_MAX_COLS) continue;
+        if (in.p0 > in.p1 || in.p1 > la) { pre.status = PGPU_EINVAL; continue; }
+        k.family = KF_BORDERS; k.R = row_class(la); k.size = (uint64_t)la * lb; break;
+      case PGPU_DP_AFFIX:
+        if (la > PGPU_MAX_ROWS_LEV || lb > PGPU_MAX_COLS) continue;
+        k.family = KF_AFFIX; k.R = row_class(la); k.size = (uint64_t)la * lb; break;
+      default: continue;
+    }
+    k.j.r_class = k.R;
+    pre.status = PGPU_OK;
+    v.push_back(k);
+  }
+  // order: family, row class, then largest first (long jobs start early; waves of a workgroup
+  // and threads of a traceback wave get similar sizes)
+  std::stable_sort(v.begin(), v.end(), [](const Keyed& x, const Keyed& y) {
+    if (x.family != y.family) return x.family < y.family;
+    if (x.R != y.R) return x.R < y.R;
+    return x.size > y.size;
+  });
+
+  // workspaces and string slots
+  size_t ws = 0, strs = 0, nkeys = 0;
+  for (auto& k : v) {
+    const uint32_t la = k.j.la, lb = k.j.lb;
+    if (k.family == KF_ALIGN) {
+      k.j.ws_off = ws; ws += ((size_t)lb + 64) * 64 * align_entry_bytes(k.R);
+      k.j.str_off = strs; strs += 2 * ((size_t)la + lb + 1);
+    } else if (k.family == KF_GAP) {
+      k.j.ws_off = ws; ws += ((size_t)lb + 64) * 64 * gap_entry_bytes(k.R);
+      k.j.str_off = strs; strs += 2 * ((size_t)la + lb + 1);
+    } else if (k.family == KF_KBAND) {
+      k.j.ws_off = ws; ws += (2 * (2 * (size_t)k.j.p0 + 1) * sizeof(uint32_t) + 15) & ~(size_t)15;
+    } else if (k.family == KF_LCF) {
+      ++nkeys;
+    }
+    ws = (ws + 15) & ~(size_t)15;
+  }
+  p->ws_bytes = ws; p->strs_bytes = strs; p->n_keys = nkeys; p->n_dev_jobs = v.size();
+
+  // launch groups
+  auto cells_of = [](const Keyed& k) -> uint64_t { return k.size; };
+  size_t i = 0;
+  while (i < v.size()) {
+    size_t j = i;
+    Group g{};
+    g.family = v[i].family; g.kind = v[i].kind; g.R = (int)v[i].R; g.first = i;
+    while (j < v.size() && v[j].family == g.family && v[j].R == v[i].R &&
+           (g.family != KF_LCF || j - i < 65535)) {
+      const Keyed& k = v[j];
+      const uint64_t la = k.j.la, lb = k.j.lb;
+      g.cells += (k.family == KF_GAP ? 3 : (k.family == KF_BORDERS ? 2 : 1)) * cells_of(k);
+      // algorithmic HBM bytes: operands once; 1 B/cell of directions for
+      // ALIGN, 3 B/cell for GAP; 8 B per row when row minima are produced
+      g.algo_bytes += la + lb;
+      if (k.family == KF_ALIGN) g.algo_bytes += la * lb;
+      if (k.family == KF_GAP) g.algo_bytes += 3 * la * lb;
+      if (k.family == KF_BORDERS) g.algo_bytes += 2 * 8 * la;
+      if (k.family == KF_LCF) {
+        const uint32_t ch = (uint32_t)((la + lb + 254) / 256);   // ceil((la+lb-1)/256) diagonals
+        g.max_chunks = std::max(g.max_chunks, ch);
+        g.max_l2 = std::max(g.max_l2, (uint32_t)lb);
+      }
+      ++j;
+    }
+    g.count = j - i;
+    char nm[64];
+    static const char* fam[] = {"lev_wave<ALIGN", "gap_wave<", "lev_wave<ED", "kband", "lcf",
+                                "lev_wave<BORDERS", "lev_wave<AFFIX", "lev_wave<ED(kband-full)"};
+    if (g.family == KF_KBAND || g.family == KF_LCF) snprintf(nm, sizeof nm, "%s", fam[g.family]);
+    else snprintf(nm, sizeof nm, "%s%sR=%d>", fam[g.family], g.family == KF_GAP ? "" : ",", g.R);
+    g.name = nm;
+    p->groups.push_back(g);
+    if (g.family == KF_ALIGN || g.family == KF_GAP) {          // traceback pass over the same slice
+      Group t = g;
+      t.traceback = true; t.cells = 0; t.algo_bytes = 0;
+      for (size_t q = g.first; q < g.first + g.count; ++q)
+        t.algo_bytes += 3ull * (v[q].j.la + v[q].j.lb);      // directions read back + two strings
+      t.name = g.family == KF_ALIGN ? "align_traceback" : "gap_traceback";
+      p->groups.push_back(t);
+    }
+    i = j;
+  }
+  for (auto& g : p->groups) {
+    p->cells[g.kind] += g.cells;
+    p->algo_bytes[g.kind] += g.algo_bytes;
+    if (hipEventCreate(&g.ev0) != hipSuccess || hipEventCreate(&g.ev1) != hipSuccess) {
+      plan_free(p);
+      return set_err(ctx, PGPU_EDEVICE, "hipEventCreate failed");
+    }
+  }
+
+  // device allocations + upload
+  auto fail_mem = [&](const char* what, size_t bytes) {
+    plan_free(p);
+    return set_err(ctx, PGPU_ENOMEM, "hipMalloc %s (%zu B) failed", what, bytes);
+  };
+  const size_t nd = std::max<size_t>(v.size(), 1);
+  if (hipMalloc(&p->d_jobs, nd * sizeof(DevJob)) != hipSuccess) return fail_mem("jobs", nd * sizeof(DevJob));
+  if (hipMalloc(&p->d_results, std::max<size_t>(n_jobs, 1) * sizeof(DevResult)) != hipSuccess) return fail_mem("results", n_jobs * sizeof(DevResult));
+  if (hipMalloc(&p->d_ws, ws + 16) != hipSuccess) return fail_mem("workspace", ws);
+  if (hipMalloc(&p->d_strs, strs + 16) != hipSuccess) return fail_mem("strings", strs);
+  if (hipMalloc(&p->d_keys, (nkeys + 1) * sizeof(unsigned long long)) != hipSuccess) return fail_mem("lcf keys", nkeys * 8);
+
+  std::vector<DevJob> hj(v.size());
+  for (size_t q = 0; q < v.size(); ++q) hj[q] = v[q].j;
+  hipError_t e = hipSuccess;
+  if (arena_len) e = hipMemcpyAsync(p->d_arena, arena, arena_len, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess && !hj.empty())
+    e = hipMemcpyAsync(p->d_jobs, hj.data(), hj.size() * sizeof(DevJob), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess && n_jobs)
+    e = hipMemcpyAsync(p->d_results, p->prefill.data(), n_jobs * sizeof(DevResult), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);     // hj / prefill are host temporaries
+  if (e != hipSuccess) { plan_free(p); return set_err(ctx, PGPU_EDEVICE, "upload failed: %s", hipGetErrorString(e)); }
+  *out = p;
+  return PGPU_OK;
+}
+
+extern "C" int pgpu_dp_plan_launch(pgpu_ctx* ctx, pgpu_dp_plan* p) {
+  if (!ctx || !p) return set_err(ctx, PGPU_EINVAL, "bad argument");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  if (p->n_keys) HIP_TRY(ctx, hipMemsetAsync(p->d_keys, 0, p->n_keys * sizeof(unsigned long long), st));
+  size_t key_base = 0;
+  for (auto& g : p->groups) {
+    const DevJob* jobs = p->d_jobs + g.first;
+    const int n = (int)g.count;
+    HIP_TRY(ctx, hipEventRecord(g.ev0, st));
+    if (g.traceback) {
+      if (g.family == KF_ALIGN) launch_align_traceback(jobs, n, p->d_results, p->d_ws, p->d_strs, st);
+      else launch_gap_traceback(jobs, n, p->d_results, p->d_ws, p->d_strs, st);
+    } else switch (g.family) {
+      case KF_ALIGN: case KF_ED: case KF_BORDERS: case KF_AFFIX:
+        launch_lev(g.family, g.R, jobs, n, p->d_results, p->d_ws, st); break;
+      case KF_KBAND_FULL:
+        launch_lev(KF_ED, g.R, jobs, n, p->d_results, p->d_ws, st);
+        launch_kband_full_fixup(jobs, n, p->d_results, st); break;
+      case KF_GAP: launch_gap(g.R, jobs, n, p->d_results, p->d_ws, st); break;
+      case KF_KBAND: launch_kband(jobs, n, p->d_results, p->d_ws, st); break;
+      case KF_LCF:
+        launch_lcf(jobs, n, g.max_chunks, g.max_l2, p->d_keys + key_base, st);
+        launch_lcf_finish(jobs, n, p->d_results, p->d_keys + key_base, st);
+        key_base += g.count; break;
+      default: break;
+    }
+    HIP_TRY(ctx, hipEventRecord(g.ev1, st));
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  p->launched = true;
+  return PGPU_OK;
+}
+
+extern "C" int pgpu_dp_plan_sync(pgpu_ctx* ctx, pgpu_dp_plan* p) {
+  if (!ctx || !p) return set_err(ctx, PGPU_EINVAL, "bad argument");
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (p->launched) {
+    for (int k = 0; k < PGPU_DP_NKINDS; ++k) { p->ms[k] = 0; p->launches[k] = 0; }
+    for (auto& g : p->groups) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, g.ev0, g.ev1) == hipSuccess) g.ms = ms;
+      p->ms[g.kind] += g.ms;
+      p->launches[g.kind] += 1;
+    }
+  }
+  return PGPU_OK;
+}
+
+extern "C" size_t pgpu_dp_plan_string_bytes(const pgpu_dp_plan* p) { return p ? p->strs_bytes : 0; }
+
+extern "C" int pgpu_dp_plan_fetch(pgpu_ctx* ctx, pgpu_dp_plan* p, pgpu_dp_result* results,
+                                  char* strings, size_t cap) {
+  if (!ctx || !p || (p->n_jobs && !results)) return set_err(ctx, PGPU_EINVAL, "bad argument");
+  if (p->strs_bytes && strings && cap < p->strs_bytes) return set_err(ctx, PGPU_ENOSPC, "string buffer too small: need %zu", p->strs_bytes);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (p->n_jobs)
+    HIP_TRY(ctx, hipMemcpyAsync(results, p->d_results, p->n_jobs * sizeof(DevResult), hipMemcpyDeviceToHost, ctx->stream));
+  if (p->strs_bytes && strings)
+    HIP_TRY(ctx, hipMemcpyAsync(strings, p->d_strs, p->strs_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return PGPU_OK;
+}
+
+extern "C" int pgpu_dp_plan_destroy(pgpu_ctx* ctx, pgpu_dp_plan* p) {
+  if (!ctx || !p) return PGPU_EINVAL;
+  hipSetDevice(ctx->device);
+  hipStreamSynchronize(ctx->stream);
+  plan_free(p);
+  return PGPU_OK;
+}
+
+extern "C" uint64_t pgpu_dp_plan_cells(const pgpu_dp_plan* p, int kind) {
+  return (p && kind >= 0 && kind < PGPU_DP_NKINDS) ? p->cells[kind] : 0;
+}
+extern "C" uint64_t pgpu_dp_plan_algo_bytes(const pgpu_dp_plan* p, int kind) {
+  return (p && kind >= 0 && kind < PGPU_DP_NKINDS) ? p->algo_bytes[kind] : 0;
+}
+extern "C" double pgpu_dp_plan_kernel_ms(const pgpu_dp_plan* p, int kind) {
+  return (p && kind >= 0 && kind < PGPU_DP_NKINDS) ? p->ms[kind] : 0.0;
+}
+extern "C" uint64_t pgpu_dp_plan_launches(const pgpu_dp_plan* p, int kind) {
+  return (p && kind >= 0 && kind < PGPU_DP_NKINDS) ? p->launches[kind] : 0;
+}
+
+extern "C" int pgpu_dp_plan_n_groups(const pgpu_dp_plan* p) { return p ? (int)p->groups.size() : 0; }
+
+extern "C" int pgpu_dp_plan_group_info(const pgpu_dp_plan* p, int i, pgpu_group_info* out) {
+  if (!p || !out || i < 0 || i >= (int)p->groups.size()) return PGPU_EINVAL;
+  const Group& g = p->groups[i];
+  memset(out, 0, sizeof(*out));
+  snprintf(out->name, sizeof(out->name), "%s", g.name.c_str());
+  out->kind = g.kind; out->jobs = g.count; out->cells = g.cells; out->algo_bytes = g.algo_bytes;
+  out->ms = g.ms;
+  return PGPU_OK;
+}
+
+extern "C" int pgpu_dp_batch(pgpu_ctx* ctx, const pgpu_index* idx, const pgpu_dp_job* jobs,
+                             size_t n_jobs, const char* arena, size_t arena_len,
+                             pgpu_dp_result* results, char* strings, size_t strings_cap,
+                             size_t* strings_used) {
+  pgpu_dp_plan* p = nullptr;
+  int rc = pgpu_dp_plan_create(ctx, idx, jobs, n_jobs, arena, arena_len, &p);
+  if (rc != PGPU_OK) return rc;
+  if (strings_used) *strings_used = p->strs_bytes;
+  rc = pgpu_dp_plan_launch(ctx, p);
+  if (rc == PGPU_OK) rc = pgpu_dp_plan_sync(ctx, p);
+  if (rc == PGPU_OK) rc = pgpu_dp_plan_fetch(ctx, p, results, strings, strings_cap);
+  pgpu_dp_plan_destroy(ctx, p);
+  return rc;
+}

@@ -1,0 +1,772 @@
+// Hand-written gfx950 (CDNA4, wave64) kernels for the est-fact dynamic programs.
+//
+// Common structure of the Levenshtein-family and gap kernels ("row strips x skewed column sweep"):
+//   * one wavefront (64 lanes) owns one job; a 256-thread workgroup carries four independent jobs;
+//   * lane l keeps R consecutive DP rows (l*R+1 .. l*R+R) of the CURRENT column in registers
+//     (R is a template parameter: 1,2,4,...,64 -> up to 4096 rows);
+//   * the wave sweeps the columns with a skew of one column per lane: at step s lane l works on
+//     column s-l+1, so the anti-diagonal of strips is processed in parallel;
+//   * the only inter-lane traffic per step is ONE 32-bit DPP wave shift (wave_shr:1) that hands
+//     the value of the strip's last row -- packed with the column character, which therefore
+//     travels down the lanes with the wavefront instead of being re-read -- to the lane below;
+//   * traceback directions are packed (2 bits/cell, or 5 bits/cell for the 3-plane gap DP) and
+//     stored step-major, [step][lane], so that every store instruction of the wave writes one
+//     contiguous 64*entry-byte segment of HBM;
+//   * tracebacks run in a second kernel, one THREAD per job: each is a latency-bound pointer
+//     chase, and a batch holds 10^4..10^6 of them, so they are overlapped with each other.
+//
+// Integer/character work only: no MFMA.  Reference routines are cited per kernel; paths are
+// relative to the AlgoLab/PIntron tree.
+#include "pgpu_internal.h"
+
+namespace {
+
+constexpr uint32_t PAD_ROW = 0x01u;   // never equal to a sequence byte nor to PAD_COL
+constexpr uint32_t PAD_COL = 0x02u;
+
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t v) {
+  // DPP wave_shr:1 -- lane l receives lane l-1's v; lane 0 keeps its own (overwritten by caller)
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xf, 0xf, false);
+}
+
+__device__ __forceinline__ bool is_n(uint32_t c) { return c == 'n' || c == 'N'; }
+
+// getBursetFrequency (src/refine-intron.c:376-556) as a table: index = donor[0],donor[1],
+// acceptor[0],acceptor[1] at 2 bits each (A=0,C=1,G=2,T=3).
+__constant__ uint8_t c_burset[256] = {
+    0,   0,   1,   1,   0,   0,   0,   0,   0,   0,   0,   1,   0,   0,   0,   0,
+    0,   0,   0,   0,   0,   1,   0,   0,   0,   0,   0,   0,   0,   0,   0,   0,
+    0,   1,   5,   0,   0,   0,   0,   2,   0,   1,   0,   0,   0,   0,   2,   0,
+    1,   8,   7,   2,   0,   0,   0,   0,   0,   1,   0,   1,   0,   0,   0,   0,
+    0,   0,   1,   0,   0,   0,   0,   0,   0,   0,   0,   0,   0,   0,   0,   1,
+    0,   0,   2,   0,   0,   0,   0,   0,   0,   0,   0,   0,   0,   0,   0,   0,
+    0,   0,   1,   0,   1,   0,   0,   0,   0,   0,   0,   0,   0,   0,   0,   0,
+    0,   2,   0,   0,   1,   0,   0,   0,   0,   0,   0,   0,   0,   0,   0,   0,
+    0,   0,   8,   0,   0,   0,   0,   0,   0,   0,   0,   1,   0,   1,   1,   0,
+    0,   0, 126,   0,   0,   0,   0,   0,   0,   0,   1,   0,   1,   0,   0,   0,
+    0,   1,  11,   0,   1,   0,   0,   0,   2,   0,   0,   0,   0,   2,   0,   0,
+    0,   4, 200,   2,   9,   0,   4,   3,   0,   1,  10,   1,   7,   2,   8,   2,
+    0,   0,   6,   0,   0,   0,   1,   0,   0,   0,   0,   0,   0,   1,   0,   0,
+    0,   0,   1,   0,   0,   0,   0,   0,   0,   0,   1,   0,   0,   0,   0,   0,
+    0,   1,   7,   0,   0,   0,   0,   0,   0,   0,   2,   0,   0,   0,   0,   0,
+    0,   0,   5,   1,   0,   0,   0,   0,   0,   0,   1,   0,   0,   0,   0,   0,
+};
+
+__device__ __forceinline__ int base_code(uint32_t c) {
+  switch (c) {
+    case 'A': case 'a': return 0;
+    case 'C': case 'c': return 1;
+    case 'G': case 'g': return 2;
+    case 'T': case 't': return 3;
+    default: return -1;
+  }
+}
+
+// getBursetFrequency_adaptor (src/refine-intron.c:362-374) over t with `avail` readable bytes
+__device__ int burset_adaptor(const uint8_t* t, uint32_t avail, uint32_t cut1, uint32_t cut2) {
+  if (cut2 < 2) return 0;
+  if (cut1 + 1 >= avail || cut2 - 1 >= avail) return 0;   // a NUL terminates the C string
+  const int c0 = base_code(t[cut1]), c1 = base_code(t[cut1 + 1]);
+  const int c2 = base_code(t[cut2 - 2]), c3 = base_code(t[cut2 - 1]);
+  if ((c0 | c1 | c2 | c3) < 0) return 0;
+  return c_burset[(c0 << 6) | (c1 << 4) | (c2 << 2) | c3];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Levenshtein family
+// ---------------------------------------------------------------------------------------------
+
+struct Operand {            // a string read forwards or backwards
+  const uint8_t* base;
+  uint32_t total;           // length of the underlying buffer (for reversed reads)
+  bool rev;
+  __device__ __forceinline__ uint32_t at(uint32_t i) const {
+    return rev ? base[total - 1 - i] : base[i];
+  }
+};
+
+template <int R> struct DirPack {          // 2 bits per row, R rows
+  static constexpr int WORDS = (R + 15) / 16;
+  uint32_t w[WORDS];
+  __device__ __forceinline__ void clear() {
+#pragma unroll
+    for (int i = 0; i < WORDS; ++i) w[i] = 0;
+  }
+  __device__ __forceinline__ void set(int r, uint32_t d) { w[r / 16] |= d << (2 * (r % 16)); }
+  __device__ __forceinline__ void store(uint8_t* p) const {
+    if constexpr (R <= 4)       *p = (uint8_t)w[0];
+    else if constexpr (R == 8)  *reinterpret_cast<uint16_t*>(p) = (uint16_t)w[0];
+    else if constexpr (R == 16) *reinterpret_cast<uint32_t*>(p) = w[0];
+    else if constexpr (R == 32) *reinterpret_cast<uint2*>(p) = make_uint2(w[0], w[1]);
+    else                        *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+};
+
+struct AffixBest {          // running best cut of find_longest_affix
+  uint32_t valid, v, s, e, g;
+  // true when candidate (cv/cs, ce, cg) replaces (v/s, e, g) under the reference's scan rule:
+  // smaller weight wins, equal weight -> the cell scanned later (larger (e,g)) wins.
+  __device__ __forceinline__ bool worse_than(uint32_t cv, uint32_t cs, uint32_t ce, uint32_t cg) const {
+    if (!valid) return true;
+    const uint64_t lhs = (uint64_t)cv * s, rhs = (uint64_t)v * cs;
+    if (lhs != rhs) return lhs < rhs;
+    return ce > e || (ce == e && cg > g);
+  }
+};
+
+// One column sweep.  On return cur[r] = M[row(l,r)][nc].
+template <int R, bool WILD, bool DIRS, bool ROWMIN, bool AFFIX>
+__device__ __forceinline__ void lev_sweep(const Operand rows, const uint32_t nr,
+                                          const Operand cols, const uint32_t nc,
+                                          const uint32_t lane, uint32_t (&cur)[R],
+                                          uint32_t (&minv)[R], uint32_t (&minpos)[R],
+                                          AffixBest& best, uint8_t* dir_ws) {
+  uint32_t rc[R];                       // row characters of this lane's strip
+  const uint32_t row0 = lane * R;       // rows row0+1 .. row0+R
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const uint32_t i = row0 + r;
+    rc[r] = i < nr ? rows.at(i) : PAD_ROW;
+    cur[r] = i + 1;                     // M[i+1][0]
+    if constexpr (ROWMIN) { minv[r] = i + 1; minpos[r] = 0; }
+  }
+  if (nr == 0 || nc == 0) return;
+  const uint32_t last_lane = (nr - 1) / R;
+  const uint32_t steps = nc + last_lane;
+  uint32_t diag_in = row0;              // M[row0][j-1] for j = 1
+  uint32_t out = 0;                     // (value of the strip's last row) | (column char << 24)
+  uint32_t chunk = 0;
+  constexpr uint32_t EB = R <= 4 ? 1u : R / 4;
+
+  for (uint32_t s = 0; s < steps; ++s) {
+    const uint32_t t = s & 63u;
+    if (t == 0) {                       // refill the column-character window (coalesced 64 B)
+      const uint32_t j = s + lane;
+      chunk = j < nc ? cols.at(j) : PAD_COL;
+    }
+    uint32_t in = wave_shr1(out);
+    const uint32_t ch0 = (uint32_t)__builtin_amdgcn_readlane((int)chunk, (int)t);
+    if (lane == 0) in = (s + 1) | (ch0 << 24);          // M[0][j] = j, j = s+1
+    const uint32_t j = s - lane + 1;                     // column of this lane (wraps when idle)
+    if (j - 1u < nc) {
+      const uint32_t ch = in >> 24;
+      const uint32_t in_val = in & 0xFFFFFFu;
+      uint32_t up = in_val;
+      uint32_t diag = diag_in;
+      const bool ch_n = WILD && is_n(ch);
+      DirPack<R> dp;
+      if constexpr (DIRS) dp.clear();
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const uint32_t left = cur[r];
+        bool match = rc[r] == ch;
+        if constexpr (WILD) match = match || ch_n || is_n(rc[r]);
+        uint32_t v = diag + (match ? 0u : 1u);
+        if constexpr (DIRS) {
+          // ComputeAlignMatrix tie-break: diagonal, then up (dir 1), then left (dir 2), strict >
+          uint32_t d = 0;
+          if (v > up + 1) { v = up + 1; d = 1; }
+          if (v > left + 1) { v = left + 1; d = 2; }
+          dp.set(r, d);
+        } else {
+          v = min(v, min(up + 1, left + 1));
+        }
+        if constexpr (ROWMIN) {
+          if (minv[r] > v) { minv[r] = v; minpos[r] = j; }   // strict: first arg-min
+        }
+        if constexpr (AFFIX) {
+          const uint32_t e = row0 + r + 1, sum = e + j;
+          // cut_weight = 2*v/(e+g) <= 0.17  <=>  200*v <= 17*(e+g)   (exact)
+          if (rc[r] == ch && 200u * v <= 17u * sum && best.worse_than(v, sum, e, j)) {
+            best.valid = 1; best.v = v; best.s = sum; best.e = e; best.g = j;
+          }
+        }
+        diag = left;
+        cur[r] = v;
+        up = v;
+      }
+      diag_in = in_val;
+      out = up | (ch << 24);
+      if constexpr (DIRS) dp.store(dir_ws + ((size_t)s * 64 + lane) * EB);
+    }
+  }
+}
+
+// value of row `row` (1-based) after a sweep, written by the lane that owns it (predicated
+// stores instead of a dynamically indexed register array)
+template <int R>
+__device__ __forceinline__ void store_row_value(const uint32_t (&a)[R], uint32_t lane, uint32_t row,
+                                                int32_t* dst) {
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+    if (lane * R + r + 1 == row) *dst = (int32_t)a[r];
+}
+
+enum { MODE_ED = 0, MODE_ALIGN = 1, MODE_BORDERS = 2, MODE_AFFIX = 3 };
+
+// MODE_ED      edit_distance last cell (src/refine.c:50-83) / compute_edit_distance
+//              (src/compute-alignments.c:240-249)
+// MODE_ALIGN   ComputeAlignMatrix (src/compute-alignments.c:85-147) incl. the equal-string
+//              shortcut of compute_alignment (:48-58); directions go to the workspace
+// MODE_BORDERS general_refine_borders (src/refine.c:105-192)
+// MODE_AFFIX   find_longest_affix (src/factorization-refinement.c:1136-1173)
+template <int R, int MODE>
+__global__ __launch_bounds__(MODE == MODE_BORDERS ? 64 : 256)
+void lev_wave_kernel(const DevJob* __restrict__ jobs, int njobs, DevResult* __restrict__ results,
+                     uint8_t* __restrict__ ws) {
+  constexpr int WAVES = MODE == MODE_BORDERS ? 1 : 4;
+  const uint32_t lane = threadIdx.x & 63u;
+  const int w = blockIdx.x * WAVES + (threadIdx.x >> 6);
+  if (w >= njobs) return;
+  const DevJob job = jobs[w];
+  DevResult* res = &results[job.out_idx];
+  uint32_t cur[R], minv[R], minpos[R];
+  AffixBest best{0, 0, 0, 0, 0};
+
+  if constexpr (MODE == MODE_ED) {
+    // distance is symmetric: keep the shorter string on the rows
+    const bool swap = job.la > job.lb;
+    const Operand rows{swap ? job.b : job.a, 0, false}, cols{swap ? job.a : job.b, 0, false};
+    const uint32_t nr = swap ? job.lb : job.la, nc = swap ? job.la : job.lb;
+    lev_sweep<R, false, false, false, false>(rows, nr, cols, nc, lane, cur, minv, minpos, best, nullptr);
+    if (nr == 0) { if (lane == 0) { res->status = 0; res->v[0] = (int32_t)nc; } return; }
+    store_row_value<R>(cur, lane, nr, &res->v[0]);
+    if (lane == 0) res->status = 0;
+  } else if constexpr (MODE == MODE_ALIGN) {
+    const uint32_t n = job.la, m = job.lb;
+    bool same = n == m;
+    if (same) for (uint32_t i = lane; i < n; i += 64) same = same && job.a[i] == job.b[i];
+    if (__all(same)) {                   // identity alignment, score 0 (compute-alignments.c:48-58)
+      if (lane == 0) { res->status = 0; res->v[0] = 0; res->v[1] = (int32_t)n; res->v[5] = 1; }
+      return;
+    }
+    const Operand rows{job.a, 0, false}, cols{job.b, 0, false};
+    lev_sweep<R, true, true, false, false>(rows, n, cols, m, lane, cur, minv, minpos, best, ws + job.ws_off);
+    if (n == 0 || m == 0) { if (lane == 0) { res->status = 0; res->v[0] = (int32_t)(n + m); res->v[5] = 0; } return; }
+    store_row_value<R>(cur, lane, n, &res->v[0]);
+    if (lane == 0) { res->status = 0; res->v[5] = 0; }
+  } else if constexpr (MODE == MODE_BORDERS) {
+    extern __shared__ uint32_t lds[];    // pre[], pre_pos[], suf[], suf_pos[], each len_p+1
+    const uint32_t len_p = job.la, len_t = job.lb, max_errs = job.p2;
+    const uint32_t t_win = min(len_p + max_errs, len_t);
+    uint32_t* pre = lds; uint32_t* pre_pos = pre + (len_p + 1);
+    uint32_t* suf = pre_pos + (len_p + 1); uint32_t* suf_pos = suf + (len_p + 1);
+    {
+      const Operand rows{job.a, len_p, false}, cols{job.b, len_t, false};
+      lev_sweep<R, false, false, true, false>(rows, len_p, cols, t_win, lane, cur, minv, minpos, best, nullptr);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const uint32_t i = lane * R + r + 1;
+        if (i <= len_p) { pre[i] = minv[r]; pre_pos[i] = minpos[r]; }
+      }
+    }
+    {
+      const Operand rows{job.a, len_p, true}, cols{job.b, len_t, true};
+      lev_sweep<R, false, false, true, false>(rows, len_p, cols, t_win, lane, cur, minv, minpos, best, nullptr);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const uint32_t i = lane * R + r + 1;
+        if (i <= len_p) { suf[i] = minv[r]; suf_pos[i] = minpos[r]; }
+      }
+    }
+    if (lane == 0) { pre[0] = 0; pre_pos[0] = 0; suf[0] = 0; suf_pos[0] = 0; }
+    __syncthreads();
+    if (lane == 0) {                     // cut scan of src/refine.c:161-178 (<= len_p+1 steps)
+      const uint32_t avail = len_t + min(job.tail, 2u);
+      const uint32_t lo = job.p0, hi = job.p1;
+      uint32_t off_p = lo, off_t1 = pre_pos[lo], off_t2 = suf_pos[len_p - lo];
+      uint32_t bestv = pre[lo] + suf[len_p - lo];
+      int best_freq = burset_adaptor(job.b, avail, off_t1, len_t - off_t2);
+      for (uint32_t i = lo + 1; i <= hi; ++i) {
+        const int freq = burset_adaptor(job.b, avail, pre_pos[i], len_t - suf_pos[len_p - i]);
+        const uint32_t c = pre[i] + suf[len_p - i];
+        if (bestv > c || (bestv == c && freq > best_freq)) {
+          bestv = c; off_p = i; off_t1 = pre_pos[i]; off_t2 = suf_pos[len_p - i]; best_freq = freq;
+        }
+      }
+      res->status = 0;
+      res->v[0] = bestv <= max_errs ? 1 : 0;
+      res->v[1] = (int32_t)off_p; res->v[2] = (int32_t)off_t1;
+      res->v[3] = (int32_t)(len_t - off_t2); res->v[4] = (int32_t)bestv;
+    }
+  } else {  // MODE_AFFIX
+    const Operand rows{job.a, 0, false}, cols{job.b, 0, false};
+    lev_sweep<R, false, false, false, true>(rows, job.la, cols, job.lb, lane, cur, minv, minpos, best, nullptr);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {       // wave-wide arg-best
+      AffixBest o;
+      o.valid = __shfl_xor(best.valid, off); o.v = __shfl_xor(best.v, off);
+      o.s = __shfl_xor(best.s, off); o.e = __shfl_xor(best.e, off); o.g = __shfl_xor(best.g, off);
+      if (o.valid && best.worse_than(o.v, o.s, o.e, o.g)) best = o;
+    }
+    if (lane == 0) {
+      res->status = 0; res->v[0] = (int32_t)best.valid;
+      res->v[1] = (int32_t)best.e; res->v[2] = (int32_t)best.g;
+    }
+  }
+}
+
+// TracebackAlignment (src/compute-alignments.c:149-207), one thread per job.  Strings are
+// written back-to-front into the job's slot so no reversal pass is needed.
+__global__ __launch_bounds__(64)
+void align_traceback_kernel(const DevJob* __restrict__ jobs, int njobs,
+                            DevResult* __restrict__ results, const uint8_t* __restrict__ ws,
+                            uint8_t* __restrict__ strs) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= njobs) return;
+  const DevJob job = jobs[t];
+  DevResult* res = &results[job.out_idx];
+  const uint32_t n = job.la, m = job.lb, cap = n + m + 1;
+  uint8_t* ea = strs + job.str_off;
+  uint8_t* ga = ea + cap;
+  if (res->v[5] == 1) {                  // identity alignment
+    for (uint32_t i = 0; i < n; ++i) { ea[i] = job.a[i]; ga[i] = job.b[i]; }
+    ea[n] = 0; ga[n] = 0;
+    res->v[1] = (int32_t)n;
+    res->str[0] = job.str_off; res->str[1] = job.str_off + cap;
+    res->v[5] = 0;
+    return;
+  }
+  const uint32_t R = job.r_class, EB = R <= 4 ? 1u : R / 4;
+  const uint8_t* dirs = ws + job.ws_off;
+  uint32_t i = n, j = m, k = 0;
+  uint32_t pos = cap - 1;
+  ea[pos] = 0; ga[pos] = 0;
+  while (i > 0 && j > 0) {
+    const uint32_t l = (i - 1) / R, r = (i - 1) % R, s = (j - 1) + l;
+    const uint32_t d = (dirs[((size_t)s * 64 + l) * EB + (r >> 2)] >> (2 * (r & 3))) & 3u;
+    --pos;
+    if (d == 0)      { ea[pos] = job.a[--i]; ga[pos] = job.b[--j]; }
+    else if (d == 1) { ea[pos] = job.a[--i]; ga[pos] = '-'; }
+    else             { ea[pos] = '-';        ga[pos] = job.b[--j]; }
+    ++k;
+  }
+  while (i > 0) { --pos; ea[pos] = job.a[--i]; ga[pos] = '-'; ++k; }
+  while (j > 0) { --pos; ea[pos] = '-'; ga[pos] = job.b[--j]; ++k; }
+  res->v[1] = (int32_t)k;
+  res->str[0] = job.str_off + pos;
+  res->str[1] = job.str_off + cap + pos;
+}
+
+// ---------------------------------------------------------------------------------------------
+// 3-state gap alignment: ComputeGapAlignMatrix with only_one_align (src/refine-intron.c:623-824)
+// ---------------------------------------------------------------------------------------------
+template <int R>
+__global__ __launch_bounds__(256)
+void gap_wave_kernel(const DevJob* __restrict__ jobs, int njobs, DevResult* __restrict__ results,
+                     uint8_t* __restrict__ ws) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= njobs) return;
+  const DevJob job = jobs[w];
+  DevResult* res = &results[job.out_idx];
+  const uint32_t n = job.la, m = job.lb;
+  int32_t cL[R], cG[R], cR[R];
+  uint32_t rc[R];
+  const uint32_t row0 = lane * R;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    rc[r] = row0 + r < n ? job.a[row0 + r] : PAD_ROW;
+    cL[r] = 0; cG[r] = 0; cR[r] = 0;                       // column 0 of every plane is 0
+  }
+  if (n > 0 && m > 0) {
+    const uint32_t last_lane = (n - 1) / R, steps = m + last_lane;
+    int32_t dgL = 0, dgR = 0;                               // row above the strip, previous column
+    uint32_t out = 0, outc = 0, chunk = 0;
+    uint8_t* dirs = ws + job.ws_off;
+    for (uint32_t s = 0; s < steps; ++s) {
+      const uint32_t t = s & 63u;
+      if (t == 0) { const uint32_t j = s + lane; chunk = j < m ? job.b[j] : PAD_COL; }
+      uint32_t in = wave_shr1(out);
+      uint32_t inc = wave_shr1(outc);
+      const uint32_t ch0 = (uint32_t)__builtin_amdgcn_readlane((int)chunk, (int)t);
+      if (lane == 0) { in = 0; inc = ch0; }                 // row 0 of L and R is 0
+      const uint32_t j = s - lane + 1;
+      if (j - 1u < m) {
+        const uint32_t ch = inc;
+        const int32_t inL = (int32_t)(int16_t)(in & 0xFFFFu), inR = (int32_t)(int16_t)(in >> 16);
+        int32_t upL = inL, upR = inR, diagL = dgL, diagR = dgR;
+        const bool ch_n = is_n(ch);
+        uint32_t packed[(R + 3) / 4];
+#pragma unroll
+        for (int q = 0; q < (R + 3) / 4; ++q) packed[q] = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int32_t leftL = cL[r], leftG = cG[r], leftR = cR[r];
+          const int32_t sub = (rc[r] == ch || ch_n || is_n(rc[r])) ? 1 : -1;
+          // L plane: diag, up (1), left (2); strict '<' replaces
+          int32_t v = diagL + sub; uint32_t dl = 0;
+          if (v < upL - 1) { v = upL - 1; dl = 1; }
+          if (v < leftL - 1) { v = leftL - 1; dl = 2; }
+          // G plane: stay (2) or enter from L (-2)
+          int32_t g = leftG; uint32_t dg = 0;
+          if (g < leftL) { g = leftL; dg = 1; }
+          // R plane: diag, left (2; free in the last EST row), from G (-2), up (1)
+          int32_t rv = diagR + sub; uint32_t dr = 0;
+          const int32_t lc = (row0 + r + 1 != n) ? leftR - 1 : leftR;
+          if (rv < lc) { rv = lc; dr = 2; }
+          if (rv < leftG) { rv = leftG; dr = 3; }
+          if (rv < upR - 1) { rv = upR - 1; dr = 1; }
+          packed[r / 4] |= (dl | (dg << 2) | (dr << 3)) << (8 * (r % 4));
+          diagL = leftL; diagR = leftR;
+          cL[r] = v; cG[r] = g; cR[r] = rv;
+          upL = v; upR = rv;
+        }
+        dgL = inL; dgR = inR;
+        out = ((uint32_t)upL & 0xFFFFu) | ((uint32_t)upR << 16);
+        outc = ch;
+        uint8_t* p = dirs + ((size_t)s * 64 + lane) * R;
+        if constexpr (R == 1)      *p = (uint8_t)packed[0];
+        else if constexpr (R == 2) *reinterpret_cast<uint16_t*>(p) = (uint16_t)packed[0];
+        else if constexpr (R == 4) *reinterpret_cast<uint32_t*>(p) = packed[0];
+        else if constexpr (R == 8) *reinterpret_cast<uint2*>(p) = make_uint2(packed[0], packed[1]);
+        else {
+#pragma unroll
+          for (int q = 0; q < R / 16; ++q)
+            reinterpret_cast<uint4*>(p)[q] =
+                make_uint4(packed[4 * q], packed[4 * q + 1], packed[4 * q + 2], packed[4 * q + 3]);
+        }
+      }
+    }
+  }
+  // start plane (src/refine-intron.c:808-819); with n==0 or m==0 every plane is 0 -> R
+  if (n == 0 || m == 0) {
+    if (lane == 0) { res->status = 0; res->pad = 2; }
+    return;
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    if (row0 + r + 1 == n) {
+      const int32_t fl = cL[r], fg = cG[r], fr = cR[r];
+      int plane;
+      if (fr >= fg) plane = fr >= fl ? 2 : 0; else plane = fg >= fl ? 1 : 0;
+      res->status = 0;
+      res->pad = plane;
+    }
+  }
+}
+
+// TracebackGapAlignment (src/refine-intron.c:828-890), one thread per job.
+__global__ __launch_bounds__(64)
+void gap_traceback_kernel(const DevJob* __restrict__ jobs, int njobs,
+                          DevResult* __restrict__ results, const uint8_t* __restrict__ ws,
+                          uint8_t* __restrict__ strs) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= njobs) return;
+  const DevJob job = jobs[t];
+  DevResult* res = &results[job.out_idx];
+  const uint32_t n = job.la, m = job.lb, cap = n + m + 1, R = job.r_class;
+  uint8_t* ea = strs + job.str_off;
+  uint8_t* ga = ea + cap;
+  const uint8_t* dirs = ws + job.ws_off;
+  int plane = res->pad;
+  int32_t factor_cut = 0, intron_start = 0, intron_end = 0;
+  int32_t rev_end = -1, rev_start = -1;
+  uint32_t i = n, j = m, k = 0, pos = cap - 1;
+  ea[pos] = 0; ga[pos] = 0;
+  while (i > 0 && j > 0) {
+    const uint32_t l = (i - 1) / R, r = (i - 1) % R, s = (j - 1) + l;
+    const uint32_t b = dirs[((size_t)s * 64 + l) * R + r];
+    // decode to the reference's direction values: 0, 1, 2, or -2 (here 3)
+    uint32_t d;
+    if (plane == 2) d = (b >> 3) & 3u;
+    else if (plane == 1) d = ((b >> 2) & 1u) ? 3u : 2u;
+    else d = b & 3u;
+    --pos;
+    if (d == 0)      { ea[pos] = job.a[--i]; ga[pos] = job.b[--j]; }
+    else if (d == 1) { ea[pos] = job.a[--i]; ga[pos] = '-'; }
+    else {
+      if (d == 3) {
+        if (plane == 2) { intron_end = (int32_t)j - 1; factor_cut = (int32_t)i; rev_end = (int32_t)k; }
+        else            { intron_start = (int32_t)j - 1; rev_start = (int32_t)k; }
+        --plane;
+      }
+      ea[pos] = '-'; ga[pos] = job.b[--j];
+    }
+    ++k;
+  }
+  while (i > 0) { --pos; ea[pos] = job.a[--i]; ga[pos] = '-'; ++k; }
+  while (j > 0) { --pos; ea[pos] = '-'; ga[pos] = job.b[--j]; ++k; }
+  res->v[0] = (int32_t)k;
+  res->v[1] = factor_cut; res->v[2] = intron_start; res->v[3] = intron_end;
+  res->v[4] = rev_start >= 0 ? (int32_t)k - 1 - rev_start : 0;
+  res->v[5] = rev_end >= 0 ? (int32_t)k - 1 - rev_end : 0;
+  res->pad = 0;
+  res->str[0] = job.str_off + pos;
+  res->str[1] = job.str_off + cap + pos;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K-band edit distance: K_band_edit_distance (src/compute-alignments.c:319-453).
+// One thread per job (bands are 2k+1 <= a few dozen cells wide and there are ~10 jobs per EST);
+// the two rolling band rows live in a per-job HBM scratch (L1/L2 resident).  The loops mirror
+// the reference's three row ranges exactly, including which slots each row writes.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64)
+void kband_kernel(const DevJob* __restrict__ jobs, int njobs, DevResult* __restrict__ results,
+                  uint8_t* __restrict__ ws) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= njobs) return;
+  const DevJob job = jobs[t];
+  DevResult* res = &results[job.out_idx];
+  res->status = 0;
+  const uint32_t ub = job.p0;
+  uint32_t n = job.la, m = job.lb;
+  const uint8_t* lng = job.a; const uint8_t* sht = job.b;
+  bool same = n == m;
+  for (uint32_t i = 0; same && i < n; ++i) same = lng[i] == sht[i];
+  if (same) { res->v[0] = 1; res->v[1] = 0; return; }
+  if (ub == 0) { res->v[0] = 0; res->v[1] = 1; return; }
+  if (n < m) { const uint8_t* p = lng; lng = sht; sht = p; const uint32_t x = n; n = m; m = x; }
+  if (n - m > ub) { res->v[0] = 0; res->v[1] = (int32_t)(n - m); return; }
+  const uint32_t k = ub;
+  // (2k+1 >= n falls back to the full matrix in the reference; the host routes those jobs to the
+  //  Levenshtein wave kernel and patches v[0], so they never reach this kernel)
+  const uint32_t W = 2 * k + 1;
+  uint32_t* A = reinterpret_cast<uint32_t*>(ws + job.ws_off);
+  uint32_t* B = A + W;
+  for (uint32_t c = 0; c < W; ++c) { A[c] = 0; B[c] = k + 1; }
+  for (uint32_t c = 0; c <= k; ++c) A[k + c] = c;
+  uint32_t d;
+  for (uint32_t r = 1; r <= k; ++r) {
+    const uint32_t sc = sht[r - 1];
+    B[k - r] = r;
+    for (uint32_t c = 1; c < r + k; ++c) {
+      d = A[k - r + c] + (lng[c - 1] != sc);
+      d = min(d, B[k - r + c - 1] + 1);
+      d = min(d, A[k - r + c + 1] + 1);
+      B[k - r + c] = d;
+    }
+    d = A[2 * k] + (lng[r + k - 1] != sc);
+    d = min(d, B[2 * k - 1] + 1);
+    B[2 * k] = d;
+    uint32_t* x = A; A = B; B = x;
+  }
+  for (uint32_t r = k + 1; r <= n - k; ++r) {
+    const uint32_t sc = sht[r - 1];
+    d = A[0] + (lng[r - k - 1] != sc);
+    B[0] = min(d, A[1] + 1);
+    for (uint32_t c = r + 1 - k; c < r + k; ++c) {
+      d = A[c + k - r] + (lng[c - 1] != sc);
+      d = min(d, B[c + k - r - 1] + 1);
+      d = min(d, A[c + k - r + 1] + 1);
+      B[c + k - r] = d;
+    }
+    d = A[2 * k] + (lng[r + k - 1] != sc);
+    d = min(d, B[2 * k - 1] + 1);
+    B[2 * k] = d;
+    uint32_t* x = A; A = B; B = x;
+  }
+  for (uint32_t r = n + 1 - k; r <= m; ++r) {
+    const uint32_t sc = sht[r - 1];
+    d = A[0] + (lng[r - k - 1] != sc);
+    B[0] = min(d, A[1] + 1);
+    for (uint32_t c = r + 1 - k; c <= n; ++c) {
+      d = A[c + k - r] + (lng[c - 1] != sc);
+      d = min(d, B[c + k - r - 1] + 1);
+      d = min(d, A[c + k - r + 1] + 1);
+      B[c + k - r] = d;
+    }
+    uint32_t* x = A; A = B; B = x;
+  }
+  const uint32_t result = A[n + k - m];
+  res->v[0] = result <= ub ? 1 : 0;
+  res->v[1] = (int32_t)result;
+}
+
+// K_band_edit_distance jobs with 2k+1 >= n use the full matrix in the reference
+// (src/compute-alignments.c:370-373).  They run through the Levenshtein wave kernel (v[0] =
+// distance); this pass rewrites the result the way the reference's early exits order it:
+// equal strings -> (0,true); upper_bound 0 -> (1,false); |n-m| > ub -> (|n-m|,false).
+__global__ void kband_full_fixup_kernel(const DevJob* __restrict__ jobs, int njobs,
+                                        DevResult* __restrict__ results) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= njobs) return;
+  const DevJob job = jobs[t];
+  DevResult* res = &results[job.out_idx];
+  const uint32_t dist = (uint32_t)res->v[0], ub = job.p0;
+  const uint32_t diff = job.la > job.lb ? job.la - job.lb : job.lb - job.la;
+  uint32_t edit; int ok;
+  if (dist == 0) { edit = 0; ok = 1; }
+  else if (ub == 0) { edit = 1; ok = 0; }
+  else if (diff > ub) { edit = diff; ok = 0; }
+  else { edit = dist; ok = dist <= ub; }
+  res->v[0] = ok; res->v[1] = (int32_t)edit;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Longest common factor with N wildcard: find_longest_common_factor_dp
+// (src/factorization-refinement.c:255-316).  curr[i2+1] = match ? prev[i2]+1 : 0 only couples
+// cells of one diagonal, so the l1+l2-1 diagonals are independent: one thread per diagonal,
+// 256 diagonals per workgroup, a tile of s1 and the whole of s2 staged in LDS.  The reference
+// keeps the FIRST maximum in (i1,i2) scan order == among maximal runs the smallest start in s1,
+// then in s2; that order is folded into a 64-bit key reduced with atomicMax.
+// ---------------------------------------------------------------------------------------------
+constexpr int LCF_BLOCK = 256;
+constexpr uint32_t LCF_MAX_L2 = 65535u;
+
+__device__ __forceinline__ unsigned long long lcf_key(uint32_t len, uint32_t occ1, uint32_t occ2) {
+  return ((unsigned long long)len << 44) | ((unsigned long long)(0x0FFFFFFFu - occ1) << 16) |
+         (unsigned long long)(0xFFFFu - occ2);
+}
+
+__global__ __launch_bounds__(LCF_BLOCK)
+void lcf_kernel(const DevJob* __restrict__ jobs, int njobs, unsigned long long* __restrict__ keys) {
+  extern __shared__ uint8_t lcf_lds[];         // [s2: l2 bytes][s1 tile: LCF_BLOCK + l2 bytes]
+  const DevJob job = jobs[blockIdx.y];
+  const uint32_t l1 = job.la, l2 = job.lb;
+  if (l1 == 0 || l2 == 0) return;
+  uint8_t* s2 = lcf_lds;
+  uint8_t* tile = lcf_lds + ((l2 + 15u) & ~15u);
+  for (uint32_t i = threadIdx.x; i < l2; i += LCF_BLOCK) s2[i] = job.b[i];
+  const uint32_t ndiag = l1 + l2 - 1;
+  const uint32_t nchunks = (ndiag + LCF_BLOCK - 1) / LCF_BLOCK;
+  unsigned long long best = 0;
+  for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    // diagonal index dg in [0, ndiag): i1 - i2 = dg - (l2-1).  This chunk covers s1 positions
+    // [base, base + LCF_BLOCK + l2 - 1) where base = chunk*LCF_BLOCK - (l2-1) (may be negative)
+    const int64_t base = (int64_t)chunk * LCF_BLOCK - (int64_t)(l2 - 1);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < LCF_BLOCK + l2 - 1; i += LCF_BLOCK) {
+      const int64_t g = base + i;
+      tile[i] = (g >= 0 && g < (int64_t)l1) ? job.a[g] : 0;
+    }
+    __syncthreads();
+    const uint32_t dg = chunk * LCF_BLOCK + threadIdx.x;
+    if (dg < ndiag) {
+      // cells of this diagonal: i2 from max(0, l2-1-dg), i1 = i2 + dg - (l2-1)
+      const uint32_t i2_lo = dg < l2 - 1 ? l2 - 1 - dg : 0;
+      const int64_t shift = (int64_t)dg - (int64_t)(l2 - 1);       // i1 - i2
+      uint32_t i2_hi = l2;                                          // exclusive
+      if ((int64_t)l1 - shift < (int64_t)i2_hi) i2_hi = (uint32_t)((int64_t)l1 - shift);
+      uint32_t run = 0, brun = 0, bend = 0;
+      for (uint32_t i2 = i2_lo; i2 < i2_hi; ++i2) {
+        const uint32_t c1 = tile[threadIdx.x + i2];                // s1[i2 + shift] = tile[i2+shift-base]
+        const uint32_t c2 = s2[i2];
+        run = (c1 == c2 || is_n(c1) || is_n(c2)) ? run + 1 : 0;
+        if (run > brun) { brun = run; bend = i2; }
+      }
+      if (brun > 0) {
+        const uint32_t occ2 = bend + 1 - brun;
+        const uint32_t occ1 = (uint32_t)((int64_t)occ2 + shift);
+        const unsigned long long key = lcf_key(brun, occ1, occ2);
+        best = key > best ? key : best;
+      }
+    }
+  }
+  // workgroup reduction, one atomic per workgroup
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const unsigned long long o = __shfl_xor(best, off);
+    best = o > best ? o : best;
+  }
+  __shared__ unsigned long long wbest[LCF_BLOCK / 64];
+  if ((threadIdx.x & 63) == 0) wbest[threadIdx.x >> 6] = best;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int wv = 1; wv < LCF_BLOCK / 64; ++wv) best = wbest[wv] > best ? wbest[wv] : best;
+    if (best) atomicMax(&keys[blockIdx.y], best);
+  }
+}
+
+__global__ void lcf_finish_kernel(const DevJob* __restrict__ jobs, int njobs,
+                                  DevResult* __restrict__ results,
+                                  const unsigned long long* __restrict__ keys) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= njobs) return;
+  DevResult* res = &results[jobs[t].out_idx];
+  const unsigned long long key = keys[t];
+  res->status = 0;
+  if (key == 0) { res->v[0] = 0; res->v[1] = 0; res->v[2] = 0; return; }
+  res->v[0] = (int32_t)(key >> 44);
+  res->v[1] = (int32_t)(0x0FFFFFFFu - (uint32_t)((key >> 16) & 0x0FFFFFFFu));
+  res->v[2] = (int32_t)(0xFFFFu - (uint32_t)(key & 0xFFFFu));
+}
+
+template <int MODE, int R>
+void launch_lev_r(const DevJob* jobs, int njobs, DevResult* res, uint8_t* ws, hipStream_t st) {
+  if constexpr (MODE == MODE_BORDERS) {
+    const size_t lds = 4 * (64 * R + 1) * sizeof(uint32_t);
+    hipLaunchKernelGGL((lev_wave_kernel<R, MODE>), dim3(njobs), dim3(64), lds, st, jobs, njobs, res, ws);
+  } else {
+    hipLaunchKernelGGL((lev_wave_kernel<R, MODE>), dim3((njobs + 3) / 4), dim3(256), 0, st, jobs, njobs, res, ws);
+  }
+}
+
+template <int MODE>
+void launch_lev_mode(int R, const DevJob* jobs, int njobs, DevResult* res, uint8_t* ws, hipStream_t st) {
+  switch (R) {
+    case 1:  launch_lev_r<MODE, 1>(jobs, njobs, res, ws, st); break;
+    case 2:  launch_lev_r<MODE, 2>(jobs, njobs, res, ws, st); break;
+    case 4:  launch_lev_r<MODE, 4>(jobs, njobs, res, ws, st); break;
+    case 8:  launch_lev_r<MODE, 8>(jobs, njobs, res, ws, st); break;
+    case 16: launch_lev_r<MODE, 16>(jobs, njobs, res, ws, st); break;
+    case 32: launch_lev_r<MODE, 32>(jobs, njobs, res, ws, st); break;
+    default: launch_lev_r<MODE, 64>(jobs, njobs, res, ws, st); break;
+  }
+}
+
+}  // namespace
+
+void launch_lev(int family, int R, const DevJob* jobs, int njobs, DevResult* res, uint8_t* ws,
+                hipStream_t st) {
+  if (njobs <= 0) return;
+  switch (family) {
+    case KF_ED:      launch_lev_mode<MODE_ED>(R, jobs, njobs, res, ws, st); break;
+    case KF_ALIGN:   launch_lev_mode<MODE_ALIGN>(R, jobs, njobs, res, ws, st); break;
+    case KF_BORDERS: launch_lev_mode<MODE_BORDERS>(R, jobs, njobs, res, ws, st); break;
+    case KF_AFFIX:   launch_lev_mode<MODE_AFFIX>(R, jobs, njobs, res, ws, st); break;
+    default: break;
+  }
+}
+
+void launch_align_traceback(const DevJob* jobs, int njobs, DevResult* res, const uint8_t* ws,
+                            uint8_t* strs, hipStream_t st) {
+  if (njobs <= 0) return;
+  hipLaunchKernelGGL(align_traceback_kernel, dim3((njobs + 63) / 64), dim3(64), 0, st, jobs, njobs, res, ws, strs);
+}
+
+void launch_gap(int R, const DevJob* jobs, int njobs, DevResult* res, uint8_t* ws, hipStream_t st) {
+  if (njobs <= 0) return;
+  const dim3 grid((njobs + 3) / 4), block(256);
+  switch (R) {
+    case 1:  hipLaunchKernelGGL(gap_wave_kernel<1>, grid, block, 0, st, jobs, njobs, res, ws); break;
+    case 2:  hipLaunchKernelGGL(gap_wave_kernel<2>, grid, block, 0, st, jobs, njobs, res, ws); break;
+    case 4:  hipLaunchKernelGGL(gap_wave_kernel<4>, grid, block, 0, st, jobs, njobs, res, ws); break;
+    case 8:  hipLaunchKernelGGL(gap_wave_kernel<8>, grid, block, 0, st, jobs, njobs, res, ws); break;
+    case 16: hipLaunchKernelGGL(gap_wave_kernel<16>, grid, block, 0, st, jobs, njobs, res, ws); break;
+    default: hipLaunchKernelGGL(gap_wave_kernel<32>, grid, block, 0, st, jobs, njobs, res, ws); break;
+  }
+}
+
+void launch_gap_traceback(const DevJob* jobs, int njobs, DevResult* res, const uint8_t* ws,
+                          uint8_t* strs, hipStream_t st) {
+  if (njobs <= 0) return;
+  hipLaunchKernelGGL(gap_traceback_kernel, dim3((njobs + 63) / 64), dim3(64), 0, st, jobs, njobs, res, ws, strs);
+}
+
+void launch_kband(const DevJob* jobs, int njobs, DevResult* res, uint8_t* ws, hipStream_t st) {
+  if (njobs <= 0) return;
+  hipLaunchKernelGGL(kband_kernel, dim3((njobs + 63) / 64), dim3(64), 0, st, jobs, njobs, res, ws);
+}
+
+void launch_lcf(const DevJob* jobs, int njobs, uint32_t max_chunks, uint32_t max_l2,
+                unsigned long long* keys, hipStream_t st) {
+  if (njobs <= 0) return;
+  // grid.y = job (<= 65535 per launch, the caller slices), grid.x strides over diagonal chunks
+  const uint32_t gx = max_chunks < 64u ? (max_chunks ? max_chunks : 1u) : 64u;
+  // LDS: s2 (rounded to 16) + s1 tile (256 + l2 - 1), sized for the largest l2 of the launch
+  const size_t lds = ((max_l2 + 15u) & ~15u) + LCF_BLOCK + max_l2;
+  hipLaunchKernelGGL(lcf_kernel, dim3(gx, njobs), dim3(LCF_BLOCK), lds, st, jobs, njobs, keys);
+}
+
+void launch_kband_full_fixup(const DevJob* jobs, int njobs, DevResult* res, hipStream_t st) {
+  if (njobs <= 0) return;
+  hipLaunchKernelGGL(kband_full_fixup_kernel, dim3((njobs + 255) / 256), dim3(256), 0, st, jobs, njobs, res);
+}
+
+void launch_lcf_finish(const DevJob* jobs, int njobs, DevResult* res,
+                       const unsigned long long* keys, hipStream_t st) {
+  if (njobs <= 0) return;
+  hipLaunchKernelGGL(lcf_finish_kernel, dim3((njobs + 255) / 256), dim3(256), 0, st, jobs, njobs, res, keys);
+}

@@ -1,0 +1,13 @@
+// Internal view of the genomic index (pgpu_index.hip).
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+#include <hip/hip_runtime.h>
+#include "../../include/pintron_gpu.h"
+
+const uint8_t* pgpu_index_genomic(const pgpu_index* idx);   // device pointer
+size_t pgpu_index_length(const pgpu_index* idx);
+
+// context helpers implemented in pgpu_api.hip
+hipStream_t pgpu_ctx_stream(pgpu_ctx* ctx);
+int pgpu_ctx_fail(pgpu_ctx* ctx, int code, const char* msg);

@@ -1,0 +1,46 @@
+// Internal declarations shared by the HIP translation units of libpintron_gpu.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pintron_gpu.h"
+
+// Job descriptor as the kernels see it: operand pointers already resolved to HBM addresses.
+struct DevJob {
+  const uint8_t* a;
+  const uint8_t* b;
+  uint32_t la, lb;
+  uint32_t p0, p1, p2, tail;
+  uint64_t ws_off;      // byte offset of this job's traceback workspace
+  uint64_t str_off;     // byte offset of this job's two alignment strings
+  uint32_t out_idx;     // index of the caller's job (results are written in caller order)
+  uint32_t r_class;     // rows per lane (R) of the kernel instance that ran the job
+};
+static_assert(sizeof(DevJob) == 64, "DevJob layout");
+
+using DevResult = pgpu_dp_result;
+
+// kernel families (one launch group per family and row class)
+enum KernelFamily {
+  KF_ALIGN = 0, KF_GAP, KF_ED, KF_KBAND, KF_LCF, KF_BORDERS, KF_AFFIX, KF_KBAND_FULL, KF_COUNT
+};
+
+// launchers (pgpu_dp_kernels.hip)
+void launch_lev(int mode_family, int R, const DevJob* jobs, int njobs, DevResult* res,
+                uint8_t* ws, hipStream_t st);
+void launch_align_traceback(const DevJob* jobs, int njobs, DevResult* res, const uint8_t* ws,
+                            uint8_t* strs, hipStream_t st);
+void launch_gap(int R, const DevJob* jobs, int njobs, DevResult* res, uint8_t* ws, hipStream_t st);
+void launch_gap_traceback(const DevJob* jobs, int njobs, DevResult* res, const uint8_t* ws,
+                          uint8_t* strs, hipStream_t st);
+void launch_kband(const DevJob* jobs, int njobs, DevResult* res, uint8_t* ws, hipStream_t st);
+void launch_lcf(const DevJob* jobs, int njobs, uint32_t max_chunks, uint32_t max_l2,
+                unsigned long long* keys, hipStream_t st);
+void launch_kband_full_fixup(const DevJob* jobs, int njobs, DevResult* res, hipStream_t st);
+void launch_lcf_finish(const DevJob* jobs, int njobs, DevResult* res,
+                       const unsigned long long* keys, hipStream_t st);
+
+// bytes of one traceback entry (all rows of one lane in one column)
+static inline uint32_t align_entry_bytes(uint32_t R) { return R <= 4 ? 1u : R / 4; }
+static inline uint32_t gap_entry_bytes(uint32_t R) { return R; }

@@ -1,0 +1,37 @@
+"""Loads tests/golden/dp_calls.jsonl.gz (made by tools/make_golden.py from the reference) as
+(Case, expected) pairs."""
+import gzip
+import json
+import os
+
+import dp_cases as D
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load():
+    out = []
+    with gzip.open(os.path.join(GOLD, "dp_calls.jsonl.gz"), "rt") as f:
+        for line in f:
+            r = json.loads(line)
+            a, b = r["a"].encode("latin1"), r["b"].encode("latin1")
+            k = r["k"]
+            if k == "ALIGN":
+                out.append((D.Case(D.ALIGN, a, b), dict(score=r["score"], dim=r["dim"], ea=r["ea"].encode(), ga=r["ga"].encode())))
+            elif k == "GAP":
+                e = {f: r[f] for f in D.FIELDS[D.GAP] if f not in ("ea", "ga")}
+                e.update(ea=r["ea"].encode(), ga=r["ga"].encode())
+                out.append((D.Case(D.GAP, a, b), e))
+            elif k in ("ED", "EDM"):
+                out.append((D.Case(D.ED, a, b), dict(score=r["score"])))
+            elif k == "KBAND":
+                out.append((D.Case(D.KBAND, a, b, p0=r["ub"]), dict(ok=r["ok"], edit=r["edit"])))
+            elif k == "BORDERS":
+                out.append((D.Case(D.BORDERS, a, b, p0=r["min_cut"], p1=r["max_cut"], p2=r["max_errs"],
+                                   b_tail=r["b_tail"].encode("latin1")),
+                            dict(ok=r["ok"], off_p=r["off_p"], off_t1=r["off_t1"], off_t2=r["off_t2"], ed=r["ed"])))
+            elif k == "LCF":
+                out.append((D.Case(D.LCF, a, b), dict(len=r["len"], occ1=r["occ1"], occ2=r["occ2"])))
+            elif k == "AFFIX":
+                out.append((D.Case(D.AFFIX, a, b), dict(valid=r["valid"], ecut=r["ecut"], gcut=r["gcut"])))
+    return out

@@ -1,0 +1,123 @@
+"""GPU parity tests proper: every DP kind through the C-ABI (libpintron_gpu.so, HIP/gfx950)
+against the CPU oracle and the committed golden vectors.  Bit-exact (integer / byte work)."""
+import random
+
+import pytest
+
+import dp_cases as D
+import golden_cases as G
+
+pytestmark = pytest.mark.gpu
+
+
+def run_and_check(ctx, O, cases, expected=None):
+    import pintron_amd.capi as capi
+    jl = capi.JobList()
+    for c in cases:
+        c.add_to(jl)
+    out = capi.run_jobs(ctx, jl)
+    bad = []
+    for i, (c, got) in enumerate(zip(cases, out)):
+        exp = expected[i] if expected is not None else c.expected(O)
+        if not D.check_case(c, got, O, expected=exp):
+            bad.append((c, exp, got))
+    assert not bad, "%d/%d jobs differ; first: %r\nexpected %r\ngot      %r" % (
+        len(bad), len(cases), *bad[0])
+
+
+def test_golden_vectors(gpu_ctx, O):
+    pairs = G.load()
+    run_and_check(gpu_ctx, O, [c for c, _ in pairs], [e for _, e in pairs])
+
+
+def test_edge_cases(gpu_ctx, O):
+    run_and_check(gpu_ctx, O, D.edge_cases())
+
+
+@pytest.mark.parametrize("seed,max_len", [(1, 64), (2, 300), (3, 700), (4, 1500)])
+def test_random_cases(gpu_ctx, O, seed, max_len):
+    run_and_check(gpu_ctx, O, D.random_cases(random.Random(seed), n_per_kind=60, max_len=max_len))
+
+
+def test_large_rows(gpu_ctx, O):
+    """Row classes R=32 and R=64 (up to 4096 rows) and the dimension limits."""
+    import pintron_amd.capi as capi
+    rng = random.Random(9)
+    cases = []
+    for n in (1100, 2047, 2421, 4096):
+        a, b = D.pair(rng, n, 0.03, 0.001)
+        cases.append(D.Case(D.ALIGN, a, b))
+        cases.append(D.Case(D.ED, a, b))
+        cases.append(D.Case(D.KBAND, a, b, p0=n // 25))
+    a, b = D.pair(rng, 1500, 0.05)
+    cases.append(D.Case(D.AFFIX, a, b))
+    cases.append(D.Case(D.BORDERS, a[:1100], b, p0=0, p1=1100, p2=60))
+    cases.append(D.Case(D.GAP, a[:1500], b + D.rand_seq(rng, 300)))
+    run_and_check(gpu_ctx, O, cases)
+    # over the limit: per-job ERANGE, the rest of the batch still runs
+    jl = capi.JobList()
+    big = D.rand_seq(rng, 4097)
+    jl.add(capi.ALIGN, big, big[:-1] + b"A")
+    jl.add(capi.ED, b"ACGT", b"ACGA")
+    out = capi.run_jobs(gpu_ctx, jl)
+    assert out[0]["status"] == capi.PGPU_ERANGE
+    assert out[1] == dict(status=0, score=1)
+
+
+def test_lcf_genomic_scale(gpu_ctx, O):
+    """LCF at the BASELINE configs' genomic lengths (200 kb and 1 Mb prefixes) with the operand
+    taken from the resident genomic; checked against the oracle (seconds on CPU)."""
+    import pintron_amd.capi as capi
+    rng = random.Random(21)
+    gen = D.rand_seq(rng, 1_000_000, 0.0005)
+    idx = capi.Index(gpu_ctx, gen)
+    try:
+        jl = capi.JobList()
+        cases = []
+        for glen in (199_990, 1_000_000, 65_536, 77):
+            for _ in range(3):
+                est = bytearray(D.rand_seq(rng, rng.randint(20, 46), 0.02))
+                k = rng.randint(8, 18)
+                p = rng.randint(0, glen - k); q = rng.randint(0, len(est) - k)
+                est[q:q + k] = gen[p:p + k]
+                cases.append(D.Case(D.LCF, gen[:glen], bytes(est)))
+                jl.add(capi.LCF, gen[:glen], bytes(est), a_gen_off=0)
+        out = capi.run_jobs(gpu_ctx, jl, idx)
+        for c, got in zip(cases, out):
+            assert D.check_case(c, got, O), (len(c.a), c.b, got, c.expected(O))
+    finally:
+        idx.close()
+
+
+def test_properties_at_full_size(gpu_ctx, O):
+    """Size-independent properties on a C3-shaped batch (20k jobs): ALIGN of a string with
+    itself is the identity; alignment strings project back onto their inputs; the alignment's
+    mismatch+gap count equals the score; ED is symmetric and equals ALIGN's score when no N is
+    present; KBAND agrees with ED whenever ED <= k."""
+    import pintron_amd.capi as capi
+    rng = random.Random(33)
+    jl = capi.JobList()
+    meta = []
+    for i in range(5000):
+        a, b = D.pair(rng, rng.randint(80, 600), 0.03)
+        k = max(len(a), len(b)) // 25 + 1
+        meta.append((a, b, k))
+        jl.add(capi.ALIGN, a, b)
+        jl.add(capi.ED, a, b)
+        jl.add(capi.ED, b, a)
+        jl.add(capi.KBAND, a, b, p0=k)
+    out = capi.run_jobs(gpu_ctx, jl)
+    for i, (a, b, k) in enumerate(meta):
+        al, e1, e2, kb = out[4 * i: 4 * i + 4]
+        assert al["ea"].replace(b"-", b"") == a and al["ga"].replace(b"-", b"") == b
+        assert len(al["ea"]) == len(al["ga"]) == al["dim"]
+        cost = sum(1 for x, y in zip(al["ea"], al["ga"]) if x != y)
+        assert cost == al["score"] == e1["score"] == e2["score"]
+        assert kb["ok"] == (1 if e1["score"] <= k else 0)
+        if kb["ok"]:
+            assert kb["edit"] == e1["score"]
+    jl = capi.JobList()
+    for a, _, _ in meta[:200]:
+        jl.add(capi.ALIGN, a, a)
+    for o, (a, _, _) in zip(capi.run_jobs(gpu_ctx, jl), meta):
+        assert o["score"] == 0 and o["ea"] == a and o["ga"] == a
