@@ -144,6 +144,10 @@ int pgpu_dp_plan_sync(pgpu_ctx* ctx, pgpu_dp_plan* plan);
 size_t pgpu_dp_plan_string_bytes(const pgpu_dp_plan* plan);
 int pgpu_dp_plan_fetch(pgpu_ctx* ctx, pgpu_dp_plan* plan, pgpu_dp_result* results,
                        char* strings, size_t strings_cap);
+/* copies the result table (n_jobs * sizeof(pgpu_dp_result), caller order) into DEVICE memory the
+ * caller owns (e.g. a buffer handed to an RCCL gather), stream-ordered after the plan's kernels;
+ * returns after the copy has completed */
+int pgpu_dp_plan_results_to_device(pgpu_ctx* ctx, pgpu_dp_plan* plan, void* device_dst, size_t cap);
 int pgpu_dp_plan_destroy(pgpu_ctx* ctx, pgpu_dp_plan* plan);
 
 /* measurement hooks (bench.py): DP cells of the plan per kind with the reference's own loop

@@ -46,6 +46,7 @@ EXPORTS = [
     "pgpu_index_build", "pgpu_index_destroy", "pgpu_index_suffix_array", "pgpu_pairings",
     "pgpu_dp_plan_create", "pgpu_dp_plan_launch", "pgpu_dp_plan_sync",
     "pgpu_dp_plan_string_bytes", "pgpu_dp_plan_fetch", "pgpu_dp_plan_destroy",
+    "pgpu_dp_plan_results_to_device",
     "pgpu_dp_plan_cells", "pgpu_dp_plan_algo_bytes", "pgpu_dp_plan_kernel_ms",
     "pgpu_dp_plan_launches", "pgpu_dp_plan_n_groups", "pgpu_dp_plan_group_info", "pgpu_dp_batch",
 ]
@@ -86,6 +87,7 @@ def lib():
         L.pgpu_dp_plan_string_bytes.restype = sz
         L.pgpu_dp_plan_fetch.argtypes = [vp, vp, C.POINTER(DpResult), C.c_char_p, sz]
         L.pgpu_dp_plan_destroy.argtypes = [vp, vp]
+        L.pgpu_dp_plan_results_to_device.argtypes = [vp, vp, vp, sz]
         for nm in ("pgpu_dp_plan_cells", "pgpu_dp_plan_algo_bytes", "pgpu_dp_plan_launches"):
             getattr(L, nm).argtypes = [vp, C.c_int]
             getattr(L, nm).restype = u64
@@ -203,6 +205,9 @@ class Plan:
         sbuf = C.create_string_buffer(max(nbytes, 1))
         self.ctx.check(L.pgpu_dp_plan_fetch(self.ctx.h, self.h, res, sbuf, nbytes))
         return res, sbuf.raw
+
+    def results_to_device(self, device_ptr: int, cap: int):
+        self.ctx.check(self.ctx.L.pgpu_dp_plan_results_to_device(self.ctx.h, self.h, device_ptr, cap))
 
     def groups(self):
         L = self.ctx.L

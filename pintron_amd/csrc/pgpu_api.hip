@@ -374,6 +374,16 @@ extern "C" int pgpu_dp_plan_fetch(pgpu_ctx* ctx, pgpu_dp_plan* p, pgpu_dp_result
   return PGPU_OK;
 }
 
+extern "C" int pgpu_dp_plan_results_to_device(pgpu_ctx* ctx, pgpu_dp_plan* p, void* dst, size_t cap) {
+  if (!ctx || !p || !dst) return set_err(ctx, PGPU_EINVAL, "bad argument");
+  const size_t bytes = p->n_jobs * sizeof(DevResult);
+  if (cap < bytes) return set_err(ctx, PGPU_ENOSPC, "device buffer too small: need %zu", bytes);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (bytes) HIP_TRY(ctx, hipMemcpyAsync(dst, p->d_results, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return PGPU_OK;
+}
+
 extern "C" int pgpu_dp_plan_destroy(pgpu_ctx* ctx, pgpu_dp_plan* p) {
   if (!ctx || !p) return PGPU_EINVAL;
   hipSetDevice(ctx->device);

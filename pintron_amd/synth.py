@@ -1,0 +1,145 @@
+"""Seeded synthetic est-fact workloads: one genomic sequence with a planted
+gene model and ESTs sampled from its transcripts.  Used by bench.py, the tests and the tools; it is
+input generation only (numpy), not part of the accelerated path.
+
+Config shapes (BASELINE.json `configs`):
+  C2: 50 kb x 1 000 ESTs ~500 bp, 1 % errors      C3: 200 kb x 100 000 ESTs ~600 bp, 3 % errors
+  C5: 1 Mb x 2 000 000 ESTs of exactly 150 bp, 1 % errors
+"""
+from dataclasses import dataclass, field
+
+import numpy as np
+
+_ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+_COMP = np.zeros(256, dtype=np.uint8)
+for _a, _b in zip(b"ACGTNacgtn", b"TGCANtgcan"):
+    _COMP[_a] = _b
+
+
+def revcomp(a: np.ndarray) -> np.ndarray:
+    return _COMP[a[::-1]]
+
+
+@dataclass
+class Workload:
+    name: str
+    genomic: bytes
+    exons: list                 # [(start, end)) on the genomic, ascending
+    est_seqs: list              # list[bytes] as they would appear in ests.txt
+    est_headers: list           # list[str]
+    truth: list = field(default_factory=list)   # per EST: dict(tstart, tend, rc, exon_blocks)
+
+    def genomic_fasta(self) -> str:
+        return ">chrS:1:%d:+1\n%s\n" % (len(self.genomic), self.genomic.decode())
+
+    def ests_fasta(self) -> str:
+        return "".join("%s\n%s\n" % (h, s.decode()) for h, s in zip(self.est_headers, self.est_seqs))
+
+
+CONFIGS = {
+    "C2": dict(gen_len=50_000, n_est=1_000, est_len=500, est_sd=100, err=0.01, seed=2),
+    "C3": dict(gen_len=200_000, n_est=100_000, est_len=600, est_sd=100, err=0.03, seed=3),
+    "C5": dict(gen_len=1_000_000, n_est=2_000_000, est_len=150, est_sd=0, err=0.01, seed=5),
+}
+
+
+def make(name="C3", n_est=None, seed=None, gen_len=None) -> Workload:
+    cfg = dict(CONFIGS[name])
+    if n_est is not None:
+        cfg["n_est"] = n_est
+    if seed is not None:
+        cfg["seed"] = seed
+    if gen_len is not None:
+        cfg["gen_len"] = gen_len
+    rng = np.random.default_rng(cfg["seed"])
+    L = cfg["gen_len"]
+    gen = _ACGT[rng.integers(0, 4, L)]
+
+    # gene model: 8-12 exons of 80-300 bp, introns 500 bp .. 20 kb (scaled to fit), GT..AG ends
+    n_ex = int(rng.integers(8, 13))
+    ex_len = rng.integers(80, 301, n_ex)
+    room = L - int(ex_len.sum()) - 2_000
+    raw = rng.integers(500, 20_001, n_ex - 1).astype(np.float64)
+    if raw.sum() > room:
+        raw = np.maximum(500, raw * (room / raw.sum()) * 0.98)
+    introns = raw.astype(np.int64)
+    pos = int(rng.integers(500, max(501, L - int(ex_len.sum()) - int(introns.sum()) - 500)))
+    exons = []
+    for k in range(n_ex):
+        exons.append((pos, pos + int(ex_len[k])))
+        pos += int(ex_len[k])
+        if k < n_ex - 1:
+            donor = b"GC" if rng.random() < 0.02 else b"GT"
+            gen[pos:pos + 2] = np.frombuffer(donor, dtype=np.uint8)
+            pos += int(introns[k])
+            gen[pos - 2:pos] = np.frombuffer(b"AG", dtype=np.uint8)
+
+    # transcripts: the full one plus a few exon-skipping isoforms
+    isoforms = [list(range(n_ex))]
+    for _ in range(3):
+        skip = int(rng.integers(1, n_ex - 1))
+        isoforms.append([k for k in range(n_ex) if k != skip])
+    tx = []
+    for iso in isoforms:
+        seq = np.concatenate([gen[exons[k][0]:exons[k][1]] for k in iso])
+        bounds = np.cumsum([0] + [exons[k][1] - exons[k][0] for k in iso])
+        tx.append((seq, iso, bounds))
+
+    n = cfg["n_est"]
+    which = rng.integers(0, len(tx), n)
+    if cfg["est_sd"]:
+        lens = np.clip(rng.normal(cfg["est_len"], cfg["est_sd"], n).astype(np.int64), 100, None)
+    else:
+        lens = np.full(n, cfg["est_len"], dtype=np.int64)
+    is_rc = rng.random(n) < 0.5
+    has_polya = rng.random(n) < 0.10
+    polya_len = rng.integers(20, 41, n)
+
+    est_seqs, headers, truth = [], [], []
+    err = cfg["err"]
+    for i in range(n):
+        seq, iso, bounds = tx[int(which[i])]
+        ln = int(min(lens[i], len(seq)))
+        st = int(rng.integers(0, len(seq) - ln + 1))
+        s = seq[st:st + ln].copy()
+        # errors: 2/3 substitutions, 1/3 indels (half insertions, half deletions)
+        r = rng.random(ln)
+        sub = r < err * 2 / 3
+        dele = (r >= err * 2 / 3) & (r < err * 5 / 6)
+        ins = (r >= err * 5 / 6) & (r < err)
+        s[sub] = _ACGT[(np.searchsorted(_ACGT, s[sub]) + rng.integers(1, 4, int(sub.sum()))) % 4]
+        if rng.random() < 0.3:                      # <= 0.1 % N overall
+            nn = rng.random(ln) < 0.003
+            s[nn] = ord("N")
+        rep = np.ones(ln, dtype=np.int64)
+        rep[dele] = 0
+        rep[ins] = 2
+        out = np.repeat(s, rep)
+        if ins.any():
+            ends = np.cumsum(rep)[ins] - 1          # second copy of each duplicated base
+            out[ends] = _ACGT[rng.integers(0, 4, len(ends))]
+        if has_polya[i]:
+            out = np.concatenate([out, np.full(int(polya_len[i]), ord("A"), dtype=np.uint8)])
+        rc = bool(is_rc[i])
+        if rc:
+            out = revcomp(out)
+        est_seqs.append(out.tobytes())
+        headers.append(">/gb=SYN%07d /clone_end=%s" % (i, "5'" if rc else "3'"))
+        # ground truth exon blocks (genomic coordinates) of the error-free EST
+        blocks = []
+        for bi, k in enumerate(iso):
+            lo, hi = max(st, int(bounds[bi])), min(st + ln, int(bounds[bi + 1]))
+            if lo < hi:
+                g0 = exons[k][0] + (lo - int(bounds[bi]))
+                blocks.append((lo - st, hi - st, g0, g0 + (hi - lo)))
+        truth.append(dict(rc=rc, blocks=blocks, polya=bool(has_polya[i])))
+    return Workload(name, gen.tobytes(), exons, est_seqs, headers, truth)
+
+
+def write_files(w: Workload, directory: str) -> None:
+    import os
+    os.makedirs(directory, exist_ok=True)
+    with open(os.path.join(directory, "genomic.txt"), "w") as f:
+        f.write(w.genomic_fasta())
+    with open(os.path.join(directory, "ests.txt"), "w") as f:
+        f.write(w.ests_fasta())
