@@ -109,6 +109,26 @@ def main():
         elif c.kind == D.AFFIX:
             r = R.longest_affix(c.a, c.b)
             sample.append(json.dumps(dict(k="AFFIX", a=c.a.decode(), b=c.b.decode(), **r)) + "\n")
+    # pairings (MEG vertex sets) from the reference's own suffix tree + build_vertex_set
+    import pairing_lib as PL
+    sets = []
+    gen = PL.read_fasta(os.path.join(REF, "regressionTest", "test-AMBN", "genomic.txt"))[0]
+    ests = PL.read_fasta(os.path.join(REF, "regressionTest", "test-AMBN", "ests.txt"))
+    ri = PL.RefIndex(gen)
+    sets.append(dict(genomic=gen.decode(), cases=[
+        dict(est=e.decode(), L=15, rate=0.2, pairings=ri.pairings(e).tolist())
+        for e in ests + [PL.revcomp(x) for x in ests]]))
+    gen, ests = PL.repeat_workload(5)
+    ri = PL.RefIndex(gen)
+    cases = []
+    for L, rate in ((15, 0.2), (16, 0.2), (22, 0.2), (15, 0.5), (15, 1.0)):
+        for e in ests:
+            if e:
+                cases.append(dict(est=e.decode(), L=L, rate=rate, pairings=ri.pairings(e, L, rate).tolist()))
+    sets.append(dict(genomic=gen.decode(), cases=cases))
+    with gzip.open(os.path.join(GOLD, "pairings.json.gz"), "wt") as f:
+        json.dump(dict(sets=sets), f)
+    print("pairing cases:", sum(len(s["cases"]) for s in sets))
     with gzip.open(os.path.join(GOLD, "dp_calls.jsonl.gz"), "wt") as f:
         f.writelines(sample)
     json.dump(sums, open(os.path.join(GOLD, "reference_md5.json"), "w"), indent=1, sort_keys=True)
