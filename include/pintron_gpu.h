@@ -75,6 +75,23 @@ int pgpu_pairings(pgpu_ctx* ctx, const pgpu_index* idx,
                   const pgpu_pairing_params* params,
                   pgpu_pairing* out, size_t out_cap, uint64_t* out_first, size_t* n_out);
 
+/* The same in three steps for callers that keep the patterns resident (bench, batched host):
+ * create uploads the patterns; run launches every kernel with the given parameters (may be
+ * repeated with other parameters: the reference re-runs build_vertex_set with a longer
+ * min_factor_len when a MEG is too complex, src/compute-est-fact.c:132-144); fetch downloads. */
+typedef struct pgpu_pairing_plan pgpu_pairing_plan;
+int pgpu_pairing_plan_create(pgpu_ctx* ctx, const pgpu_index* idx, const char* patterns,
+                             const uint64_t* pat_off, size_t n_pat, pgpu_pairing_plan** plan);
+int pgpu_pairing_plan_run(pgpu_ctx* ctx, pgpu_pairing_plan* plan, const pgpu_pairing_params* params);
+uint64_t pgpu_pairing_plan_count(const pgpu_pairing_plan* plan);       /* pairings of the last run */
+uint64_t pgpu_pairing_plan_positions(const pgpu_pairing_plan* plan);   /* pattern positions */
+/* HIP-event time of stage k of the last run: 0 locate, 1 chain, 2 count+scan, 3 fill,
+ * 4 cross+scan, 5 emit */
+double pgpu_pairing_plan_kernel_ms(const pgpu_pairing_plan* plan, int k);
+int pgpu_pairing_plan_fetch(pgpu_ctx* ctx, pgpu_pairing_plan* plan, pgpu_pairing* out, size_t out_cap,
+                            uint64_t* out_first);
+int pgpu_pairing_plan_destroy(pgpu_ctx* ctx, pgpu_pairing_plan* plan);
+
 /* ------------------------------------------------------------------------------------------ */
 /* batched dynamic programs                                                                   */
 /* ------------------------------------------------------------------------------------------ */

@@ -44,6 +44,9 @@ assert C.sizeof(DpJob) == 48 and C.sizeof(DpResult) == 48
 EXPORTS = [
     "pgpu_init", "pgpu_destroy", "pgpu_last_error", "pgpu_abi_version",
     "pgpu_index_build", "pgpu_index_destroy", "pgpu_index_suffix_array", "pgpu_pairings",
+    "pgpu_pairing_plan_create", "pgpu_pairing_plan_run", "pgpu_pairing_plan_count",
+    "pgpu_pairing_plan_positions", "pgpu_pairing_plan_kernel_ms", "pgpu_pairing_plan_fetch",
+    "pgpu_pairing_plan_destroy",
     "pgpu_dp_plan_create", "pgpu_dp_plan_launch", "pgpu_dp_plan_sync",
     "pgpu_dp_plan_string_bytes", "pgpu_dp_plan_fetch", "pgpu_dp_plan_destroy",
     "pgpu_dp_plan_results_to_device",
@@ -79,6 +82,16 @@ def lib():
         L.pgpu_pairings.argtypes = [vp, vp, C.c_char_p, C.POINTER(u64), sz,
                                     C.POINTER(PairingParams), C.POINTER(Pairing), sz,
                                     C.POINTER(u64), C.POINTER(sz)]
+        L.pgpu_pairing_plan_create.argtypes = [vp, vp, C.c_char_p, C.POINTER(u64), sz, C.POINTER(vp)]
+        L.pgpu_pairing_plan_run.argtypes = [vp, vp, C.POINTER(PairingParams)]
+        L.pgpu_pairing_plan_count.argtypes = [vp]
+        L.pgpu_pairing_plan_count.restype = u64
+        L.pgpu_pairing_plan_positions.argtypes = [vp]
+        L.pgpu_pairing_plan_positions.restype = u64
+        L.pgpu_pairing_plan_kernel_ms.argtypes = [vp, C.c_int]
+        L.pgpu_pairing_plan_kernel_ms.restype = C.c_double
+        L.pgpu_pairing_plan_fetch.argtypes = [vp, vp, C.POINTER(Pairing), sz, C.POINTER(u64)]
+        L.pgpu_pairing_plan_destroy.argtypes = [vp, vp]
         L.pgpu_dp_plan_create.argtypes = [vp, vp, C.POINTER(DpJob), sz, C.c_char_p, sz,
                                           C.POINTER(vp)]
         L.pgpu_dp_plan_launch.argtypes = [vp, vp]
@@ -144,6 +157,45 @@ class Index:
     def close(self):
         if self.h:
             self.ctx.L.pgpu_index_destroy(self.ctx.h, self.h)
+            self.h = C.c_void_p()
+
+
+class PairingPlan:
+    """Patterns resident in HBM; run() = all pairing kernels; fetch() -> (triples[n,3], first[n_pat+1])."""
+    STAGES = ["locate", "chain", "count+scan", "fill", "cross+scan", "emit"]
+
+    def __init__(self, ctx: Context, index: Index, patterns):
+        import numpy as np
+        self.ctx, self.n_pat = ctx, len(patterns)
+        self._blob = b"".join(patterns)
+        self._off = np.zeros(len(patterns) + 1, dtype=np.uint64)
+        np.cumsum([len(p) for p in patterns], out=self._off[1:])
+        self.h = C.c_void_p()
+        ctx.check(ctx.L.pgpu_pairing_plan_create(ctx.h, index.h, self._blob,
+                                                 self._off.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                                 self.n_pat, C.byref(self.h)))
+
+    def run(self, min_factor_len=15, rate=0.2):
+        prm = PairingParams(min_factor_len, 0, rate)
+        self.ctx.check(self.ctx.L.pgpu_pairing_plan_run(self.ctx.h, self.h, C.byref(prm)))
+        return self.ctx.L.pgpu_pairing_plan_count(self.h)
+
+    def stage_ms(self):
+        return {s: self.ctx.L.pgpu_pairing_plan_kernel_ms(self.h, k) for k, s in enumerate(self.STAGES)}
+
+    def fetch(self):
+        import numpy as np
+        n = self.ctx.L.pgpu_pairing_plan_count(self.h)
+        out = np.zeros((max(n, 1), 3), dtype=np.int32)
+        first = np.zeros(self.n_pat + 1, dtype=np.uint64)
+        self.ctx.check(self.ctx.L.pgpu_pairing_plan_fetch(
+            self.ctx.h, self.h, out.ctypes.data_as(C.POINTER(Pairing)), n,
+            first.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return out[:n], first
+
+    def close(self):
+        if self.h:
+            self.ctx.L.pgpu_pairing_plan_destroy(self.ctx.h, self.h)
             self.h = C.c_void_p()
 
 

@@ -1,15 +1,334 @@
-// Genomic index resident in HBM: the sequence (1 B/base) and its suffix array.
+// Genomic index resident in HBM -- the sequence (1 B/base), its suffix array and LCP array -- and
+// the pairing kernels that replace the reference's augmented suffix tree:
+//   lst_stree_new (stree_src/lst_stree.c:816), stree_preprocess (src/aug_suffix_tree.c:247) and
+//   build_vertex_set (src/max-emb-graph.c:218-392).
+// Semantics (how the tree walk maps onto SA intervals, the suffix-link start rule, the two
+// low-complexity filters) are stated in DESIGN.md section 4b and restated on the CPU, for the
+// tests only, in oracle/pairing_oracle.c.
+//
+// Index build: prefix doubling on the device; the device-wide sorts and scans are rocPRIM
+// (one-off per gene, not a hot path).  Everything per-EST is hand-written:
+//   pair_locate   one wave per pattern, one lane per position: SA interval of the L-mer
+//                 (two binary searches, T and SA are L2-resident: 9 B/base), then the longest
+//                 match among the occurrences that are not preceded by P[i-1]
+//   pair_chain    one thread per pattern: the sequential locus-depth recurrence
+//                 D_i = max(A_i, s_i), threshold, next start depth from LCP-interval borders
+//   pair_count / pair_fill / pair_cross / pair_emit
+//                 per position: occurrences above the threshold, sort by t, filter (a);
+//                 filter (b) against the previous position; compaction into (p,t,l) triples
+#include <cstring>
 #include <new>
+#include <vector>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
 #include "pgpu_index.h"
 
 struct pgpu_index {
   uint8_t* d_gen = nullptr;
   uint32_t* d_sa = nullptr;
+  uint32_t* d_lcp = nullptr;      // n+1 entries; lcp[0] = lcp[n] = 0
   size_t len = 0;
 };
 
 const uint8_t* pgpu_index_genomic(const pgpu_index* idx) { return idx->d_gen; }
 size_t pgpu_index_length(const pgpu_index* idx) { return idx->len; }
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// suffix array by prefix doubling
+// ---------------------------------------------------------------------------------------------
+__global__ void sa_init_kernel(const uint8_t* __restrict__ T, uint32_t n, uint32_t* rank, uint32_t* sa) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { rank[i] = (uint32_t)T[i] + 1u; sa[i] = i; }
+}
+
+__global__ void sa_keys_kernel(const uint32_t* __restrict__ rank, const uint32_t* __restrict__ sa,
+                               uint32_t n, uint32_t h, unsigned long long* keys) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const uint32_t i = sa[k];
+  const uint32_t r2 = (i + h < n) ? rank[i + h] : 0u;          // past the end sorts first ('$')
+  keys[k] = ((unsigned long long)rank[i] << 32) | r2;
+}
+
+__global__ void sa_flags_kernel(const unsigned long long* __restrict__ keys, uint32_t n, uint32_t* flags) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) flags[k] = (k == 0 || keys[k] != keys[k - 1]) ? 1u : 0u;
+}
+
+__global__ void sa_rerank_kernel(const uint32_t* __restrict__ sa, const uint32_t* __restrict__ newrank_sorted,
+                                 uint32_t n, uint32_t* rank) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) rank[sa[k]] = newrank_sorted[k];
+}
+
+__global__ void lcp_kernel(const uint8_t* __restrict__ T, const uint32_t* __restrict__ sa, uint32_t n,
+                           uint32_t* lcp) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k > n) return;
+  if (k == 0 || k == n) { lcp[k] = 0; return; }
+  const uint32_t a = sa[k - 1], b = sa[k];
+  uint32_t h = 0;
+  const uint32_t lim = n - (a > b ? a : b);
+  while (h < lim && T[a + h] == T[b + h]) ++h;
+  lcp[k] = h;
+}
+
+// ---------------------------------------------------------------------------------------------
+// pairings
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t NONE = 0xFFFFFFFFu;
+
+struct PairParams {
+  uint32_t L;
+  double rate;
+};
+
+// compare suffix t (from character `skip` on) with q[skip..d): -1 / 0 (q[0..d) is a prefix) / +1.
+// The caller guarantees the first `skip` characters are equal.
+__device__ __forceinline__ int cmp_suffix(const uint8_t* __restrict__ T, uint32_t n, uint32_t t,
+                                          const uint8_t* __restrict__ q, uint32_t d, uint32_t skip) {
+  for (uint32_t x = skip; x < d; ++x) {
+    if (t + x >= n) return -1;                      // the suffix ended: it sorts first
+    const uint32_t c = T[t + x], e = q[x];
+    if (c != e) return c < e ? -1 : 1;
+  }
+  return 0;
+}
+
+// [lo,hi) of suffixes in sa[from,to) having q[0..d) as a prefix (all share q[0..skip))
+__device__ void sa_interval(const uint8_t* __restrict__ T, uint32_t n, const uint32_t* __restrict__ sa,
+                            const uint8_t* __restrict__ q, uint32_t d, uint32_t skip,
+                            uint32_t from, uint32_t to, uint32_t* lo, uint32_t* hi) {
+  uint32_t a = from, b = to;
+  while (a < b) {
+    const uint32_t mid = a + ((b - a) >> 1);
+    if (cmp_suffix(T, n, sa[mid], q, d, skip) < 0) a = mid + 1; else b = mid;
+  }
+  *lo = a;
+  b = to;
+  while (a < b) {
+    const uint32_t mid = a + ((b - a) >> 1);
+    if (cmp_suffix(T, n, sa[mid], q, d, skip) <= 0) a = mid + 1; else b = mid;
+  }
+  *hi = a;
+}
+
+__device__ __forceinline__ bool prev_excluded(const uint8_t* __restrict__ T, uint32_t t,
+                                              const uint8_t* __restrict__ P, uint32_t i) {
+  return i > 0 && t > 0 && T[t - 1] == P[i - 1];     // src/max-emb-graph.c:178-181,195
+}
+
+__device__ __forceinline__ uint32_t extend(const uint8_t* __restrict__ T, uint32_t n, uint32_t t,
+                                           const uint8_t* __restrict__ P, uint32_t m, uint32_t i,
+                                           uint32_t from) {
+  uint32_t l = from;
+  while (i + l < m && t + l < n && P[i + l] == T[t + l]) ++l;
+  return l;
+}
+
+// one wave per pattern, lanes stride over its positions
+__global__ __launch_bounds__(64)
+void pair_locate_kernel(const uint8_t* __restrict__ T, uint32_t n, const uint32_t* __restrict__ sa,
+                        const uint8_t* __restrict__ pats, const unsigned long long* __restrict__ pat_off,
+                        PairParams prm, uint32_t* __restrict__ lo_out, uint32_t* __restrict__ hi_out,
+                        uint32_t* __restrict__ a_out) {
+  const unsigned long long base = pat_off[blockIdx.x];
+  const uint32_t m = (uint32_t)(pat_off[blockIdx.x + 1] - base);
+  const uint8_t* P = pats + base;
+  for (uint32_t i = threadIdx.x; i < m; i += 64) {
+    uint32_t lo = 0, hi = 0, A = 0;
+    if (m - i >= prm.L) {
+      sa_interval(T, n, sa, P + i, prm.L, 0, 0, n, &lo, &hi);
+      for (uint32_t k = lo; k < hi; ++k) {
+        const uint32_t t = sa[k];
+        if (prev_excluded(T, t, P, i)) continue;
+        const uint32_t l = extend(T, n, t, P, m, i, prm.L);
+        A = l > A ? l : A;
+      }
+    }
+    lo_out[base + i] = lo; hi_out[base + i] = hi; a_out[base + i] = A;
+  }
+}
+
+// one thread per pattern: the locus-depth recurrence (sequential in i)
+__global__ __launch_bounds__(64)
+void pair_chain_kernel(const uint8_t* __restrict__ T, uint32_t n, const uint32_t* __restrict__ sa,
+                       const uint32_t* __restrict__ lcp, const uint8_t* __restrict__ pats,
+                       const unsigned long long* __restrict__ pat_off, uint32_t n_pat, PairParams prm,
+                       const uint32_t* __restrict__ lo_in, const uint32_t* __restrict__ hi_in,
+                       const uint32_t* __restrict__ a_in, uint32_t* __restrict__ thr_out) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_pat) return;
+  const unsigned long long base = pat_off[p];
+  const uint32_t m = (uint32_t)(pat_off[p + 1] - base);
+  const uint8_t* P = pats + base;
+  uint32_t s = 0;
+  for (uint32_t i = 0; i < m; ++i) {
+    const uint32_t A = a_in[base + i];
+    const uint32_t D = A > s ? A : s;
+    if (D < prm.L) { thr_out[base + i] = NONE; s = 0; continue; }
+    const double scaled = (double)D * prm.rate;                  // src/max-emb-graph.c:273-274
+    const double thr_d = scaled > (double)prm.L ? scaled : (double)prm.L;
+    thr_out[base + i] = (uint32_t)thr_d;
+    const uint32_t lo = lo_in[base + i], hi = hi_in[base + i];
+    uint32_t l2 = lo, h2 = hi;
+    if (hi - lo > 1 && D > prm.L) sa_interval(T, n, sa, P + i, D, prm.L, lo, hi, &l2, &h2);
+    const uint32_t pl = lcp[l2], ph = lcp[h2];
+    const uint32_t par = pl > ph ? pl : ph;
+    if (par == 0) { s = 0; continue; }
+    bool at_node = false;
+    if (h2 - l2 >= 2) {
+      const uint32_t t1 = sa[l2], t2 = sa[h2 - 1];
+      const int c1 = t1 + D < n ? (int)T[t1 + D] : -1;
+      const int c2 = t2 + D < n ? (int)T[t2 + D] : -1;
+      at_node = c1 != c2;
+    }
+    s = at_node ? D - 1 : par - 1;
+  }
+}
+
+// number of occurrences at or above the threshold (before the filters)
+__global__ __launch_bounds__(64)
+void pair_count_kernel(const uint8_t* __restrict__ T, uint32_t n, const uint32_t* __restrict__ sa,
+                       const uint8_t* __restrict__ pats, const unsigned long long* __restrict__ pat_off,
+                       PairParams prm, const uint32_t* __restrict__ lo_in, const uint32_t* __restrict__ hi_in,
+                       const uint32_t* __restrict__ thr_in, uint32_t* __restrict__ cnt_out) {
+  const unsigned long long base = pat_off[blockIdx.x];
+  const uint32_t m = (uint32_t)(pat_off[blockIdx.x + 1] - base);
+  const uint8_t* P = pats + base;
+  for (uint32_t i = threadIdx.x; i < m; i += 64) {
+    const uint32_t thr = thr_in[base + i];
+    uint32_t c = 0;
+    if (thr != NONE) {
+      const uint32_t lo = lo_in[base + i], hi = hi_in[base + i];
+      for (uint32_t k = lo; k < hi; ++k) {
+        const uint32_t t = sa[k];
+        if (prev_excluded(T, t, P, i)) continue;
+        if (extend(T, n, t, P, m, i, prm.L) >= thr) ++c;
+      }
+    }
+    cnt_out[base + i] = c;
+  }
+}
+
+struct Cand { uint32_t t, l; };
+
+// write the candidates of each position, sort them by t, apply filter (a)
+// (src/max-emb-graph.c:301-334) and move the survivors to the front of the position's slot
+__global__ __launch_bounds__(64)
+void pair_fill_kernel(const uint8_t* __restrict__ T, uint32_t n, const uint32_t* __restrict__ sa,
+                      const uint8_t* __restrict__ pats, const unsigned long long* __restrict__ pat_off,
+                      PairParams prm, const uint32_t* __restrict__ lo_in, const uint32_t* __restrict__ hi_in,
+                      const uint32_t* __restrict__ thr_in, const unsigned long long* __restrict__ cand_off,
+                      Cand* __restrict__ cand, uint32_t* __restrict__ cnt_a) {
+  const unsigned long long base = pat_off[blockIdx.x];
+  const uint32_t m = (uint32_t)(pat_off[blockIdx.x + 1] - base);
+  const uint8_t* P = pats + base;
+  for (uint32_t i = threadIdx.x; i < m; i += 64) {
+    const uint32_t thr = thr_in[base + i];
+    uint32_t c = 0;
+    if (thr != NONE) {
+      Cand* slot = cand + cand_off[base + i];
+      const uint32_t lo = lo_in[base + i], hi = hi_in[base + i];
+      for (uint32_t k = lo; k < hi; ++k) {
+        const uint32_t t = sa[k];
+        if (prev_excluded(T, t, P, i)) continue;
+        const uint32_t l = extend(T, n, t, P, m, i, prm.L);
+        if (l < thr) continue;
+        uint32_t q = c++;                                  // insertion sort by t (t is unique)
+        while (q > 0 && slot[q - 1].t > t) { slot[q] = slot[q - 1]; --q; }
+        slot[q].t = t; slot[q].l = l;
+      }
+      // filter (a): PJ dies when an earlier PI (smaller t) covers it or is its twin shifted by one.
+      // The reference tests against ALL earlier entries, dead ones included, so deaths are
+      // decided on the unmodified sorted list: mark with the top bit of l, then compact.
+      for (uint32_t j = c; j-- > 1;) {
+        const uint32_t tj = slot[j].t, lj = slot[j].l & 0x7FFFFFFFu;
+        for (uint32_t q = j; q-- > 0;) {
+          const uint32_t ti = slot[q].t, li = slot[q].l & 0x7FFFFFFFu;
+          if ((tj > ti && tj + lj <= ti + li) || (tj == ti + 1 && lj == li)) { slot[j].l |= 0x80000000u; break; }
+        }
+      }
+      uint32_t w = 0;
+      for (uint32_t k = 0; k < c; ++k)
+        if (!(slot[k].l & 0x80000000u)) slot[w++] = slot[k];
+      c = w;
+    }
+    cnt_a[base + i] = c;
+  }
+}
+
+// filter (b) (src/max-emb-graph.c:349-375): position i loses I1 when position i-1 (after filter
+// (a), before (b)) holds I with I.t == I1.t and I.l >= I1.l.  Flags only: lists stay intact.
+__global__ __launch_bounds__(64)
+void pair_cross_kernel(const unsigned long long* __restrict__ pat_off,
+                       const unsigned long long* __restrict__ cand_off, const Cand* __restrict__ cand,
+                       const uint32_t* __restrict__ cnt_a, uint8_t* __restrict__ keep,
+                       uint32_t* __restrict__ cnt_b) {
+  const unsigned long long base = pat_off[blockIdx.x];
+  const uint32_t m = (uint32_t)(pat_off[blockIdx.x + 1] - base);
+  for (uint32_t i = threadIdx.x; i < m; i += 64) {
+    const uint32_t c = cnt_a[base + i];
+    const unsigned long long off = cand_off[base + i];
+    uint32_t kept = 0;
+    if (c) {
+      const uint32_t cp = i > 0 ? cnt_a[base + i - 1] : 0;
+      const Cand* prev = i > 0 ? cand + cand_off[base + i - 1] : nullptr;
+      for (uint32_t k = 0; k < c; ++k) {
+        const Cand x = cand[off + k];
+        bool rim = false;
+        for (uint32_t q = 0; q < cp && !rim; ++q) rim = prev[q].t == x.t && prev[q].l >= x.l;
+        keep[off + k] = rim ? 0 : 1;
+        kept += rim ? 0 : 1;
+      }
+    }
+    cnt_b[base + i] = kept;
+  }
+}
+
+__global__ __launch_bounds__(64)
+void pair_emit_kernel(const unsigned long long* __restrict__ pat_off,
+                      const unsigned long long* __restrict__ cand_off, const Cand* __restrict__ cand,
+                      const uint32_t* __restrict__ cnt_a, const uint8_t* __restrict__ keep,
+                      const unsigned long long* __restrict__ out_off, pgpu_pairing* __restrict__ out,
+                      unsigned long long* __restrict__ out_first, uint32_t n_pat, unsigned long long total_pos) {
+  const unsigned long long base = pat_off[blockIdx.x];
+  const uint32_t m = (uint32_t)(pat_off[blockIdx.x + 1] - base);
+  if (threadIdx.x == 0) {
+    out_first[blockIdx.x] = base < total_pos ? out_off[base] : out_off[total_pos];
+    if (blockIdx.x == n_pat - 1) out_first[n_pat] = out_off[total_pos];
+  }
+  for (uint32_t i = threadIdx.x; i < m; i += 64) {
+    const uint32_t c = cnt_a[base + i];
+    const unsigned long long off = cand_off[base + i];
+    unsigned long long w = out_off[base + i];
+    for (uint32_t k = 0; k < c; ++k) {
+      if (!keep[off + k]) continue;
+      out[w].p = (int32_t)i; out[w].t = (int32_t)cand[off + k].t; out[w].l = (int32_t)cand[off + k].l;
+      ++w;
+    }
+  }
+}
+
+template <class T> hipError_t dmalloc(T** p, size_t count) {
+  return hipMalloc((void**)p, (count ? count : 1) * sizeof(T));
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// C-ABI: index
+// ---------------------------------------------------------------------------------------------
+#define TRY_HIP(call)                                                                        \
+  do {                                                                                       \
+    hipError_t e_ = (call);                                                                  \
+    if (e_ != hipSuccess) { rc = pgpu_ctx_fail(ctx, e_ == hipErrorOutOfMemory ? PGPU_ENOMEM : PGPU_EDEVICE, \
+                                               hipGetErrorString(e_)); goto done; }          \
+  } while (0)
 
 extern "C" int pgpu_index_build(pgpu_ctx* ctx, const char* genomic, size_t len, pgpu_index** out) {
   if (!ctx || !out || (len && !genomic)) return PGPU_EINVAL;
@@ -19,13 +338,54 @@ extern "C" int pgpu_index_build(pgpu_ctx* ctx, const char* genomic, size_t len, 
   if (!idx) return pgpu_ctx_fail(ctx, PGPU_ENOMEM, "out of host memory");
   idx->len = len;
   hipStream_t st = pgpu_ctx_stream(ctx);
-  if (hipMalloc(&idx->d_gen, len + 64) != hipSuccess) { delete idx; return pgpu_ctx_fail(ctx, PGPU_ENOMEM, "hipMalloc genomic"); }
-  if (hipMemsetAsync(idx->d_gen, 0, len + 64, st) != hipSuccess ||
-      (len && hipMemcpyAsync(idx->d_gen, genomic, len, hipMemcpyHostToDevice, st) != hipSuccess) ||
-      hipStreamSynchronize(st) != hipSuccess) {
-    hipFree(idx->d_gen); delete idx;
-    return pgpu_ctx_fail(ctx, PGPU_EDEVICE, "genomic upload failed");
+  const uint32_t n = (uint32_t)len;
+  int rc = PGPU_OK;
+  uint32_t *rank = nullptr, *sa2 = nullptr, *flags = nullptr, *newrank = nullptr;
+  unsigned long long *keys = nullptr, *keys2 = nullptr;
+  void* tmp = nullptr;
+  size_t tmp_bytes = 0;
+  const dim3 blk(256), grd((n + 255) / 256 + 1);
+
+  TRY_HIP(hipMalloc((void**)&idx->d_gen, len + 64));
+  TRY_HIP(hipMemsetAsync(idx->d_gen, 0, len + 64, st));
+  if (len) TRY_HIP(hipMemcpyAsync(idx->d_gen, genomic, len, hipMemcpyHostToDevice, st));
+  TRY_HIP(dmalloc(&idx->d_sa, n + 1));
+  TRY_HIP(dmalloc(&idx->d_lcp, n + 2));
+  if (n > 0) {
+    TRY_HIP(dmalloc(&rank, n)); TRY_HIP(dmalloc(&sa2, n)); TRY_HIP(dmalloc(&flags, n));
+    TRY_HIP(dmalloc(&newrank, n)); TRY_HIP(dmalloc(&keys, n)); TRY_HIP(dmalloc(&keys2, n));
+    {
+      size_t b1 = 0, b2 = 0;
+      TRY_HIP(rocprim::radix_sort_pairs(nullptr, b1, keys, keys2, idx->d_sa, sa2, n, 0, 64, st));
+      TRY_HIP(rocprim::inclusive_scan(nullptr, b2, flags, newrank, n, rocprim::plus<uint32_t>(), st));
+      tmp_bytes = b1 > b2 ? b1 : b2;
+      TRY_HIP(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
+    }
+    hipLaunchKernelGGL(sa_init_kernel, grd, blk, 0, st, idx->d_gen, n, rank, idx->d_sa);
+    for (uint32_t h = 0;; h = h ? h * 2 : 1) {
+      // h == 0: sort by the first character alone (key low half = 0 because i+0 < n gives rank[i]
+      // again -- harmless duplicate), afterwards by (rank of 2^k prefix, rank of the next 2^k)
+      hipLaunchKernelGGL(sa_keys_kernel, grd, blk, 0, st, rank, idx->d_sa, n, h ? h : n, keys);
+      size_t b = tmp_bytes;
+      TRY_HIP(rocprim::radix_sort_pairs(tmp, b, keys, keys2, idx->d_sa, sa2, n, 0, 64, st));
+      hipLaunchKernelGGL(sa_flags_kernel, grd, blk, 0, st, keys2, n, flags);
+      b = tmp_bytes;
+      TRY_HIP(rocprim::inclusive_scan(tmp, b, flags, newrank, n, rocprim::plus<uint32_t>(), st));
+      hipLaunchKernelGGL(sa_rerank_kernel, grd, blk, 0, st, sa2, newrank, n, rank);
+      TRY_HIP(hipMemcpyAsync(idx->d_sa, sa2, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+      uint32_t distinct = 0;
+      TRY_HIP(hipMemcpyAsync(&distinct, newrank + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+      TRY_HIP(hipStreamSynchronize(st));
+      if (distinct == n) break;
+      if (h >= n) { rc = pgpu_ctx_fail(ctx, PGPU_EDEVICE, "suffix array construction did not converge"); goto done; }
+    }
   }
+  hipLaunchKernelGGL(lcp_kernel, grd, blk, 0, st, idx->d_gen, idx->d_sa, n, idx->d_lcp);
+  TRY_HIP(hipStreamSynchronize(st));
+  TRY_HIP(hipGetLastError());
+done:
+  hipFree(rank); hipFree(sa2); hipFree(flags); hipFree(newrank); hipFree(keys); hipFree(keys2); hipFree(tmp);
+  if (rc != PGPU_OK) { hipFree(idx->d_gen); hipFree(idx->d_sa); hipFree(idx->d_lcp); delete idx; return rc; }
   *out = idx;
   return PGPU_OK;
 }
@@ -33,19 +393,183 @@ extern "C" int pgpu_index_build(pgpu_ctx* ctx, const char* genomic, size_t len, 
 extern "C" int pgpu_index_destroy(pgpu_ctx* ctx, pgpu_index* idx) {
   if (!ctx || !idx) return PGPU_EINVAL;
   hipStreamSynchronize(pgpu_ctx_stream(ctx));
-  hipFree(idx->d_gen); hipFree(idx->d_sa);
+  hipFree(idx->d_gen); hipFree(idx->d_sa); hipFree(idx->d_lcp);
   delete idx;
   return PGPU_OK;
 }
 
 extern "C" int pgpu_index_suffix_array(pgpu_ctx* ctx, const pgpu_index* idx, uint32_t* sa_out, size_t cap) {
-  (void)idx; (void)sa_out; (void)cap;
-  return pgpu_ctx_fail(ctx, PGPU_ENOSYS, "suffix array not built in this build");
+  if (!ctx || !idx || !sa_out) return PGPU_EINVAL;
+  if (cap < idx->len) return pgpu_ctx_fail(ctx, PGPU_ENOSPC, "suffix array buffer too small");
+  hipStream_t st = pgpu_ctx_stream(ctx);
+  if (idx->len && (hipMemcpyAsync(sa_out, idx->d_sa, idx->len * sizeof(uint32_t), hipMemcpyDeviceToHost, st) != hipSuccess ||
+                   hipStreamSynchronize(st) != hipSuccess))
+    return pgpu_ctx_fail(ctx, PGPU_EDEVICE, "suffix array download failed");
+  return PGPU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// C-ABI: pairings (plan = patterns resident in HBM; launch = all kernels; fetch = triples)
+// ---------------------------------------------------------------------------------------------
+struct pgpu_pairing_plan {
+  const pgpu_index* idx = nullptr;
+  size_t n_pat = 0;
+  unsigned long long total_pos = 0;
+  uint8_t* d_pats = nullptr;
+  unsigned long long* d_pat_off = nullptr;
+  uint32_t *d_lo = nullptr, *d_hi = nullptr, *d_a = nullptr, *d_thr = nullptr, *d_cnt = nullptr,
+           *d_cnt_a = nullptr, *d_cnt_b = nullptr;
+  unsigned long long *d_cand_off = nullptr, *d_out_off = nullptr, *d_out_first = nullptr;
+  Cand* d_cand = nullptr;
+  uint8_t* d_keep = nullptr;
+  pgpu_pairing* d_out = nullptr;
+  size_t cand_cap = 0, out_cap = 0;
+  void* d_tmp = nullptr;
+  size_t tmp_bytes = 0;
+  unsigned long long n_cand = 0, n_out = 0;
+  hipEvent_t ev[8] = {nullptr};
+  float ms[7] = {0};
+};
+
+static void pairing_plan_free(pgpu_pairing_plan* p) {
+  if (!p) return;
+  hipFree(p->d_pats); hipFree(p->d_pat_off); hipFree(p->d_lo); hipFree(p->d_hi); hipFree(p->d_a);
+  hipFree(p->d_thr); hipFree(p->d_cnt); hipFree(p->d_cnt_a); hipFree(p->d_cnt_b);
+  hipFree(p->d_cand_off); hipFree(p->d_out_off); hipFree(p->d_out_first); hipFree(p->d_cand);
+  hipFree(p->d_keep); hipFree(p->d_out); hipFree(p->d_tmp);
+  for (auto& e : p->ev) if (e) hipEventDestroy(e);
+  delete p;
+}
+
+extern "C" int pgpu_pairing_plan_create(pgpu_ctx* ctx, const pgpu_index* idx, const char* patterns,
+                                        const uint64_t* pat_off, size_t n_pat, pgpu_pairing_plan** out) {
+  if (!ctx || !idx || !out || !pat_off || (n_pat && pat_off[n_pat] && !patterns)) return PGPU_EINVAL;
+  *out = nullptr;
+  for (size_t i = 0; i < n_pat; ++i)
+    if (pat_off[i + 1] < pat_off[i] || pat_off[i + 1] - pat_off[i] > 0x7fffffffull) return pgpu_ctx_fail(ctx, PGPU_EINVAL, "bad pattern offsets");
+  pgpu_pairing_plan* p = new (std::nothrow) pgpu_pairing_plan();
+  if (!p) return pgpu_ctx_fail(ctx, PGPU_ENOMEM, "out of host memory");
+  int rc = PGPU_OK;
+  hipStream_t st = pgpu_ctx_stream(ctx);
+  p->idx = idx; p->n_pat = n_pat; p->total_pos = n_pat ? pat_off[n_pat] : 0;
+  const size_t tp = (size_t)p->total_pos;
+  TRY_HIP(hipMalloc((void**)&p->d_pats, tp + 64));
+  TRY_HIP(dmalloc(&p->d_pat_off, n_pat + 1));
+  TRY_HIP(dmalloc(&p->d_lo, tp)); TRY_HIP(dmalloc(&p->d_hi, tp)); TRY_HIP(dmalloc(&p->d_a, tp));
+  TRY_HIP(dmalloc(&p->d_thr, tp)); TRY_HIP(dmalloc(&p->d_cnt, tp + 1)); TRY_HIP(dmalloc(&p->d_cnt_a, tp + 1));
+  TRY_HIP(dmalloc(&p->d_cnt_b, tp + 1));
+  TRY_HIP(dmalloc(&p->d_cand_off, tp + 1)); TRY_HIP(dmalloc(&p->d_out_off, tp + 1));
+  TRY_HIP(dmalloc(&p->d_out_first, n_pat + 1));
+  {
+    size_t b = 0;
+    TRY_HIP(rocprim::exclusive_scan(nullptr, b, p->d_cnt, p->d_cand_off, 0ull, tp + 1, rocprim::plus<unsigned long long>(), st));
+    p->tmp_bytes = b;
+    TRY_HIP(hipMalloc(&p->d_tmp, b ? b : 16));
+  }
+  for (auto& e : p->ev) TRY_HIP(hipEventCreate(&e));
+  if (tp) TRY_HIP(hipMemcpyAsync(p->d_pats, patterns, tp, hipMemcpyHostToDevice, st));
+  TRY_HIP(hipMemcpyAsync(p->d_pat_off, pat_off, (n_pat + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+  TRY_HIP(hipStreamSynchronize(st));
+done:
+  if (rc != PGPU_OK) { pairing_plan_free(p); return rc; }
+  *out = p;
+  return PGPU_OK;
+}
+
+// runs every kernel; the two size-dependent buffers (candidates, output) grow on demand, which
+// costs one stream synchronisation after each scan (the totals are needed on the host anyway)
+extern "C" int pgpu_pairing_plan_run(pgpu_ctx* ctx, pgpu_pairing_plan* p, const pgpu_pairing_params* params) {
+  if (!ctx || !p || !params || params->min_factor_len == 0) return PGPU_EINVAL;
+  int rc = PGPU_OK;
+  hipStream_t st = pgpu_ctx_stream(ctx);
+  const pgpu_index* ix = p->idx;
+  const uint32_t n = (uint32_t)ix->len;
+  const size_t tp = (size_t)p->total_pos;
+  const PairParams prm{params->min_factor_len, params->min_string_depth_rate};
+  const dim3 pgrid((unsigned)(p->n_pat ? p->n_pat : 1)), pblk(64);
+  p->n_cand = p->n_out = 0;
+  if (p->n_pat == 0) return PGPU_OK;
+  size_t b;
+  TRY_HIP(hipEventRecord(p->ev[0], st));
+  hipLaunchKernelGGL(pair_locate_kernel, pgrid, pblk, 0, st, ix->d_gen, n, ix->d_sa, p->d_pats, p->d_pat_off, prm, p->d_lo, p->d_hi, p->d_a);
+  TRY_HIP(hipEventRecord(p->ev[1], st));
+  hipLaunchKernelGGL(pair_chain_kernel, dim3((unsigned)((p->n_pat + 63) / 64)), pblk, 0, st, ix->d_gen, n, ix->d_sa, ix->d_lcp,
+                     p->d_pats, p->d_pat_off, (uint32_t)p->n_pat, prm, p->d_lo, p->d_hi, p->d_a, p->d_thr);
+  TRY_HIP(hipEventRecord(p->ev[2], st));
+  hipLaunchKernelGGL(pair_count_kernel, pgrid, pblk, 0, st, ix->d_gen, n, ix->d_sa, p->d_pats, p->d_pat_off, prm, p->d_lo, p->d_hi, p->d_thr, p->d_cnt);
+  TRY_HIP(hipMemsetAsync(p->d_cnt + tp, 0, sizeof(uint32_t), st));
+  b = p->tmp_bytes;
+  TRY_HIP(rocprim::exclusive_scan(p->d_tmp, b, p->d_cnt, p->d_cand_off, 0ull, tp + 1, rocprim::plus<unsigned long long>(), st));
+  TRY_HIP(hipEventRecord(p->ev[3], st));
+  TRY_HIP(hipMemcpyAsync(&p->n_cand, p->d_cand_off + tp, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+  TRY_HIP(hipStreamSynchronize(st));
+  if (p->n_cand > p->cand_cap) {
+    hipFree(p->d_cand); hipFree(p->d_keep); p->d_cand = nullptr; p->d_keep = nullptr;
+    p->cand_cap = (size_t)(p->n_cand + p->n_cand / 8 + 1024);
+    TRY_HIP(dmalloc(&p->d_cand, p->cand_cap));
+    TRY_HIP(dmalloc(&p->d_keep, p->cand_cap));
+  }
+  hipLaunchKernelGGL(pair_fill_kernel, pgrid, pblk, 0, st, ix->d_gen, n, ix->d_sa, p->d_pats, p->d_pat_off, prm, p->d_lo, p->d_hi, p->d_thr,
+                     p->d_cand_off, p->d_cand, p->d_cnt_a);
+  TRY_HIP(hipEventRecord(p->ev[4], st));
+  hipLaunchKernelGGL(pair_cross_kernel, pgrid, pblk, 0, st, p->d_pat_off, p->d_cand_off, p->d_cand, p->d_cnt_a, p->d_keep, p->d_cnt_b);
+  TRY_HIP(hipMemsetAsync(p->d_cnt_b + tp, 0, sizeof(uint32_t), st));
+  b = p->tmp_bytes;
+  TRY_HIP(rocprim::exclusive_scan(p->d_tmp, b, p->d_cnt_b, p->d_out_off, 0ull, tp + 1, rocprim::plus<unsigned long long>(), st));
+  TRY_HIP(hipEventRecord(p->ev[5], st));
+  TRY_HIP(hipMemcpyAsync(&p->n_out, p->d_out_off + tp, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+  TRY_HIP(hipStreamSynchronize(st));
+  if (p->n_out > p->out_cap) {
+    hipFree(p->d_out); p->d_out = nullptr;
+    p->out_cap = (size_t)(p->n_out + p->n_out / 8 + 1024);
+    TRY_HIP(dmalloc(&p->d_out, p->out_cap));
+  }
+  hipLaunchKernelGGL(pair_emit_kernel, pgrid, pblk, 0, st, p->d_pat_off, p->d_cand_off, p->d_cand, p->d_cnt_a, p->d_keep, p->d_out_off,
+                     p->d_out, p->d_out_first, (uint32_t)p->n_pat, p->total_pos);
+  TRY_HIP(hipEventRecord(p->ev[6], st));
+  TRY_HIP(hipStreamSynchronize(st));
+  TRY_HIP(hipGetLastError());
+  for (int k = 0; k < 6; ++k) hipEventElapsedTime(&p->ms[k], p->ev[k], p->ev[k + 1]);
+done:
+  return rc;
+}
+
+extern "C" uint64_t pgpu_pairing_plan_count(const pgpu_pairing_plan* p) { return p ? p->n_out : 0; }
+extern "C" uint64_t pgpu_pairing_plan_positions(const pgpu_pairing_plan* p) { return p ? p->total_pos : 0; }
+extern "C" double pgpu_pairing_plan_kernel_ms(const pgpu_pairing_plan* p, int k) { return (p && k >= 0 && k < 6) ? p->ms[k] : 0.0; }
+
+extern "C" int pgpu_pairing_plan_fetch(pgpu_ctx* ctx, pgpu_pairing_plan* p, pgpu_pairing* out, size_t out_cap,
+                                       uint64_t* out_first) {
+  if (!ctx || !p || !out_first) return PGPU_EINVAL;
+  if (out_cap < p->n_out) return pgpu_ctx_fail(ctx, PGPU_ENOSPC, "pairing buffer too small");
+  int rc = PGPU_OK;
+  hipStream_t st = pgpu_ctx_stream(ctx);
+  if (p->n_pat == 0) { out_first[0] = 0; return PGPU_OK; }
+  if (p->n_out) TRY_HIP(hipMemcpyAsync(out, p->d_out, (size_t)p->n_out * sizeof(pgpu_pairing), hipMemcpyDeviceToHost, st));
+  TRY_HIP(hipMemcpyAsync(out_first, p->d_out_first, (p->n_pat + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+  TRY_HIP(hipStreamSynchronize(st));
+done:
+  return rc;
+}
+
+extern "C" int pgpu_pairing_plan_destroy(pgpu_ctx* ctx, pgpu_pairing_plan* p) {
+  if (!ctx || !p) return PGPU_EINVAL;
+  hipStreamSynchronize(pgpu_ctx_stream(ctx));
+  pairing_plan_free(p);
+  return PGPU_OK;
 }
 
 extern "C" int pgpu_pairings(pgpu_ctx* ctx, const pgpu_index* idx, const char* patterns,
                              const uint64_t* pat_off, size_t n_pat, const pgpu_pairing_params* params,
                              pgpu_pairing* out, size_t out_cap, uint64_t* out_first, size_t* n_out) {
-  (void)idx; (void)patterns; (void)pat_off; (void)n_pat; (void)params; (void)out; (void)out_cap; (void)out_first; (void)n_out;
-  return pgpu_ctx_fail(ctx, PGPU_ENOSYS, "pairings not implemented in this build");
+  pgpu_pairing_plan* p = nullptr;
+  int rc = pgpu_pairing_plan_create(ctx, idx, patterns, pat_off, n_pat, &p);
+  if (rc != PGPU_OK) return rc;
+  rc = pgpu_pairing_plan_run(ctx, p, params);
+  if (rc == PGPU_OK) {
+    if (n_out) *n_out = (size_t)p->n_out;
+    rc = pgpu_pairing_plan_fetch(ctx, p, out, out_cap, out_first);
+  }
+  pgpu_pairing_plan_destroy(ctx, p);
+  return rc;
 }
