@@ -2,13 +2,15 @@
 """bench.py -- est-fact hot path on MI355X: one step = one pass of the accelerated stages over one
 C3 batch (BASELINE.json configs[2]: 200 kb genomic x 100 000 ESTs ~600 bp, 3 % errors).
 
-What a step runs TODAY (round 1): the batched DP stage -- every dynamic-programming call the
-reference est-fact makes for the batch (ALIGN, GAP, ED/EDM, KBAND, BORDERS, LCF; AFFIX when
-present), operands resident in HBM, through the C-ABI (libpintron_gpu.so).  The job mix is the
+What a step runs TODAY (round 1), all through the C-ABI (libpintron_gpu.so), inputs resident in HBM:
+  1. the pairing stage (build_vertex_set replacement) for the 100 000 ESTs of the batch over the
+     device suffix-array index of the 200 kb genomic;
+  2. the batched DP stage -- every dynamic-programming call the reference est-fact makes for the
+     batch (ALIGN, GAP, ED/EDM, KBAND, BORDERS, LCF; AFFIX when present).  The job mix is the
 reference's own: tests/golden/c3_sample_jobs.jsonl.gz holds the DP calls of the unmodified
 reference on a seeded 400-EST C3 sample (tools/make_bench_fixture.py), tiled to 100 000 ESTs.
-The pairing/MEG/embedding host logic of est-fact is NOT in the step yet; `config.stages` says so
-and the value must be read as the throughput of the DP stage, not of the whole program.
+The MEG/embedding/filter host logic of est-fact is NOT in the step yet; `config.stages` says so
+and the value must be read as the throughput of the accelerated stages, not of the whole program.
 
 Contract: python bench.py --gpus N --steps K --warmup W ; one JSON line on rank 0.
 """
@@ -144,8 +146,16 @@ def main():
     import pintron_amd.capi as capi
     from pintron_amd import synth
     ctx = capi.Context(local if world > 1 else 0)       # raises without the HIP library / a GPU
-    genomic = synth.make("C3", n_est=1).genomic           # the seeded 200 kb C3 genomic
+    wl = synth.make("C3", n_est=args.ests)                # seeded C3: 200 kb genomic + ESTs
+    genomic = wl.genomic
+    t0 = time.perf_counter()
     idx = capi.Index(ctx, genomic)
+    t_index = time.perf_counter() - t0
+    # patterns as est-fact sees them after strand handling (src/main-est-fact.c:190-213):
+    # /clone_end=5' ESTs are reverse-complemented
+    comp = bytes.maketrans(b"ACGTN", b"TGCAN")
+    pats = [s.translate(comp)[::-1] if t["rc"] else s for s, t in zip(wl.est_seqs, wl.truth)]
+    pplan = capi.PairingPlan(ctx, idx, pats)
     tile, tile_arena, meta = load_tile(genomic)
     n_tiles = max(1, -(-args.ests // meta["n_est"]))
     n_est = n_tiles * meta["n_est"]
@@ -162,6 +172,7 @@ def main():
             gather_list = [torch.empty_like(rec) for _ in range(world)]
 
     def step():
+        pplan.run(15, 0.2)                 # options.ggo defaults: -l 15, -d 0.2
         plan.launch()
         plan.sync()
         if world > 1:
@@ -177,10 +188,13 @@ def main():
     for _ in range(args.warmup):
         step()
     groups_acc = None
+    pair_ms = {k: 0.0 for k in capi.PairingPlan.STAGES}
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+        for k, v in pplan.stage_ms().items():
+            pair_ms[k] += v / args.steps
         g = plan.groups()
         if groups_acc is None:
             groups_acc = g
@@ -219,8 +233,9 @@ def main():
             "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8/int32", "data": "synthetic",
             "config": {"workload": "C3: 200 kb genomic x %d ESTs ~600 bp, 3%% errors, per GPU" % n_est,
-                       "stages": "batched DP stage only (reference's own DP call mix, %d calls/step/GPU);"
-                                 " pairing/MEG/embedding host logic not yet in the step" % len(jobs),
+                       "stages": "pairing stage (%d pattern positions, %d pairings) + batched DP stage (reference's own DP"
+                                 " call mix, %d calls) per step per GPU; MEG/embedding/filter host logic not yet in the step"
+                                 % (sum(len(x) for x in pats), pplan.ctx.L.pgpu_pairing_plan_count(pplan.h), len(jobs)),
                        "ests_per_gpu": n_est, "dp_jobs_per_gpu": int(len(jobs)), "parallelism": "est-shard x%d" % world},
             "dp_mcells_per_s": (tile_cells * n_tiles * world / (dt / args.steps) / 1e6) if tile_cells else None,
             "roofline": {"bound": "hbm", "kernel": dom["name"], "achieved": dom["algo_bytes"] / (dom["ms"] * 1e-3) / 1e9 if dom["ms"] else None,
@@ -229,7 +244,10 @@ def main():
                          "traffic": None, "avg_launch_ms": dom["ms"], "algo_bytes_per_launch": dom["algo_bytes"]},
             "kernels": [{"name": g["name"], "jobs": g["jobs"], "ms": round(g["ms"], 4),
                          "algo_GBs": round(g["algo_bytes"] / (g["ms"] * 1e-3) / 1e9, 1) if g["ms"] else None}
-                        for g in groups_acc],
+                        for g in groups_acc] +
+                       [{"name": "pair_" + k, "jobs": len(pats), "ms": round(v, 4), "algo_GBs": None}
+                        for k, v in pair_ms.items()],
+            "index_build_s": t_index,
             "upload_s": t_upload,
         }
         if base:
@@ -239,6 +257,7 @@ def main():
                                    "mcells_per_s": base["mcells_per_s"]}
         print(json.dumps(out), flush=True)
     plan.close()
+    pplan.close()
     idx.close()
     ctx.close()
     if world > 1:
