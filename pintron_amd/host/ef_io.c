@@ -1,0 +1,267 @@
+/* Multifasta input, sequence preparation and record output of est-fact.
+ * Behaviour follows src/io-multifasta.c and src/main-est-fact.c of the reference (cited per
+ * function); the implementation is our own. */
+#define _GNU_SOURCE
+#include <ctype.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "estfact.h"
+
+static char* dup_range(const char* s, size_t n) {
+  char* r = (char*)malloc(n + 1);
+  memcpy(r, s, n);
+  r[n] = '\0';
+  return r;
+}
+
+void ef_seq_free(ef_seq* s) {
+  if (!s) return;
+  free(s->id); free(s->seq); free(s->original_seq); free(s->gb); free(s->chr);
+  free(s);
+}
+
+static ef_seq* seq_new(void) {
+  ef_seq* s = (ef_seq*)calloc(1, sizeof(ef_seq));
+  s->strand = 1;
+  return s;
+}
+
+/* One logical line: bytes up to '\n', then trailing bytes whose SIGNED value is below ' ' are
+ * dropped (src/util.c:166-173 strips with a plain `char` comparison, so bytes >= 0x80 go too). */
+typedef struct { const char* p; size_t len; } line_t;
+
+static bool next_line(const char* buf, size_t size, size_t* pos, line_t* ln) {
+  if (*pos >= size) return false;
+  const char* start = buf + *pos;
+  const char* nl = (const char*)memchr(start, '\n', size - *pos);
+  size_t raw = nl ? (size_t)(nl - start) + 1 : size - *pos;
+  *pos += raw;
+  while (raw > 0 && (signed char)start[raw - 1] < ' ') --raw;
+  ln->p = start; ln->len = raw;
+  return true;
+}
+
+/* read_multifasta (src/io-multifasta.c:133-164) with getData (:94-130): a record starts at a line
+ * beginning with '>', its sequence is the concatenation of the following non-empty lines up to
+ * the next '>' line, the literal line "#\#" or the end of the file. */
+long ef_read_multifasta(const char* path, ef_seq*** out) {
+  FILE* f = fopen(path, "rb");
+  if (!f) return -1;
+  fseek(f, 0, SEEK_END);
+  const long sz = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  char* buf = (char*)malloc((size_t)sz + 1);
+  if (fread(buf, 1, (size_t)sz, f) != (size_t)sz) { fclose(f); free(buf); return -1; }
+  fclose(f);
+  size_t pos = 0, cap = 16, n = 0;
+  ef_seq** v = (ef_seq**)malloc(cap * sizeof(ef_seq*));
+  line_t ln;
+  bool have = next_line(buf, (size_t)sz, &pos, &ln);
+  while (have) {
+    if (ln.len > 0 && ln.p[0] == '>') {
+      ef_seq* s = seq_new();
+      s->id = dup_range(ln.p + 1, ln.len - 1);
+      size_t scap = 256, slen = 0;
+      char* data = (char*)malloc(scap);
+      while ((have = next_line(buf, (size_t)sz, &pos, &ln))) {
+        if (ln.len > 0 && ln.p[0] == '>') break;
+        if (ln.len == 3 && memcmp(ln.p, "#\\#", 3) == 0) break;
+        if (ln.len == 0) continue;
+        /* an embedded NUL would end the reference's C string copy of the line */
+        size_t use = strnlen(ln.p, ln.len);
+        if (slen + use + 1 > scap) { while (slen + use + 1 > scap) scap *= 2; data = (char*)realloc(data, scap); }
+        memcpy(data + slen, ln.p, use);
+        slen += use;
+      }
+      data[slen] = '\0';
+      s->seq = data;
+      s->original_seq = dup_range(data, slen);
+      if (n == cap) { cap *= 2; v = (ef_seq**)realloc(v, cap * sizeof(ef_seq*)); }
+      v[n++] = s;
+    } else {
+      have = next_line(buf, (size_t)sz, &pos, &ln);
+    }
+  }
+  free(buf);
+  *out = v;
+  return (long)n;
+}
+
+/* parse_genomic_header (src/io-multifasta.c:307-423): ">chr:start:end:+-1", else defaults */
+void ef_parse_genomic_header(ef_seq* gen) {
+  char* h = strdup(gen->id);
+  char* fields[5] = {0};
+  int nf = 0;
+  char* cur = h;
+  while (cur && nf < 5) { fields[nf++] = strsep(&cur, ":"); }
+  bool ok = (nf == 4 && cur == NULL);
+  if (ok) {
+    const int a = atoi(fields[1]), b = atoi(fields[2]), st = atoi(fields[3]);
+    ok = a >= 1 && b >= 1 && (st == -1 || st == 1);
+    if (ok) {
+      gen->chr = strdup(fields[0]);
+      gen->abs_start = a; gen->abs_end = b; gen->strand = st;
+      snprintf(gen->strand_as_read, sizeof gen->strand_as_read, "%s", fields[3]);
+    }
+  }
+  if (!ok) {
+    fprintf(stderr, "* ERROR The header of the genomic file is not in the correct standard! "
+                    "This may lead to prediction errors.\n");
+    gen->chr = strdup("unknown");
+    gen->abs_start = 1; gen->abs_end = (int)strlen(gen->seq); gen->strand = 1;
+    strcpy(gen->strand_as_read, "+1");
+  }
+  free(h);
+}
+
+/* Ntails_removal (src/io-multifasta.c:830-868): upper-case N runs at both ends of the working
+ * sequence; the original sequence keeps them and pref_N_length shifts the output coordinates. */
+int ef_ntails_removal(ef_seq* gen) {
+  char* s = gen->seq;
+  size_t len = strlen(s), pref = 0, suff = 0;
+  while (s[pref] == 'N') ++pref;
+  if (pref) memmove(s, s + pref, len - pref + 1);
+  gen->pref_N_length = (int)pref;
+  len -= pref;
+  while (suff < len && s[len - 1 - suff] == 'N') ++suff;
+  if (suff == len) return -1;
+  s[len - suff] = '\0';
+  gen->suff_N_length = (int)suff;
+  return 0;
+}
+
+/* set_EST_GB_identification (src/io-multifasta.c:279-304) */
+void ef_set_gb_identification(ef_seq* est) {
+  const char* p = strstr(est->id, "/gb=");
+  if (!p) p = strstr(est->id, "/GB=");
+  if (!p) return;
+  p += 4;
+  size_t len = 0;
+  while (p[len] != ' ' && p[len] != '/' && p[len] != '\0') ++len;
+  est->gb = dup_range(p, len);
+}
+
+static char complement(char c) {           /* get_Complement (src/io-multifasta.c:40-92) */
+  static const char from[] = "ATCGRYMKBVDHatcgrymkbvdh";
+  static const char to[]   = "TAGCYRKMVBHDtagcyrkmvbhd";
+  const char* q = c ? strchr(from, c) : NULL;
+  return q ? to[q - from] : c;
+}
+
+/* reverse_and_complement (src/io-multifasta.c:506-522).  Both sequences are rewritten from the
+ * WORKING sequence, so a sibling built after polyA/T masking carries the mask characters in its
+ * output sequence too. */
+void ef_reverse_and_complement(ef_seq* est) {
+  const size_t len = strlen(est->seq);
+  if (len == 0) return;
+  size_t left = 0, right = len - 1;
+  while (left <= right) {
+    const char nr = complement(est->seq[left]), nl = complement(est->seq[right]);
+    est->seq[right] = nr; est->seq[left] = nl;
+    est->original_seq[right] = nr; est->original_seq[left] = nl;
+    ++left;
+    if (right == 0) break;
+    --right;
+  }
+}
+
+/* set_EST_Strand_and_RC (src/io-multifasta.c:425-504) */
+void ef_set_strand_and_rc(ef_seq* est) {
+  est->strand_as_read[0] = '\0';
+  const char* gb = est->gb;
+  const bool refseq = gb && gb[0] == 'N' && gb[1] != '\0' && gb[2] == '_' && (gb[1] == 'M' || gb[1] == 'R');
+  if (refseq) {
+    strcpy(est->strand_as_read, "1");
+    est->strand = 1;
+    est->fixed_strand = true;
+  } else {
+    const char* p = strstr(est->id, "/clone_end=");
+    if (!p) p = strstr(est->id, "/CLONE_END=");
+    if (p) {
+      p += 11;
+      int i = 0;
+      while (i < 10 && *p != '\0' && *p != '\'') est->strand_as_read[i++] = *p++;
+      est->strand_as_read[i] = '\0';
+      bool valid = false;
+      if (!strcmp(est->strand_as_read, "3")) { est->strand = 1; valid = true; }
+      else if (!strcmp(est->strand_as_read, "5")) { est->strand = -1; valid = true; }
+      else est->strand = 1;
+      if (valid) {
+        p = strstr(est->id, "/fixed_strand=");
+        if (!p) p = strstr(est->id, "/FIXED_STRAND=");
+        if (p) est->fixed_strand = (p[14] == '1');
+      }
+    } else {
+      est->strand = 1;
+    }
+  }
+  if (est->strand == -1) ef_reverse_and_complement(est);
+}
+
+/* one end of polyAT_substitution (src/io-multifasta.c:662-828); at(i) walks inwards from the end */
+#define POLYA_MIN_LEN 14
+#define POLYA_MIN_FRACTION 0.72
+static int mask_end(char* s, size_t len, bool from_back, char* which) {
+#define AT(i) (*(from_back ? &s[len - 1 - (i)] : &s[(i)]))
+  size_t count_A = 0, count_T = 0, last_A = 0, last_T = 0, last_A_count = 0, last_T_count = 0;
+  size_t i;
+  for (i = 0; i < POLYA_MIN_LEN && i < len; ++i) {
+    if (AT(i) == 'A') { ++count_A; last_A = i; last_A_count = count_A; }
+    if (AT(i) == 'T') { ++count_T; last_T = i; last_T_count = count_T; }
+  }
+  size_t run_A = count_A, run_T = count_T;
+  while (i < len && (run_A >= (POLYA_MIN_FRACTION * POLYA_MIN_LEN) || run_T >= (POLYA_MIN_FRACTION * POLYA_MIN_LEN))) {
+    if (AT(i - POLYA_MIN_LEN) == 'A') --run_A;
+    if (AT(i - POLYA_MIN_LEN) == 'T') --run_T;
+    if (AT(i) == 'A') { ++count_A; ++run_A; last_A = i; last_A_count = count_A; }
+    if (AT(i) == 'T') { ++count_T; ++run_T; last_T = i; last_T_count = count_T; }
+    ++i;
+  }
+  if (last_A < POLYA_MIN_LEN - 1) last_A = POLYA_MIN_LEN - 1;
+  if (last_T < POLYA_MIN_LEN - 1) last_T = POLYA_MIN_LEN - 1;
+  if (last_A_count >= (POLYA_MIN_FRACTION * (last_A + 1)) || last_T_count >= (POLYA_MIN_FRACTION * (last_T + 1))) {
+    const char c = (((double)last_A_count) / (last_A + 1)) >= (((double)last_T_count) / (last_T + 1)) ? 'A' : 'T';
+    const size_t mlen = c == 'A' ? last_A + 1 : last_T + 1;
+    for (i = 0; i < mlen; ++i) AT(i) = c == 'A' ? EF_POLYA_CHR : EF_POLYT_CHR;
+    *which = c;
+    return (int)mlen;
+  }
+  return -1;
+#undef AT
+}
+
+void ef_polyAT_substitution(ef_seq* est) {
+  const size_t len = strlen(est->seq);
+  est->pref_polyA_length = est->suff_polyA_length = -1;
+  est->pref_polyT_length = est->suff_polyT_length = -1;
+  if (len < POLYA_MIN_LEN) return;
+  char c = 0;
+  int m = mask_end(est->seq, len, false, &c);
+  if (m >= 0) { if (c == 'A') est->pref_polyA_length = m; else est->pref_polyT_length = m; }
+  m = mask_end(est->seq, len, true, &c);
+  if (m >= 0) { if (c == 'A') est->suff_polyA_length = m; else est->suff_polyT_length = m; }
+}
+
+/* copy_and_reverse (src/main-est-fact.c:67-87) */
+ef_seq* ef_copy_and_reverse(const ef_seq* est) {
+  ef_seq* r = seq_new();
+  r->seq = strdup(est->seq);
+  r->original_seq = strdup(est->original_seq);
+  ef_reverse_and_complement(r);
+  r->id = strdup(est->id);
+  r->gb = est->gb ? strdup(est->gb) : NULL;
+  r->chr = est->chr ? strdup(est->chr) : NULL;
+  memcpy(r->strand_as_read, est->strand_as_read, sizeof r->strand_as_read);
+  r->strand = -est->strand;
+  r->fixed_strand = est->fixed_strand;
+  r->pref_polyA_length = est->suff_polyT_length;
+  r->suff_polyA_length = est->pref_polyT_length;
+  r->pref_polyT_length = est->suff_polyA_length;
+  r->suff_polyT_length = est->pref_polyA_length;
+  return r;
+}
+
+void ef_write_single_est_info(FILE* f, const ef_seq* s) {
+  fprintf(f, ">%s\n%s\n", s->id, s->original_seq);
+}

@@ -1,0 +1,101 @@
+/* Minimal doubly-linked list used by the est-fact host logic.
+ *
+ * The reference's algorithms (MEG simplification, embedding enumeration, filters) are defined
+ * on linked lists that are modified WHILE being iterated, and their results depend on the exact
+ * iterator behaviour of the reference's container (src/list.c, include/list.h:209-280): the
+ * iterator caches the NEXT node when it hands out an element, so
+ *   - an element appended while the iterator stands on the last node is NOT visited,
+ *   - an element appended earlier IS visited,
+ *   - "remove at iterator" drops the element handed out last and iteration continues.
+ * This container reproduces those semantics (behaviour, not code): circular list with a sentinel,
+ * iterator = (next, prev).
+ */
+#ifndef EF_LIST_H
+#define EF_LIST_H
+
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdlib.h>
+
+typedef struct ef_node { struct ef_node *next, *prev; void* el; } ef_node;
+typedef struct ef_list { ef_node sent; size_t size; } ef_list;
+typedef struct ef_iter { ef_node *next, *prev; ef_list* l; } ef_iter;
+
+static inline ef_list* efl_new(void) {
+  ef_list* l = (ef_list*)malloc(sizeof(ef_list));
+  l->sent.next = l->sent.prev = &l->sent; l->sent.el = NULL; l->size = 0;
+  return l;
+}
+static inline void efl_free(ef_list* l, void (*del)(void*)) {
+  if (!l) return;
+  ef_node* n = l->sent.next;
+  while (n != &l->sent) { ef_node* nx = n->next; if (del && n->el) del(n->el); free(n); n = nx; }
+  free(l);
+}
+static inline size_t efl_size(const ef_list* l) { return l->size; }
+static inline bool efl_empty(const ef_list* l) { return l->size == 0; }
+static inline void efl_push_back(ef_list* l, void* el) {
+  ef_node* n = (ef_node*)malloc(sizeof(ef_node));
+  n->el = el; n->prev = l->sent.prev; n->next = &l->sent; n->prev->next = n; l->sent.prev = n; ++l->size;
+}
+static inline void efl_push_front(ef_list* l, void* el) {
+  ef_node* n = (ef_node*)malloc(sizeof(ef_node));
+  n->el = el; n->next = l->sent.next; n->prev = &l->sent; n->next->prev = n; l->sent.next = n; ++l->size;
+}
+static inline void* efl_head(const ef_list* l) { return l->sent.next->el; }   /* NULL when empty */
+static inline void* efl_tail(const ef_list* l) { return l->sent.prev->el; }
+static inline void* efl_pop_front(ef_list* l) {
+  ef_node* n = l->sent.next; void* el = n->el;
+  l->sent.next = n->next; n->next->prev = &l->sent; free(n); --l->size; return el;
+}
+static inline void* efl_pop_back(ef_list* l) {
+  ef_node* n = l->sent.prev; void* el = n->el;
+  l->sent.prev = n->prev; n->prev->next = &l->sent; free(n); --l->size; return el;
+}
+
+static inline ef_iter efl_begin(ef_list* l) { ef_iter it = { l->sent.next, &l->sent, l }; return it; }
+static inline ef_iter efl_end(ef_list* l) { ef_iter it = { &l->sent, l->sent.prev, l }; return it; }
+static inline bool efi_has_next(const ef_iter* it) { return it->next != &it->l->sent; }
+static inline void* efi_next(ef_iter* it) {
+  void* el = it->next->el; it->prev = it->next; it->next = it->next->next; return el;
+}
+static inline bool efi_has_prev(const ef_iter* it) { return it->prev != &it->l->sent; }
+static inline void* efi_prev(ef_iter* it) {
+  void* el = it->prev->el; it->next = it->prev; it->prev = it->prev->prev; return el;
+}
+/* removes the element handed out by the last efi_next */
+static inline void efi_remove(ef_iter* it, void (*del)(void*)) {
+  ef_node* dead = it->prev;
+  it->next->prev = dead->prev; dead->prev->next = it->next;
+  if (del) del(dead->el);
+  --it->l->size;
+  it->prev = dead->prev;
+  free(dead);
+}
+/* inserts before the element handed out by the last efi_next (include/list.h add_before_iterator) */
+static inline void efi_insert_before(ef_iter* it, void* el) {
+  ef_node* cur = it->prev;
+  ef_node* n = (ef_node*)malloc(sizeof(ef_node));
+  n->el = el; n->prev = cur->prev; n->next = cur; cur->prev->next = n; cur->prev = n; ++it->l->size;
+}
+/* removes the first node holding el; true when found */
+static inline bool efl_remove_first(ef_list* l, void* el) {
+  for (ef_node* n = l->sent.next; n != &l->sent; n = n->next)
+    if (n->el == el) { n->prev->next = n->next; n->next->prev = n->prev; free(n); --l->size; return true; }
+  return false;
+}
+/* qsort on the element pointers, written back into the existing nodes (as the reference does:
+ * same libc qsort, same input order => same order among equal keys) */
+static inline void efl_sort(ef_list* l, int (*cmp)(const void*, const void*)) {
+  const size_t n = l->size;
+  if (n < 2) return;
+  void** base = (void**)malloc(n * sizeof(void*));
+  size_t i = 0;
+  for (ef_node* x = l->sent.next; x != &l->sent; x = x->next) base[i++] = x->el;
+  qsort(base, n, sizeof(void*), cmp);
+  i = 0;
+  for (ef_node* x = l->sent.next; x != &l->sent; x = x->next) x->el = base[i++];
+  free(base);
+}
+
+#endif

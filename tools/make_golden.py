@@ -88,7 +88,7 @@ def main():
             os.makedirs(dst, exist_ok=True)
             for f in ("genomic.txt", "ests.txt"):
                 shutil.copy(os.path.join(fx, f), dst)
-            for f in ("raw-multifasta-out.txt", "processed-ests.txt"):
+            for f in ("raw-multifasta-out.txt", "processed-ests.txt", "megs.txt", "processed-megs.txt", "meg-edges.txt"):
                 shutil.copy(os.path.join(tmp, f), os.path.join(dst, "expected-" + f))
         os.unlink(cap)
         shutil.rmtree(tmp)
