@@ -1,0 +1,141 @@
+/* compute_est_fact and the est-fact process flow.
+ * Behaviour follows src/compute-est-fact.c:192-293 and src/main-est-fact.c:90-339 of the reference
+ * (same files in cwd, same record formats, same order of ESTs and of the reverse-complement
+ * siblings).  The wall-clock timeout of the reference (src/my_time.c:177-198) is not reproduced:
+ * nothing here depends on time. */
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+
+#include "estfact.h"
+
+/* write_multifasta_output (src/io-multifasta.c:187-246) */
+void ef_write_multifasta_output(const ef_seq* gen, const ef_est* e, FILE* f, char retain_externals) {
+  if (!e->factorizations || efl_empty(e->factorizations)) return;
+  ef_iter fi = efl_begin(e->factorizations), pa = efl_begin(e->polyA_signals), pd = efl_begin(e->polyadenil_signals);
+  while (efi_has_next(&fi)) {
+    ef_list* fact = (ef_list*)efi_next(&fi);
+    int polya = efi_next(&pa) == (void*)1, polyad = efi_next(&pd) == (void*)1;
+    const size_t n = efl_size(fact);
+    if (!(retain_externals || (n > 2 || (n == 2 && e->info->suff_polyA_length != -1)))) continue;
+    fprintf(f, ">%s\n", e->info->id);
+    if (!retain_externals) { polya = 0; polyad = 0; }
+    fprintf(f, "#polya=%d\n#polyad=%d\n", polya, polyad);
+    unsigned counter = 1;
+    const unsigned l_index = retain_externals == 0 ? 1 : 0;
+    const unsigned r_index = retain_externals == 0 ? (e->info->suff_polyA_length == -1 ? (unsigned)n : (unsigned)n + 1) : (unsigned)n + 1;
+    ef_iter xi = efl_begin(fact);
+    while (efi_has_next(&xi)) {
+      const ef_factor* x = (const ef_factor*)efi_next(&xi);
+      if (counter > l_index && counter < r_index)
+        fprintf(f, "%d %d %d %d %.*s %.*s\n", x->EST_start + 1, x->EST_end + 1,
+                gen->pref_N_length + x->GEN_start + 1, gen->pref_N_length + x->GEN_end + 1,
+                x->EST_end + 1 - x->EST_start, e->info->original_seq + x->EST_start,
+                x->GEN_end + 1 - x->GEN_start, gen->original_seq + gen->pref_N_length + x->GEN_start);
+      ++counter;
+    }
+  }
+}
+
+/* compute_est_fact (src/compute-est-fact.c:192-293) */
+ef_est* ef_compute_est_fact(const ef_seq* gen, const ef_seq* est, ef_backend* be, const ef_config* cfg,
+                            const ef_side_files* side) {
+  size_t inc = 0, prev_tp = 0, prev_te = 0, tp, te;
+  ef_meg* V = NULL;
+  bool same;
+  do {
+    V = ef_build_meg(est, be, cfg, &inc);
+    ef_meg_stats(V, &tp, &te);
+    same = prev_tp > 2 && prev_te > 0 && (prev_tp <= tp || prev_te <= te);
+    if (same) { ++inc; ef_meg_free(V); }
+  } while (same);
+  ef_est* fe = ef_get_est_factorizations(est, V, cfg, gen, be);
+  ef_refine_est_factorizations(gen, fe, cfg, be);
+  ef_remove_factorizations_with_very_small_exons(fe->factorizations);
+  if (!efl_empty(fe->factorizations)) ef_remove_duplicated_factorizations(fe->factorizations);
+  if (side && side->fmeg) {                                   /* report_meg (:73-88) */
+    fprintf(side->fmeg, "\n\n***********\n\n");
+    ef_write_single_est_info(side->fmeg, est);
+    ef_meg_write(side->fmeg, V);
+    fflush(side->fmeg);
+  }
+  if (!efl_empty(fe->factorizations) && side) {
+    if (side->fintronic) { fprintf(side->fintronic, ">%s\n", est->id); ef_intronic_edges_write(side->fintronic, V); }
+    if (side->fpmeg) { ef_write_single_est_info(side->fpmeg, est); ef_meg_write(side->fpmeg, V); }
+    /* "<meg us> <composition us> <#factorizations>": the two timings are inherently not
+     * reproducible; written as 0 */
+    if (side->ftmeg) fprintf(side->ftmeg, "0 0 %zu\n", efl_size(fe->factorizations));
+  }
+  ef_meg_free(V);
+  return fe;
+}
+
+/* main of est-fact (src/main-est-fact.c:90-339) with the backend supplied by the caller */
+int ef_run(int argc, char** argv, ef_backend* (*open_backend)(const ef_seq* gen), void (*close_backend)(ef_backend*)) {
+  ef_config cfg;
+  if (ef_config_load(&cfg, argc, argv) != 0) return 2;
+  char buf[64];
+  snprintf(buf, sizeof buf, "info-pid-%u.log", (unsigned)getpid());
+  FILE* flog = fopen(buf, "w");
+  if (!flog) { fprintf(stderr, "* FATAL Cannot create file info.log! Terminating\n"); return 1; }
+  fprintf(flog, "start\n");
+  ef_seq** gens = NULL; ef_seq** ests = NULL;
+  const long ng = ef_read_multifasta("genomic.txt", &gens);
+  if (ng < 0) { fprintf(stderr, "* FATAL File genomic.txt not found! Terminating\n"); return 1; }
+  if (ng != 1) { fprintf(stderr, "* FATAL genomic.txt must hold exactly one sequence\n"); return 1; }
+  ef_seq* gen = gens[0];
+  ef_parse_genomic_header(gen);
+  if (ef_ntails_removal(gen) != 0) { fprintf(stderr, "* FATAL The sequence is only composed by Ns.\n"); return 1; }
+  const long n_in = ef_read_multifasta("ests.txt", &ests);
+  if (n_in < 0) { fprintf(stderr, "* FATAL File ests.txt not found! Terminating\n"); return 1; }
+  FILE* fout = fopen("raw-multifasta-out.txt", "w");
+  ef_side_files side = { fopen("megs.txt", "w"), fopen("processed-megs.txt", "w"),
+                         fopen("processed-megs-info.txt", "w"), fopen("meg-edges.txt", "w") };
+  FILE* fests = fopen("processed-ests.txt", "w");
+  if (!fout || !fests || !side.fmeg || !side.fpmeg || !side.ftmeg || !side.fintronic) {
+    fprintf(stderr, "* FATAL Cannot create an output file! Terminating\n");
+    return 1;
+  }
+  /* preparation loop (:190-213) */
+  ef_seq** list = (ef_seq**)malloc((size_t)(2 * n_in + 1) * sizeof(ef_seq*));
+  size_t n = 0;
+  for (long i = 0; i < n_in; ++i) {
+    ef_seq* est = ests[i];
+    ef_set_gb_identification(est);
+    ef_set_strand_and_rc(est);
+    list[n++] = est;
+    ef_polyAT_substitution(est);
+    if (!est->fixed_strand) {
+      ef_seq* rev = ef_copy_and_reverse(est);
+      list[n++] = rev;
+      ef_polyAT_substitution(rev);
+    }
+  }
+  ef_backend* be = open_backend(gen);
+  if (!be) { fprintf(stderr, "* FATAL cannot initialise the compute backend (no MI355X / library)\n"); return 1; }
+  /* per-EST loop (:249-291) */
+  bool reversed = false;
+  for (size_t k = 0; k < n; ++k) {
+    ef_seq* est = list[k];
+    ef_est* fe = ef_compute_est_fact(gen, est, be, &cfg, &side);
+    if (!efl_empty(fe->factorizations)) {
+      ef_write_multifasta_output(gen, fe, fout, cfg.retain_externals);
+      ef_write_single_est_info(fests, fe->info);
+      if (!est->fixed_strand && !reversed) ++k;        /* skip the reverse-complement sibling */
+      reversed = false;
+    } else if (reversed || est->fixed_strand) {
+      reversed = false;
+    } else {
+      reversed = true;
+    }
+    ef_est_free(fe);
+  }
+  close_backend(be);
+  fclose(fout); fclose(fests); fclose(side.fmeg); fclose(side.fpmeg); fclose(side.ftmeg); fclose(side.fintronic);
+  fprintf(flog, "end\n");
+  fclose(flog);
+  for (size_t k = 0; k < n; ++k) ef_seq_free(list[k]);
+  free(list); free(ests);
+  ef_seq_free(gen); free(gens);
+  return 0;
+}

@@ -1,0 +1,882 @@
+/* From the MEG to the factorizations of one EST: embedding enumeration, candidate factorizations,
+ * cleaning steps, selection filters, intron refinement, polyA detection.
+ * Behaviour follows src/est-factorizations.c, src/exon-complexity.c, src/detect-polya.c and
+ * src/list.c:306-483 of the reference (cited per function); data structures are our own.  Every
+ * dynamic program goes through the backend (ef_backend.dp), never computed here. */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "estfact.h"
+
+typedef struct { int p, t, l; } ptl;     /* pairing inside an embedding */
+
+/* ---------------------------------------------------------------------------------------------- */
+/* small helpers                                                                                  */
+/* ---------------------------------------------------------------------------------------------- */
+char* ef_real_substring(int index, int length, const char* s) {     /* src/util.c:138-158 */
+  if (index < 0) { length += index; index = 0; }
+  if (length < 0) length = 0;
+  char* r = (char*)malloc((size_t)length + 1);
+  strncpy(r, s + index, (size_t)length);
+  r[length] = '\0';
+  return r;
+}
+
+static ef_factor* factor_new(int es, int ee, int gs, int ge) {
+  ef_factor* f = (ef_factor*)malloc(sizeof(ef_factor));
+  f->EST_start = es; f->EST_end = ee; f->GEN_start = gs; f->GEN_end = ge;
+  return f;
+}
+
+void ef_factorization_free(void* fact) { efl_free((ef_list*)fact, free); }
+
+void ef_est_free(ef_est* e) {
+  if (!e) return;
+  efl_free(e->factorizations, ef_factorization_free);
+  efl_free(e->polyA_signals, NULL);
+  efl_free(e->polyadenil_signals, NULL);
+  free(e);
+}
+
+static int run_dp(ef_backend* be, int kind, const char* a, size_t la, const char* b, size_t lb,
+                  uint32_t p0, uint32_t p1, uint32_t p2, uint32_t tail, ef_dp_res* res) {
+  ef_dp_req rq = { kind, a, la, b, lb, p0, p1, p2, tail };
+  memset(res, 0, sizeof(*res));
+  if (be->dp(be->self, &rq, res) != 0) {
+    fprintf(stderr, "* FATAL dynamic-programming backend failed (kind %d, %zu x %zu)\n", kind, la, lb);
+    abort();
+  }
+  return 0;
+}
+
+uint32_t ef_edit_distance(ef_backend* be, const char* a, size_t la, const char* b, size_t lb) {
+  ef_dp_res r;
+  run_dp(be, EF_DP_ED, a, la, b, lb, 0, 0, 0, 0, &r);
+  return (uint32_t)r.v[0];
+}
+
+uint32_t ef_compute_edit_distance(ef_backend* be, const char* a, size_t la, const char* b, size_t lb) {
+  if (la == lb && strncmp(a, b, la) == 0) return 0;                 /* src/compute-alignments.c:242 */
+  return ef_edit_distance(be, a, la, b, lb);
+}
+
+/* ---------------------------------------------------------------------------------------------- */
+/* embeddings (src/est-factorizations.c:597-917, 1362-1460)                                       */
+/* ---------------------------------------------------------------------------------------------- */
+static ptl* ptl_new(int p, int t, int l) { ptl* x = (ptl*)malloc(sizeof(ptl)); x->p = p; x->t = t; x->l = l; return x; }
+static void embedding_free(void* e) { efl_free((ef_list*)e, free); }
+
+static ef_list* embedding_copy(ef_list* e) {
+  ef_list* c = efl_new();
+  ef_iter it = efl_begin(e);
+  while (efi_has_next(&it)) { const ptl* x = (const ptl*)efi_next(&it); efl_push_back(c, ptl_new(x->p, x->t, x->l)); }
+  return c;
+}
+
+/* update_embedding (:765-917): the embedding extended by `node` at its head, or NULL */
+static ef_list* update_embedding(ef_list* embedding, const ef_pairing* node, const char* GEN,
+                                 const ef_config* cfg) {
+  const ptl* head = (const ptl*)efl_head(embedding);
+  if (head->p == EF_SINK_START) {
+    if (node->p < 0) return NULL;
+    ef_list* e = efl_new();
+    efl_push_front(e, ptl_new(node->p, node->t, node->l));
+    return e;
+  }
+  if (node->p < 0) return embedding_copy(embedding);
+  const int small_delta = (head->p + head->l) - node->p;
+  const int big_delta = (head->t + head->l) - node->t;
+  const int min_fl = (int)cfg->min_factor_len;
+  const int fl = 2 * min_fl;
+  if (!(small_delta >= fl && big_delta >= fl)) return NULL;
+  if (!(small_delta - (node->l + head->l) <= fl)) return NULL;
+  if (!(small_delta - big_delta <= fl)) return NULL;
+  int head_l, head_p, head_t, node_l;
+  if (small_delta >= (node->l + head->l) && big_delta >= (node->l + head->l)) {
+    head_p = head->p; head_t = head->t; head_l = head->l; node_l = node->l;
+  } else {
+    const int ref_delta = small_delta < big_delta ? small_delta : big_delta;
+    int len_node = ref_delta / 2;
+    int len_head = ref_delta - len_node;
+    if (len_node > node->l) { len_node = node->l; len_head = ref_delta - len_node; }
+    else if (len_head > head->l) { len_head = head->l; len_node = ref_delta - len_head; }
+    head_l = len_head;
+    head_p = head->p + head->l - head_l;
+    head_t = head->t + head->l - head_l;
+    node_l = len_node;
+  }
+  const bool overlap_on_p = small_delta < (node->l + head->l);
+  const int gap_on_p = head_p - node->p - node_l - 1;
+  const int gap_on_t = head_t - node->t - node_l - 1;
+  const int intron_len = gap_on_t - (gap_on_p > 0 ? gap_on_p : 0);
+  const bool intron_on_t = intron_len >= 0 && (cfg->min_intron_length == 0 || intron_len >= cfg->min_intron_length);
+  if (overlap_on_p && intron_on_t) {                       /* best cut by Burset frequency */
+    int best_freq = -1, best_cut = 0;
+    const int lo = (node->p + min_fl > head->p) ? node->p + min_fl : head->p;
+    const int hi = (head->p + head->l - min_fl < node->p + node->l) ? head->p + head->l - min_fl : node->p + node->l;
+    for (int cut = lo; cut <= hi; ++cut) {
+      const int f = ef_burset_adaptor(GEN, (size_t)(cut - node->p + node->t), (size_t)(cut - head->p + head->t));
+      if (f >= best_freq) { best_freq = f; best_cut = cut; }
+    }
+    const int dH = best_cut - head->p;
+    head_l = head->l - dH; head_p = head->p + dH; head_t = head->t + dH;
+    node_l = node->l - (node->p + node->l - best_cut);
+  }
+  if (!(gap_on_t <= fl || intron_on_t)) return NULL;
+  ef_list* c = embedding_copy(embedding);
+  ptl* hc = (ptl*)efl_head(c);
+  hc->p = head_p; hc->t = head_t; hc->l = head_l;
+  efl_push_front(c, ptl_new(node->p, node->t, node_l));
+  return c;
+}
+
+/* does x contain y (both on P and on T)?  used by maximality_relation */
+static bool pair_inside(const ptl* inner, const ptl* outer) {
+  if (inner->p < outer->p || (inner->p + inner->l > outer->p + outer->l)) return false;
+  if (inner->t < outer->t || (inner->t + inner->l > outer->t + outer->l)) return false;
+  return true;
+}
+
+/* maximality_relation (:1362-1460): 2 = add is maximal, 1 = both, 0 = cmp is maximal */
+static int maximality_relation(ef_list* add, ef_list* cmp) {
+  ef_iter ia = efl_begin(add), ic = efl_begin(cmp);
+  if (efl_size(add) > efl_size(cmp)) {
+    bool check = true;
+    while (efi_has_next(&ic) && check) {
+      const ptl* a = (const ptl*)efi_next(&ia); const ptl* c = (const ptl*)efi_next(&ic);
+      check = pair_inside(c, a);
+    }
+    return check ? 2 : 1;
+  }
+  if (efl_size(add) < efl_size(cmp)) {
+    bool check = true;
+    while (efi_has_next(&ia) && check) {
+      const ptl* a = (const ptl*)efi_next(&ia); const ptl* c = (const ptl*)efi_next(&ic);
+      check = pair_inside(a, c);
+    }
+    return check ? 0 : 1;
+  }
+  bool check = true;
+  while (efi_has_next(&ia) && check) {
+    const ptl* a = (const ptl*)efi_next(&ia); const ptl* c = (const ptl*)efi_next(&ic);
+    check = pair_inside(a, c);
+  }
+  if (check) return 0;
+  ia = efl_begin(add); ic = efl_begin(cmp);
+  check = true;
+  while (efi_has_next(&ia) && check) {
+    const ptl* a = (const ptl*)efi_next(&ia); const ptl* c = (const ptl*)efi_next(&ic);
+    check = pair_inside(c, a);
+  }
+  return check ? 2 : 1;
+}
+
+/* get_subtree_embeddings (:597-762), memoised on the vertex */
+static ef_list* subtree_embeddings(ef_pairing* root, const ef_config* cfg, const char* GEN) {
+  if (root->emb_memo) return root->emb_memo;
+  ef_list* out = efl_new();
+  root->visited = true;
+  if (efl_empty(root->adjs)) {
+    ef_list* e = efl_new();
+    efl_push_front(e, ptl_new(root->p, root->t, root->l));
+    efl_push_front(out, e);
+  } else {
+    ef_iter ai = efl_begin(root->adjs);
+    while (efi_has_next(&ai)) {
+      ef_pairing* adj = (ef_pairing*)efi_next(&ai);
+      ef_list* sub = subtree_embeddings(adj, cfg, GEN);
+      ef_iter si = efl_begin(sub);
+      while (efi_has_next(&si)) {
+        ef_list* add = update_embedding((ef_list*)efi_next(&si), root, GEN, cfg);
+        if (!add) continue;
+        int is_max = 2;
+        ef_iter ci = efl_begin(out);
+        while (efi_has_next(&ci) && is_max >= 1) {
+          ef_list* cmp = (ef_list*)efi_next(&ci);
+          is_max = maximality_relation(add, cmp);
+          if (is_max == 2) efi_remove(&ci, embedding_free);
+        }
+        if (is_max >= 1) efl_push_back(out, add); else embedding_free(add);
+      }
+    }
+  }
+  root->emb_memo = out;
+  return out;
+}
+
+/* get_factorizations_from_embeddings (:1292-1356) */
+static ef_list* factorizations_from_embeddings(ef_list* embeddings, const ef_config* cfg) {
+  ef_list* out = efl_new();
+  const int fl = 2 * (int)cfg->min_factor_len;
+  ef_iter ei = efl_begin(embeddings);
+  while (efi_has_next(&ei)) {
+    ef_list* emb = (ef_list*)efi_next(&ei);
+    ef_list* fact = efl_new();
+    ef_factor* last = NULL;
+    ef_iter pi = efl_begin(emb);
+    while (efi_has_next(&pi)) {
+      const ptl* x = (const ptl*)efi_next(&pi);
+      if (efl_empty(fact) || (x->t - last->GEN_end - 1) > fl) {
+        last = factor_new(x->p, x->p + x->l - 1, x->t, x->t + x->l - 1);
+        efl_push_back(fact, last);
+      } else {
+        last = (ef_factor*)efl_tail(fact);
+        last->EST_end = x->p + x->l - 1;
+        last->GEN_end = x->t + x->l - 1;
+      }
+    }
+    efl_push_back(out, fact);
+  }
+  return out;
+}
+
+/* ---------------------------------------------------------------------------------------------- */
+/* cleaning steps on one candidate factorization                                                  */
+/* ---------------------------------------------------------------------------------------------- */
+static bool not_source_sink(ef_list* fact, int est_len) {             /* :2111-2125 */
+  if (efl_size(fact) > 1) return true;
+  const ef_factor* h = (const ef_factor*)efl_head(fact);
+  return !(h->EST_start < 0 || h->EST_start >= est_len);
+}
+
+static bool exon_start_end_ok(ef_list* fact) {                        /* :1989-2018 */
+  int prev_e = -1, prev_g = -1;
+  ef_iter it = efl_begin(fact);
+  while (efi_has_next(&it)) {
+    const ef_factor* x = (const ef_factor*)efi_next(&it);
+    if (x->EST_start > x->EST_end || x->GEN_start > x->GEN_end) return false;
+    if (x->EST_start < prev_e || x->GEN_start < prev_g) return false;
+    prev_e = x->EST_end; prev_g = x->GEN_end;
+  }
+  return true;
+}
+
+/* alignment rows copied into zero-padded buffers (the reference scans a little past the end) */
+static char* padded_copy(const char* s) {
+  const size_t n = strlen(s);
+  char* r = (char*)calloc(n + 32, 1);
+  memcpy(r, s, n);
+  return r;
+}
+
+/* handle_endpoints (:2127-2301) */
+static ef_list* handle_endpoints(ef_list* fact, const char* gen, const char* est, ef_backend* be) {
+  ef_factor* head = (ef_factor*)efl_head(fact);
+  {
+    char* g = ef_real_substring(head->GEN_start, head->GEN_end - head->GEN_start + 1, gen);
+    char* e = ef_real_substring(head->EST_start, head->EST_end - head->EST_start + 1, est);
+    ef_dp_res r;
+    run_dp(be, EF_DP_ALIGN, e, strlen(e), g, strlen(g), 0, 0, 0, 0, &r);
+    const char* ea = r.s0; const char* ga = r.s1;
+    const int dim = r.v[1];
+    int j = 0, matches = 0, cut_factor = head->EST_start, cut_exon = head->GEN_start;
+    bool stop = false;
+    while (j < dim && !stop) {
+      if (matches > 5) stop = true;
+      else {
+        if (ea[j] == ga[j]) { ++cut_factor; ++cut_exon; ++matches; }
+        else { if (ea[j] != '-') ++cut_factor; if (ga[j] != '-') ++cut_exon; matches = 0; }
+        ++j;
+      }
+    }
+    if (!stop) free(efl_pop_front(fact));
+    else { head->EST_start = cut_factor - matches; head->GEN_start = cut_exon - matches; }
+    free(r.s0); free(r.s1); free(g); free(e);
+  }
+  if (efl_empty(fact)) return fact;
+  ef_factor* tail = (ef_factor*)efl_tail(fact);
+  {
+    char* g = ef_real_substring(tail->GEN_start, tail->GEN_end - tail->GEN_start + 1, gen);
+    char* e = ef_real_substring(tail->EST_start, tail->EST_end - tail->EST_start + 1, est);
+    ef_dp_res r;
+    run_dp(be, EF_DP_ALIGN, e, strlen(e), g, strlen(g), 0, 0, 0, 0, &r);
+    char* ea = padded_copy(r.s0); char* ga = padded_copy(r.s1);
+    const int dim = r.v[1];
+    int j = dim - 1, matches = 0, cut_factor = tail->EST_end, cut_exon = tail->GEN_end;
+    bool stop = false;
+    while (j >= 0 && !stop) {
+      if (matches > 10) stop = true;
+      else {
+        if (ea[j] == ga[j]) { --cut_factor; --cut_exon; ++matches; }
+        else { if (ea[j] != '-') --cut_factor; if (ga[j] != '-') --cut_exon; matches = 0; }
+        --j;
+      }
+    }
+    int est_cleavage = cut_factor + matches, gen_cleavage = cut_exon + matches;
+    int cursor = j + matches + 1;
+    stop = false;
+    while (((ea[cursor] == '-' || ga[cursor] == '-') && cursor < dim - 1) && !stop) {
+      if (ea[cursor] == '-') {
+        int tr = cursor + 1;
+        while (ea[tr] == '-') ++tr;
+        if (tr < dim && ea[tr] == ga[cursor]) { ea[cursor] = ea[tr]; ea[tr] = '-'; ++est_cleavage; ++gen_cleavage; }
+        else stop = true;
+      } else {
+        int tr = cursor + 1;
+        while (ga[tr] == '-') ++tr;
+        if (tr < dim && ga[tr] == ea[cursor]) { ga[cursor] = ga[tr]; ga[tr] = '-'; ++est_cleavage; ++gen_cleavage; }
+        else stop = true;
+      }
+      ++cursor;
+    }
+    if (gen_cleavage >= tail->GEN_start) { tail->EST_end = est_cleavage; tail->GEN_end = gen_cleavage; }
+    else free(efl_pop_back(fact));
+    free(ea); free(ga); free(r.s0); free(r.s1); free(g); free(e);
+  }
+  return fact;
+}
+
+static bool is_ch(char c, char up) { return c == up || c == (char)(up + 32); }
+
+/* clean_external_exons (:1706-1826) */
+ef_list* ef_clean_external_exons(ef_list* fact, const char* gen, const char* est, ef_backend* be) {
+  if (efl_empty(fact)) return fact;
+  ef_factor* head = (ef_factor*)efl_pop_front(fact);
+  const int hl = head->GEN_end - head->GEN_start + 1;
+  bool ok = hl >= 10;
+  if (ok && hl < 20) {
+    if (!is_ch(gen[head->GEN_end + 1], 'G')) ok = false;
+    else if (!is_ch(gen[head->GEN_end + 2], 'T') && !is_ch(gen[head->GEN_end + 2], 'C')) ok = false;
+    else if (efl_size(fact) >= 1) {
+      const ef_factor* nx = (const ef_factor*)efl_head(fact);
+      if (!is_ch(gen[nx->GEN_start - 2], 'A')) ok = false;
+      else if (!is_ch(gen[nx->GEN_start - 1], 'G')) ok = false;
+    } else ok = false;
+    if (ok) {
+      char* g = ef_real_substring(head->GEN_start, head->GEN_end - head->GEN_start + 1, gen);
+      char* e = ef_real_substring(head->EST_start, head->EST_end - head->EST_start + 1, est);
+      if ((int)ef_edit_distance(be, g, strlen(g), e, strlen(e)) > 0) ok = false;
+      free(g); free(e);
+    }
+  }
+  if (ok) efl_push_front(fact, head); else free(head);
+  if (efl_empty(fact)) return fact;
+  ef_factor* tail = (ef_factor*)efl_pop_back(fact);
+  const int tl = tail->GEN_end - tail->GEN_start + 1;
+  ok = tl >= 10;
+  if (ok && tl < 20) {
+    if (!is_ch(gen[tail->GEN_start - 2], 'A')) ok = false;
+    else if (!is_ch(gen[tail->GEN_start - 1], 'G')) ok = false;
+    else if (efl_size(fact) >= 1) {
+      const ef_factor* pv = (const ef_factor*)efl_tail(fact);
+      if (!is_ch(gen[pv->GEN_end + 1], 'G')) ok = false;
+      else if (!is_ch(gen[pv->GEN_end + 2], 'T') && !is_ch(gen[pv->GEN_end + 2], 'C')) ok = false;
+    } else ok = false;
+    if (ok) {
+      char* g = ef_real_substring(tail->GEN_start, tail->GEN_end - tail->GEN_start + 1, gen);
+      char* e = ef_real_substring(tail->EST_start, tail->EST_end - tail->EST_start + 1, est);
+      if ((int)ef_edit_distance(be, g, strlen(g), e, strlen(e)) > 0) ok = false;
+      free(g); free(e);
+    }
+  }
+  if (ok) efl_push_back(fact, tail); else free(tail);
+  return fact;
+}
+
+/* dustScoreByLeftAndRight / dustScore (src/exon-complexity.c:38-79) */
+static int dinuc(char a, char b) {
+  static const char* B = "ACGT";
+  int x = -1, y = -1;
+  for (int k = 0; k < 4; ++k) { if (is_ch(a, B[k])) x = k; if (is_ch(b, B[k])) y = k; }
+  return (x < 0 || y < 0) ? 16 : 4 * x + y;
+}
+static double dust_score(const char* s, int start, int end) {
+  char* sub = ef_real_substring(start, end - start + 1, s);
+  const size_t len = strlen(sub);
+  double r = 0.0;
+  if ((int)len > 2) {
+    int freq[17] = {0}, running = 0;
+    for (int i = 0; i < (int)len - 1; ++i) { const int k = dinuc(sub[i], sub[i + 1]); running += freq[k]; ++freq[k]; }
+    const double dust = (10.0 * (double)running) / ((double)(len - 2));
+    r = dust / len;
+  }
+  free(sub);
+  return r;
+}
+
+/* update_with_subfact_with_best_coverage (:1900-1987): split_idx = 1-based indices of bad exons */
+static ef_list* keep_best_run(ef_list* fact, const int* split_idx, int n_split) {
+  if (n_split == 0) return fact;
+  int best_l = -1, best_r = -1, best_cover = -1;
+  ef_iter fi = efl_begin(fact);
+  int left = 1;
+  for (int k = 0; k < n_split; ++k) {
+    const int right = split_idx[k];
+    const ef_factor* le = (const ef_factor*)efi_next(&fi);
+    const ef_factor* re = le;
+    if (left < right) {
+      for (int times = right - left - 1; times > 0; --times) re = (const ef_factor*)efi_next(&fi);
+      const int cover = re->EST_end - le->EST_start + 1;
+      if (cover > best_cover) { best_l = left; best_r = right - 1; best_cover = cover; }
+      efi_next(&fi);
+    }
+    left = right + 1;
+  }
+  const int size = (int)efl_size(fact);
+  if (left <= size) {
+    const ef_factor* le = (const ef_factor*)efi_next(&fi);
+    const ef_factor* re = le;
+    for (int times = size - left; times > 0; --times) re = (const ef_factor*)efi_next(&fi);
+    const int cover = re->EST_end - le->EST_start + 1;
+    if (cover > best_cover) { best_l = left; best_r = size; best_cover = cover; }
+  }
+  if (best_l == -1 || best_r == -1) {
+    for (int k = size; k > 0; --k) free(efl_pop_back(fact));
+  } else {
+    for (int k = best_l - 1; k > 0; --k) free(efl_pop_front(fact));
+    for (int k = best_r + 1; k <= size; ++k) free(efl_pop_back(fact));
+  }
+  return fact;
+}
+
+/* clean_low_complexity_exons_2 (:1667-1704) */
+static ef_list* clean_low_complexity(ef_list* fact, const char* gen, const char* est, const ef_config* cfg) {
+  int* idx = (int*)malloc((efl_size(fact) + 1) * sizeof(int));
+  int n = 0, index = 1;
+  ef_iter it = efl_begin(fact);
+  while (efi_has_next(&it)) {
+    const ef_factor* x = (const ef_factor*)efi_next(&it);
+    double gd = 0.0, ed = 0.0;
+    if (x->GEN_start <= x->GEN_end) { gd = dust_score(gen, x->GEN_start, x->GEN_end); ed = dust_score(est, x->EST_start, x->EST_end); }
+    if (gd > cfg->complexity_threshold || ed > cfg->complexity_threshold) idx[n++] = index;
+    ++index;
+  }
+  fact = keep_best_run(fact, idx, n);
+  free(idx);
+  return fact;
+}
+
+static unsigned max_edit_for_exon(size_t exon_length) {                 /* :1828-1840 */
+  const double rate = exon_length > 100 ? 0.030 : (exon_length > 50 ? 0.035 : 0.040);
+  const double c = ceil(exon_length * rate);
+  return (unsigned)(c > 1.0 ? c : 1.0);
+}
+
+/* clean_noisy_exons (:1842-1898) */
+ef_list* ef_clean_noisy_exons(ef_list* fact, const char* gen, const char* est, bool only_internals, ef_backend* be) {
+  const size_t size = efl_size(fact);
+  int* idx = (int*)malloc((size + 1) * sizeof(int));
+  int n = 0;
+  int index = only_internals ? 2 : 1;
+  const int last = only_internals ? (int)(size - 1) : (int)size;
+  ef_iter it = efl_begin(fact);
+  if (only_internals) efi_next(&it);
+  while (efi_has_next(&it) && index <= last) {
+    const ef_factor* x = (const ef_factor*)efi_next(&it);
+    const unsigned max_err = max_edit_for_exon((size_t)(x->GEN_end - x->GEN_start + 1));
+    bool ok = false;
+    if (x->GEN_start <= x->GEN_end) {
+      char* g = ef_real_substring(x->GEN_start, x->GEN_end - x->GEN_start + 1, gen);
+      char* e = ef_real_substring(x->EST_start, x->EST_end - x->EST_start + 1, est);
+      ef_dp_res r;
+      run_dp(be, EF_DP_KBAND, g, strlen(g), e, strlen(e), max_err, 0, 0, 0, &r);
+      ok = r.v[0] != 0;
+      free(g); free(e);
+    }
+    if (!ok) idx[n++] = index;
+    ++index;
+  }
+  fact = keep_best_run(fact, idx, n);
+  free(idx);
+  return fact;
+}
+
+static bool est_coverage_ok(ef_list* fact, const char* est) {           /* :2303-2321 */
+  const size_t len = strlen(est);
+  const ef_factor* h = (const ef_factor*)efl_head(fact);
+  const ef_factor* t = (const ef_factor*)efl_tail(fact);
+  const double cov = (double)(t->EST_end - h->EST_start + 1) / (double)len;
+  return cov >= 0.35f;
+}
+
+/* ---------------------------------------------------------------------------------------------- */
+/* relaxed containment of factorizations (src/est-factorizations.c:1159-1259, src/list.c:306-483)  */
+/* ---------------------------------------------------------------------------------------------- */
+static int relaxed_factor_compare(const ef_factor* p1, const ef_factor* p2, int cfr_type, int allowed, ef_list* l1) {
+  if (p1->GEN_start < p2->GEN_start && p1->GEN_end < p2->GEN_start) return 1;
+  if (p2->GEN_start < p1->GEN_start && p2->GEN_end < p1->GEN_start) return 1;
+  const int max_unconf = 20;
+  if (cfr_type == 0) {
+    if (abs(p1->GEN_end - p2->GEN_end) <= allowed && abs(p1->GEN_start - p2->GEN_start) <= allowed) return 0;
+  }
+  if (abs(cfr_type) == 2) {
+    if (abs(p1->GEN_end - p2->GEN_end) <= allowed) {
+      if (cfr_type == 2) {
+        if (p1->GEN_start - p2->GEN_start > max_unconf) return 1;
+        if (p1->GEN_start - p2->GEN_start > 0) {
+          int tot = 0; bool stop = false;
+          ef_iter it = efl_begin(l1);
+          while (efi_has_next(&it) && !stop) {
+            const ef_factor* f = (const ef_factor*)efi_next(&it);
+            if (p1->GEN_start == f->GEN_start) stop = true; else tot += f->GEN_end - f->GEN_start + 1;
+          }
+          if (abs(p1->GEN_start - p2->GEN_start - tot) < 10) return 1;
+        }
+      }
+      return 0;
+    }
+  }
+  if (abs(cfr_type) == 1) {
+    if (abs(p1->GEN_start - p2->GEN_start) <= allowed) {
+      if (cfr_type == 1) {
+        if (p2->GEN_end - p1->GEN_end > max_unconf) return 1;
+        if (p2->GEN_end - p1->GEN_end > 0) {
+          int tot = 0; bool stop = false;
+          ef_iter it = efl_end(l1);
+          while (efi_has_prev(&it) && !stop) {
+            const ef_factor* f = (const ef_factor*)efi_prev(&it);
+            if (p1->GEN_start == f->GEN_start) stop = true; else tot += f->GEN_end - f->GEN_start + 1;
+          }
+          if (abs(p2->GEN_end - p1->GEN_end - tot) < 20) return 1;
+        }
+      }
+      return 0;
+    }
+  }
+  return 1;
+}
+
+/* relaxed_list_compare (src/list.c:449-483): -2 when equal, else 0 */
+static int relaxed_list_compare(ef_list* l1, ef_list* l2, int allowed_diff) {
+  if (efl_size(l1) != efl_size(l2) || efl_size(l1) == 1) return 0;
+  ef_iter i1 = efl_begin(l1), i2 = efl_begin(l2);
+  const int actual = allowed_diff == -1 ? 0 : allowed_diff;
+  int count = 1;
+  while (efi_has_next(&i1) && efi_has_next(&i2)) {
+    const int type = allowed_diff == -1 ? 0 : (count == 1 ? -2 : (count == (int)efl_size(l1) ? -1 : 0));
+    if (relaxed_factor_compare((const ef_factor*)i1.next->el, (const ef_factor*)i2.next->el, type, actual, l1) != 0) return 0;
+    efi_next(&i1); efi_next(&i2);
+    ++count;
+  }
+  return -2;
+}
+
+/* relaxed_list_contained (src/list.c:320-441): 0 different, -1 l1 in l2, 1 l2 in l1, -2 equal */
+static int relaxed_list_contained(ef_list* l1, ef_list* l2, int allowed_diff) {
+  if (efl_size(l1) == efl_size(l2)) return relaxed_list_compare(l1, l2, allowed_diff);
+  if (efl_size(l1) == 1 || efl_size(l2) == 1) return 0;
+  const int actual = allowed_diff == -1 ? 0 : allowed_diff;
+  ef_iter i1 = efl_begin(l1), i2 = efl_begin(l2);
+  bool found = false;
+  int type = allowed_diff == -1 ? 0 : -2;
+  unsigned count_long = 1;
+  const bool l1_longer = efl_size(l1) > efl_size(l2);
+  ef_list* lng = l1_longer ? l1 : l2;
+  ef_iter* il = l1_longer ? &i1 : &i2;      /* iterator on the longer list */
+  ef_iter* is = l1_longer ? &i2 : &i1;
+  while (efi_has_next(il) && !found) {
+    if (relaxed_factor_compare((const ef_factor*)il->next->el, (const ef_factor*)is->next->el, type, actual, lng) == 0) { found = true; efi_next(is); }
+    else ++count_long;
+    efi_next(il);
+    if (type == -2) type = 2;
+  }
+  if (!found) return 0;
+  unsigned count_factors = 1;
+  bool stop = false;
+  const size_t short_size = l1_longer ? efl_size(l2) : efl_size(l1);
+  const size_t long_size = l1_longer ? efl_size(l1) : efl_size(l2);
+  while (efi_has_next(&i1) && efi_has_next(&i2) && !stop) {
+    type = allowed_diff == -1 ? 0 : ((count_factors + 1 == short_size) ? ((count_long + 1 == long_size) ? -1 : 1) : 0);
+    if (relaxed_factor_compare((const ef_factor*)il->next->el, (const ef_factor*)is->next->el, type, actual, lng) == 0) { efi_next(&i1); efi_next(&i2); }
+    else stop = true;
+    ++count_factors; ++count_long;
+  }
+  if (stop) return 0;
+  if (efl_size(l1) >= efl_size(l2)) return count_factors == efl_size(l2) ? 1 : 0;
+  return count_factors == efl_size(l1) ? -1 : 0;
+}
+
+/* add_if_not_exists (:2041-2109) */
+ef_list* ef_add_if_not_exists(ef_list* to_add, ef_list* list, const ef_config* cfg, bool* added) {
+  ef_iter ci = efl_begin(list);
+  bool found = false;
+  while (efi_has_next(&ci) && !found) {
+    ef_list* cmp = (ef_list*)efi_next(&ci);
+    int res = 0;
+    if (efl_size(cmp) == efl_size(to_add) && efl_size(cmp) == 1) {
+      const ef_factor* h1 = (const ef_factor*)efl_head(to_add); const ef_factor* h2 = (const ef_factor*)efl_head(cmp);
+      if (h1->GEN_start == h2->GEN_start && h1->GEN_end == h2->GEN_end) res = -2;
+      else if (h1->GEN_start >= h2->GEN_start && h1->GEN_end <= h2->GEN_end) res = -1;
+      else if (h1->GEN_start <= h2->GEN_start && h1->GEN_end >= h2->GEN_end) res = 1;
+    } else {
+      res = relaxed_list_contained(to_add, cmp, (int)cfg->max_site_difference);
+    }
+    if (res < 0) {
+      if (res == -2) {
+        const ef_factor* h1 = (const ef_factor*)efl_head(to_add); ef_factor* h2 = (ef_factor*)efl_head(cmp);
+        if (h1->EST_start < h2->EST_start) { h2->EST_start = h1->EST_start; h2->GEN_start = h1->GEN_start; }
+        const ef_factor* t1 = (const ef_factor*)efl_tail(to_add); ef_factor* t2 = (ef_factor*)efl_tail(cmp);
+        if (t1->EST_end > t2->EST_end) { t2->EST_end = t1->EST_end; t2->GEN_end = t1->GEN_end; }
+      }
+      found = true;
+    } else if (res == 1) {
+      efi_remove(&ci, ef_factorization_free);
+    }
+  }
+  if (!found) efl_push_back(list, to_add);
+  *added = !found;
+  return list;
+}
+
+/* ---------------------------------------------------------------------------------------------- */
+/* filters                                                                                        */
+/* ---------------------------------------------------------------------------------------------- */
+static double coverage_of(ef_list* fact, unsigned length) {             /* :1262-1273 */
+  const ef_factor* h = (const ef_factor*)efl_head(fact); const ef_factor* t = (const ef_factor*)efl_tail(fact);
+  const int cover = (int)length - (h->EST_start + ((int)length - t->EST_end - 1));
+  return ((double)cover) / (double)length;
+}
+
+static int gap_length_of(ef_list* fact) {                               /* :1276-1290 */
+  if (efl_size(fact) == 1) return 0;
+  int g = 0;
+  ef_iter it = efl_begin(fact);
+  const ef_factor* d = (const ef_factor*)efi_next(&it);
+  while (efi_has_next(&it)) { const ef_factor* a = (const ef_factor*)efi_next(&it); g += a->EST_start - d->EST_end - 1; d = a; }
+  return g;
+}
+
+/* check_gap_errors (:1462-1546) */
+static bool check_gap_errors(ef_list* fact, const char* est, const char* gen, const ef_config* cfg, ef_backend* be) {
+  (void)cfg;
+  const unsigned threshold_ed = 20;
+  unsigned tot = 0;
+  bool ok = true;
+  ef_iter it = efl_begin(fact);
+  ef_factor* d = (ef_factor*)efi_next(&it);
+  while (efi_has_next(&it) && ok) {
+    ef_factor* a = (ef_factor*)efi_next(&it);
+    const size_t gapP = (size_t)(a->EST_start - d->EST_end - 1);
+    if (gapP > 0) {
+      const size_t gapT = (size_t)(a->GEN_start - d->GEN_end - 1);
+      const int max_errs = (int)gapP;
+      char* p = ef_real_substring(d->EST_end + 1, (int)gapP, est);
+      char* t = ef_real_substring(d->GEN_end + 1, (int)gapT, gen);
+      ef_dp_res r;
+      /* refine_borders(p, gapP, t, gapT, max_errs): t is a fresh NUL-terminated copy => tail 0 */
+      run_dp(be, EF_DP_BORDERS, p, gapP, t, gapT, 0, (uint32_t)gapP, (uint32_t)max_errs, 0, &r);
+      free(p); free(t);
+      ok = r.v[0] != 0;
+      if (ok) {
+        tot += (unsigned)r.v[4];
+        d->EST_end += r.v[1];
+        a->EST_start = d->EST_end + 1;
+        d->GEN_end += r.v[2];
+        a->GEN_start -= (int)gapT - r.v[3];
+      }
+    }
+    d = a;
+  }
+  if (ok && tot > threshold_ed) ok = false;
+  if (ok) {
+    it = efl_begin(fact);
+    d = (ef_factor*)efi_next(&it);
+    while (efi_has_next(&it)) {
+      ef_factor* a = (ef_factor*)efi_next(&it);
+      if (a->GEN_start - d->GEN_end - 1 <= 3) { d->EST_end = a->EST_end; d->GEN_end = a->GEN_end; efi_remove(&it, free); }
+      else d = a;
+    }
+  }
+  return ok;
+}
+
+/* correct_composition_tail + detect_polyA_signal (src/detect-polya.c:42-164) */
+static void correct_tail(ef_list* fact, const char* gen, const char* est) {
+  ef_factor* tail = (ef_factor*)efl_tail(fact);
+  size_t i = (size_t)(tail->EST_end + 1), j = (size_t)(tail->GEN_end + 1);
+  const size_t el = strlen(est), gl = strlen(gen);
+  while (i < el && j < gl && gen[j] == est[i]) { ++i; ++j; }
+  tail->EST_end = (int)i - 1; tail->GEN_end = (int)j - 1;
+}
+
+static bool detect_polyA(ef_list* fact, const char* gen, const char* est, bool* polyadenil) {
+  const ef_factor* tail = (const ef_factor*)efl_tail(fact);
+  const size_t el = strlen(est);
+  const char* cl = est + tail->EST_end + 1;
+  const int cll = (tail->EST_end + 1 <= (int)el) ? (int)(el - (size_t)tail->EST_end - 1) : 0;
+  int i = 0, matches = 0;
+  bool stop = false;
+  while (i < cll && !stop) {
+    if (cl[i] == 'a' || cl[i] == 'A') { if (matches >= 8) stop = true; else { ++matches; ++i; } }
+    else { if (matches >= 8) stop = true; else i = cll; }
+  }
+  *polyadenil = false;
+  if (stop) {
+    i = tail->GEN_end - 39 > 0 ? tail->GEN_end - 39 : 0;
+    while (i <= tail->GEN_end && !*polyadenil) {
+      if (gen[i] == 'a' || gen[i] == 'A') {
+        char* pas = ef_real_substring(i, 6, gen);
+        if (!strcmp(pas, "aataaa") || !strcmp(pas, "AATAAA") || !strcmp(pas, "attaaa") || !strcmp(pas, "ATTAAA")) *polyadenil = true;
+        free(pas);
+      }
+      ++i;
+    }
+    i = tail->GEN_end - 9 > 0 ? tail->GEN_end - 9 : 0;
+    matches = 0;
+    while (i <= tail->GEN_end + 10 && stop && gen[i] != '\0') {
+      if (matches >= 6) stop = false;
+      else { if (gen[i] == 'a' || gen[i] == 'A') ++matches; else matches = 0; ++i; }
+    }
+    if (stop) {
+      i = tail->GEN_end + 1;
+      int count = 0;
+      while (i <= tail->GEN_end + 10 && stop && gen[i] != '\0') {
+        if (count >= 7) stop = false;
+        else { if (gen[i] == 'a' || gen[i] == 'A') ++count; ++i; }
+      }
+    }
+  }
+  return stop;
+}
+
+/* ---------------------------------------------------------------------------------------------- */
+/* get_EST_factorizations (src/est-factorizations.c:126-594)                                       */
+/* ---------------------------------------------------------------------------------------------- */
+ef_est* ef_get_est_factorizations(const ef_seq* est_info, ef_meg* V, const ef_config* cfg,
+                                  const ef_seq* gen_info, ef_backend* be) {
+  ef_est* est = (ef_est*)calloc(1, sizeof(ef_est));
+  est->info = est_info;
+  const char* GEN = gen_info->seq;
+  const char* EST = est_info->seq;
+  const unsigned est_len = (unsigned)V->n - 2;
+  ef_list* flist = efl_new();
+  for (size_t i = 0; i < V->n; ++i) {
+    ef_iter it = efl_begin(V->v[i]);
+    while (efi_has_next(&it)) { ef_pairing* p = (ef_pairing*)efi_next(&it); p->visited = false; p->emb_memo = NULL; }
+  }
+  for (size_t i = 0; i < V->n; ++i) {
+    ef_iter it = efl_begin(V->v[i]);
+    while (efi_has_next(&it)) {
+      ef_pairing* root = (ef_pairing*)efi_next(&it);
+      if (root->visited) continue;
+      ef_list* embs = subtree_embeddings(root, cfg, GEN);
+      ef_list* cands = factorizations_from_embeddings(embs, cfg);
+      ef_iter ci = efl_begin(cands);
+      while (efi_has_next(&ci)) {
+        ef_list* f = (ef_list*)efi_next(&ci);
+        bool ok = not_source_sink(f, (int)est_len);
+        if (ok) ok = exon_start_end_ok(f);
+        if (ok) { f = handle_endpoints(f, GEN, EST, be); if (efl_empty(f)) ok = false; }
+        if (ok) { f = ef_clean_external_exons(f, GEN, EST, be); if (efl_empty(f)) ok = false; }
+        if (ok) { f = clean_low_complexity(f, GEN, EST, cfg); if (efl_empty(f)) ok = false; }
+        if (ok) { f = ef_clean_noisy_exons(f, GEN, EST, false, be); if (efl_empty(f)) ok = false; }
+        if (ok) ok = est_coverage_ok(f, EST);
+        if (ok) {
+          bool added;
+          flist = ef_add_if_not_exists(f, flist, cfg, &added);
+          if (!added) ef_factorization_free(f);
+        } else {
+          ef_factorization_free(f);
+        }
+      }
+      efl_free(cands, NULL);
+    }
+  }
+  /* release the memoised embeddings */
+  for (size_t i = 0; i < V->n; ++i) {
+    ef_iter it = efl_begin(V->v[i]);
+    while (efi_has_next(&it)) { ef_pairing* p = (ef_pairing*)efi_next(&it); if (p->emb_memo) { efl_free(p->emb_memo, embedding_free); p->emb_memo = NULL; } }
+  }
+
+  /* FILTER 1: coverage (:278-331) */
+  {
+    const size_t nf = efl_size(flist);
+    double* cov = (double*)malloc((nf + 1) * sizeof(double));
+    double max_cov = 0.0;
+    size_t k = 0;
+    ef_iter it = efl_begin(flist);
+    while (efi_has_next(&it)) {
+      ef_list* f = (ef_list*)efi_next(&it);
+      bool src_sink = false;
+      if (efl_size(f) == 1) {
+        const ef_factor* h = (const ef_factor*)efl_head(f);
+        if (h->EST_start < 0 || h->EST_start >= (int)est_len) { cov[k] = -1.0; src_sink = true; }
+      }
+      if (!src_sink) { cov[k] = coverage_of(f, est_len); if (max_cov < cov[k]) max_cov = cov[k]; }
+      ++k;
+    }
+    k = 0;
+    it = efl_begin(flist);
+    const int slen = (int)strlen(EST);
+    while (efi_has_next(&it)) {
+      efi_next(&it);
+      const double c = cov[k++];
+      if (c == -1.0 || max_cov - c > cfg->max_coverage_diff) efi_remove(&it, ef_factorization_free);
+      else if ((max_cov - c) * slen > 100) efi_remove(&it, ef_factorization_free);
+    }
+    free(cov);
+  }
+  /* FILTER 3: gap length on P (:376-414) */
+  {
+    const size_t nf = efl_size(flist);
+    int* gl = (int*)malloc((nf + 1) * sizeof(int));
+    int min_gl = -1;
+    size_t k = 0;
+    ef_iter it = efl_begin(flist);
+    while (efi_has_next(&it)) {
+      gl[k] = gap_length_of((ef_list*)efi_next(&it));
+      if (min_gl == -1 || min_gl > gl[k]) min_gl = gl[k];
+      ++k;
+    }
+    k = 0;
+    it = efl_begin(flist);
+    while (efi_has_next(&it)) {
+      efi_next(&it);
+      const int g = gl[k++];
+      if (cfg->max_gapLength_diff != -1 && g - min_gl > cfg->max_gapLength_diff) efi_remove(&it, ef_factorization_free);
+    }
+    free(gl);
+  }
+  /* FILTER 4: gap errors (:416-433) */
+  {
+    ef_iter it = efl_begin(flist);
+    while (efi_has_next(&it)) {
+      ef_list* f = (ef_list*)efi_next(&it);
+      if (!check_gap_errors(f, EST, GEN, cfg, be)) efi_remove(&it, ef_factorization_free);
+    }
+  }
+  if (cfg->max_number_of_factorizations != 0 && (int)efl_size(flist) > cfg->max_number_of_factorizations) {
+    efl_free(flist, ef_factorization_free);
+    flist = efl_new();
+  }
+  /* intron refinement (:446-490) */
+  {
+    ef_iter it = efl_begin(flist);
+    while (efi_has_next(&it)) {
+      ef_list* f = (ef_list*)efi_next(&it);
+      if (efl_empty(f)) continue;
+      ef_iter fi = efl_begin(f);
+      ef_factor* donor = (ef_factor*)efi_next(&fi);
+      bool first = true;
+      while (efi_has_next(&fi)) {
+        ef_factor* acc = (ef_factor*)efi_next(&fi);
+        ef_refine_intron(cfg, gen_info, est_info, donor, acc, first, be);
+        first = false;
+        donor = acc;
+      }
+      fi = efl_begin(f);
+      const ef_factor* e1 = (const ef_factor*)efi_next(&fi);
+      if (efi_has_next(&fi)) {
+        const ef_factor* e2 = (const ef_factor*)efi_next(&fi);
+        if (e1->EST_start == e2->EST_start) free(efl_pop_front(f));
+      }
+    }
+  }
+  /* tail correction and polyA (:573-585) -- on the ORIGINAL EST sequence */
+  est->polyA_signals = efl_new();
+  est->polyadenil_signals = efl_new();
+  {
+    ef_iter it = efl_begin(flist);
+    while (efi_has_next(&it)) {
+      ef_list* f = (ef_list*)efi_next(&it);
+      correct_tail(f, GEN, est_info->original_seq);
+      bool polyadenil = false;
+      const bool polyA = detect_polyA(f, GEN, est_info->original_seq, &polyadenil);
+      efl_push_back(est->polyA_signals, polyA ? (void*)1 : (void*)2);
+      efl_push_back(est->polyadenil_signals, polyadenil ? (void*)1 : (void*)2);
+    }
+  }
+  est->factorizations = flist;
+  return est;
+}

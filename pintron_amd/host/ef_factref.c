@@ -1,0 +1,366 @@
+/* Post-refinement of the factorizations of one EST: validity / duplicate removal, recovery of lost
+ * prefixes and suffixes, removal of false small exons, search for new small exons, final cleaning.
+ * Behaviour follows src/factorization-refinement.c of the reference (cited per function), quirks
+ * included.  Dynamic programs are backend (GPU) calls. */
+#include <limits.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "estfact.h"
+
+#define UB_VERY_SMALL_EXON 2
+#define LB_SMALL_EXON 6
+#define UB_SMALL_EXON 23
+#define UB_MED_EXON 100
+#define AFFIXES_LENGTH 5
+#define MAX_ERROR_RATE 0.17
+#define MIN_PERFECT_BORDER 6
+#define MAX_ERRORS_AS_SMALL 2
+#define INTRON_ND 2
+
+static size_t zmin(size_t a, size_t b) { return a < b ? a : b; }
+static size_t zmax(size_t a, size_t b) { return a > b ? a : b; }
+
+static void dp(ef_backend* be, int kind, const char* a, size_t la, const char* b, size_t lb,
+               uint32_t p0, uint32_t p1, uint32_t p2, uint32_t tail, ef_dp_res* r) {
+  ef_dp_req rq = { kind, a, la, b, lb, p0, p1, p2, tail };
+  memset(r, 0, sizeof(*r));
+  if (be->dp(be->self, &rq, r) != 0) { fprintf(stderr, "* FATAL dynamic-programming backend failed (kind %d)\n", kind); abort(); }
+}
+
+/* valid bytes after t[len] (0..2) when t points into the NUL-terminated string s */
+static uint32_t tail_of(const char* s, const char* t, size_t len) {
+  const size_t total = strlen(s), end = (size_t)(t - s) + len;
+  if (end >= total) return 0;
+  return total - end >= 2 ? 2u : 1u;
+}
+
+/* remove_factorizations_with_very_small_exons (:85-112) */
+void ef_remove_factorizations_with_very_small_exons(ef_list* facts) {
+  ef_iter it = efl_begin(facts);
+  while (efi_has_next(&it)) {
+    ef_list* f = (ef_list*)efi_next(&it);
+    bool small = false;
+    ef_iter fi = efl_begin(f);
+    while (!small && efi_has_next(&fi)) { const ef_factor* x = (const ef_factor*)efi_next(&fi); small = (x->EST_end + 1 - x->EST_start) <= UB_VERY_SMALL_EXON; }
+    if (small) efi_remove(&it, ef_factorization_free);
+  }
+}
+
+/* remove_invalid_factorizations (:121-165) */
+static void remove_invalid(ef_list* facts) {
+  ef_iter it = efl_begin(facts);
+  while (efi_has_next(&it)) {
+    ef_list* f = (ef_list*)efi_next(&it);
+    bool invalid = false;
+    const ef_factor* prev = NULL;
+    ef_iter fi = efl_begin(f);
+    while (!invalid && efi_has_next(&fi)) {
+      const ef_factor* x = (const ef_factor*)efi_next(&fi);
+      invalid = (x->EST_start > x->EST_end) || (x->GEN_start > x->GEN_end);
+      if (!invalid && prev) invalid = (prev->EST_end >= x->EST_start) || (prev->GEN_end >= x->GEN_start);
+      prev = x;
+    }
+    if (invalid) efi_remove(&it, ef_factorization_free);
+  }
+}
+
+/* remove_duplicated_factorizations (:175-240): exact duplicates, the earlier one stays (the
+ * reference's rotating-hash pre-check has no false negatives, so it never changes the result) */
+void ef_remove_duplicated_factorizations(ef_list* facts) {
+  ef_iter i1 = efl_begin(facts);
+  while (efi_has_next(&i1)) {
+    ef_list* f1 = (ef_list*)efi_next(&i1);
+    ef_iter i2 = efl_begin(facts);
+    while (efi_has_next(&i2)) {
+      ef_list* f2 = (ef_list*)efi_next(&i2);
+      if (f1 == f2) break;
+      if (efl_size(f1) != efl_size(f2)) continue;
+      bool equal = true;
+      ef_iter a = efl_begin(f1), b = efl_begin(f2);
+      while (equal && efi_has_next(&a)) {
+        const ef_factor* x = (const ef_factor*)efi_next(&a); const ef_factor* y = (const ef_factor*)efi_next(&b);
+        equal = x->EST_start == y->EST_start && x->EST_end == y->EST_end && x->GEN_start == y->GEN_start && x->GEN_end == y->GEN_end;
+      }
+      if (equal) { efi_remove(&i1, ef_factorization_free); break; }
+    }
+  }
+}
+
+/* recover_lost_prefixes_and_suffixes (:1177-1266) */
+static void recover_affixes(const ef_seq* gen, ef_est* e, ef_backend* be) {
+  const char* G = gen->seq;
+  const char* E = e->info->seq;
+  const size_t totg = strlen(G), tote = strlen(E);
+  ef_iter it = efl_begin(e->factorizations);
+  while (efi_has_next(&it)) {
+    ef_list* f = (ef_list*)efi_next(&it);
+    ef_factor* ff = (ef_factor*)efl_head(f);
+    if (ff->EST_start > 0 && ff->GEN_start > 0) {
+      const size_t flen = (size_t)(ff->EST_start < ff->GEN_start ? ff->EST_start : ff->GEN_start);
+      const int cap = (int)((1.0 + MAX_ERROR_RATE) * flen);
+      const size_t elen = (size_t)(ff->EST_start < cap ? ff->EST_start : cap);
+      const size_t glen = (size_t)(ff->GEN_start < cap ? ff->GEN_start : cap);
+      char* ef = (char*)malloc(elen + 1); char* gf = (char*)malloc(glen + 1);
+      for (size_t i = 0; i < elen; ++i) ef[i] = E[ff->EST_start - 1 - i];
+      for (size_t i = 0; i < glen; ++i) gf[i] = G[ff->GEN_start - 1 - i];
+      ef[elen] = gf[glen] = '\0';
+      if (ef[0] != gf[0]) {
+        ef_dp_res r;
+        dp(be, EF_DP_AFFIX, ef, elen, gf, glen, 0, 0, 0, 0, &r);
+        if (r.v[0]) { ff->EST_start -= r.v[1]; ff->GEN_start -= r.v[2]; }
+      }
+      free(ef); free(gf);
+    }
+    ef_factor* fl = (ef_factor*)efl_tail(f);
+    if ((tote - (size_t)fl->EST_end) > 1 && (totg - (size_t)fl->GEN_end) > 1) {
+      const size_t flen = zmin(tote - fl->EST_end - 1, totg - fl->GEN_end - 1);
+      /* `(int)(1.0+_MAX_ERROR_RATE_)*flen` in the reference: the cast binds first => 1*flen */
+      const size_t elen = zmin(tote - fl->EST_end - 1, (size_t)((int)(1.0 + MAX_ERROR_RATE)) * flen);
+      const size_t glen = zmin(totg - fl->GEN_end - 1, (size_t)((int)(1.0 + MAX_ERROR_RATE)) * flen);
+      const char* ef = E + fl->EST_end;          /* starts ON the last exon character (:1239,1242) */
+      const char* gf = G + fl->GEN_end;
+      if (ef[0] != gf[0]) {
+        ef_dp_res r;
+        dp(be, EF_DP_AFFIX, ef, elen, gf, glen, 0, 0, 0, 0, &r);
+        if (r.v[0]) { fl->EST_end += r.v[1]; fl->GEN_end += r.v[2]; }
+      }
+    }
+  }
+}
+
+/* analyze_possibly_small_exon (:960-1093); `it` stands right after `next` */
+static bool analyze_small_exon(ef_factor** pprev, ef_factor** pcurr, ef_factor* next, ef_iter* it,
+                               const ef_seq* gen, ef_est* e, ef_backend* be) {
+  ef_factor* prev = *pprev; ef_factor* curr = *pcurr;
+  if (prev == NULL || next == NULL) return false;
+  const char* G = gen->seq; const char* E = e->info->seq;
+  const size_t elen = (size_t)(curr->EST_end + 1 - curr->EST_start);
+  const size_t glen = (size_t)(curr->GEN_end + 1 - curr->GEN_start);
+  if (elen > UB_MED_EXON) return false;
+  const size_t orig_ed = ef_compute_edit_distance(be, E + curr->EST_start, elen, G + curr->GEN_start, glen);
+  const int estart_i = prev->EST_start + 1 > prev->EST_end + 1 - AFFIXES_LENGTH ? prev->EST_start + 1 : prev->EST_end + 1 - AFFIXES_LENGTH;
+  const size_t estart = (size_t)estart_i;
+  const size_t eend = zmin((size_t)next->EST_end, (size_t)(next->EST_start + AFFIXES_LENGTH));
+  const size_t epreflen = prev->EST_end + 1 - estart, esufflen = eend - next->EST_start, allelen = eend - estart;
+  const char* allefact = E + estart;
+  const int gstart_i = prev->GEN_start + 1 > prev->GEN_end + 1 - AFFIXES_LENGTH ? prev->GEN_start + 1 : prev->GEN_end + 1 - AFFIXES_LENGTH;
+  const size_t gstart = (size_t)gstart_i;
+  const size_t gend = zmin((size_t)next->GEN_end, (size_t)(next->GEN_start + AFFIXES_LENGTH));
+  const size_t gpreflen = prev->GEN_end + 1 - gstart, gsufflen = gend - next->GEN_start, allglen = gend - gstart;
+  const char* allgfact = G + gstart;
+  const size_t ed_pref = ef_compute_edit_distance(be, allefact, epreflen, allgfact, gpreflen);
+  /* the reference takes the "suffix" BEFORE the window start (allefact - esufflen, :1017-1018) */
+  const size_t ed_suff = (estart >= esufflen && gstart >= gsufflen)
+      ? ef_compute_edit_distance(be, allefact - esufflen, esufflen, allgfact - gsufflen, gsufflen) : 0;
+  ef_dp_res r;
+  const uint32_t max_errs = (uint32_t)(orig_ed + ed_pref + ed_suff);
+  dp(be, EF_DP_BORDERS, allefact, allelen, allgfact, allglen, 0, (uint32_t)allelen, max_errs, tail_of(G, allgfact, allglen), &r);
+  if (!r.v[0]) return false;
+  const size_t off_p = (size_t)r.v[1], off_t1 = (size_t)r.v[2], off_t2 = (size_t)r.v[3];
+  const double prev_avg = (ef_burset_adaptor(G, (size_t)(prev->GEN_end + 1), (size_t)curr->GEN_start) +
+                           ef_burset_adaptor(G, (size_t)(curr->GEN_end + 1), (size_t)next->GEN_start)) / 2.0;
+  const double new_freq = ef_burset_adaptor(G, gstart + off_t1, gend - allglen + off_t2);
+  if (!(new_freq >= prev_avg)) return false;
+  prev->EST_end = (int)(estart + off_p - 1);
+  next->EST_start = (int)(eend + off_p - allelen);
+  prev->GEN_end = (int)(gstart + off_t1 - 1);
+  next->GEN_start = (int)(gend + off_t2 - allglen);
+  efi_prev(it);
+  efi_remove(it, free);                      /* drops `curr` */
+  *pcurr = prev;
+  efi_prev(it);
+  *pprev = (ef_factor*)it->prev->el;         /* NULL at the list head (sentinel) */
+  efi_next(it);
+  efi_next(it);
+  return true;
+}
+
+/* remove_false_small_exons (:1095-1125) */
+static void remove_false_small_exons(const ef_seq* gen, ef_est* e, ef_backend* be) {
+  ef_iter it = efl_begin(e->factorizations);
+  while (efi_has_next(&it)) {
+    ef_list* f = (ef_list*)efi_next(&it);
+    ef_factor *prev = NULL, *curr = NULL, *next = NULL;
+    bool removed = false;
+    ef_iter fi = efl_begin(f);
+    if (efi_has_next(&fi)) next = (ef_factor*)efi_next(&fi);
+    while (next != NULL) {
+      if (!removed) {
+        prev = curr; curr = next; next = NULL;
+        if (efi_has_next(&fi)) next = (ef_factor*)efi_next(&fi);
+      }
+      removed = analyze_small_exon(&prev, &curr, next, &fi, gen, e, be);
+    }
+  }
+}
+
+static bool canonical_intron(const char* G, size_t s, size_t e) {           /* :481-494 */
+  return (G[s] == 'G' && G[s + 1] == 'T' && G[e - 1] == 'A' && G[e] == 'G') ||
+         (G[s] == 'g' && G[s + 1] == 't' && G[e - 1] == 'a' && G[e] == 'g');
+}
+
+static ef_factor* factor_new(int es, int ee, int gs, int ge) {
+  ef_factor* f = (ef_factor*)malloc(sizeof(ef_factor));
+  f->EST_start = es; f->EST_end = ee; f->GEN_start = gs; f->GEN_end = ge;
+  return f;
+}
+
+/* search_small_exon_at_prefix (:500-606) */
+static void small_exon_at_prefix(ef_factor* p1, ef_iter* it, const ef_seq* gen, ef_est* e,
+                                 const ef_config* cfg, ef_backend* be) {
+  const char* G = gen->seq; const char* E = e->info->seq;
+  const size_t e1len = (size_t)(p1->EST_end + 1 - p1->EST_start), g1len = (size_t)(p1->GEN_end + 1 - p1->GEN_start);
+  if (!((e1len + (size_t)p1->EST_start) >= (LB_SMALL_EXON + UB_SMALL_EXON))) return;
+  const size_t eplen = zmin(zmin((size_t)p1->EST_start, (size_t)p1->GEN_start), 2 * UB_SMALL_EXON);
+  const char* epfact = E + p1->EST_start - eplen;
+  const size_t e1plen = zmin(zmin(e1len, g1len), UB_SMALL_EXON);
+  ef_dp_res r;
+  dp(be, EF_DP_LCF, G, (size_t)p1->GEN_start, epfact, eplen, 0, 0, 0, 0, &r);
+  const size_t cflen = (size_t)r.v[0], pg = (size_t)r.v[1], pe = (size_t)r.v[2];
+  if (cflen < LB_SMALL_EXON) return;
+  const unsigned edp = ef_compute_edit_distance(be, E + p1->EST_start, e1plen, G + p1->GEN_start, e1plen);
+  /* `pe` is an offset inside the discarded prefix but the reference uses it as an absolute EST
+   * coordinate from here on (:551-603); reproduced as is */
+  const size_t allelen = zmin((size_t)(p1->EST_end + 1), (size_t)(p1->EST_start + UB_SMALL_EXON)) - pe;
+  const size_t allglen = zmin((size_t)(p1->GEN_end + 1), (size_t)(p1->GEN_start + UB_SMALL_EXON)) - pg;
+  if (allelen < 2 * LB_SMALL_EXON || allelen > 4096) return;     /* outside what the reference can evaluate */
+  dp(be, EF_DP_BORDERS, E + pe, allelen, G + pg, allglen, LB_SMALL_EXON, (uint32_t)(allelen - LB_SMALL_EXON), edp,
+     tail_of(G, G + pg, allglen), &r);
+  if (!r.v[0]) return;
+  const size_t off_p = (size_t)r.v[1], off_t1 = (size_t)r.v[2], off_t2 = (size_t)r.v[3];
+  if ((int)off_t2 - (int)off_t1 < cfg->min_intron_length) return;
+  if (!canonical_intron(G, pg + off_t1, pg + off_t2 - 1)) return;
+  if (off_p - pe < LB_SMALL_EXON) return;                        /* size_t arithmetic as in the reference */
+  ef_factor* nw = factor_new((int)pe, (int)(pe + off_p - 1), (int)pg, (int)(pg + off_t1 - 1));
+  p1->EST_start = (int)(pe + off_p);
+  p1->GEN_start = (int)(pg + off_t2);
+  efi_insert_before(it, nw);
+}
+
+/* search_small_exon (:641-873) */
+static void small_exon_between(ef_factor* p1, ef_factor* p2, ef_iter* it, const ef_seq* gen, ef_est* e,
+                               const ef_config* cfg, ef_backend* be) {
+  const char* G = gen->seq; const char* E = e->info->seq;
+  const size_t e1len = (size_t)(p1->EST_end + 1 - p1->EST_start), g1len = (size_t)(p1->GEN_end + 1 - p1->GEN_start);
+  const size_t e2len = (size_t)(p2->EST_end + 1 - p2->EST_start), g2len = (size_t)(p2->GEN_end + 1 - p2->GEN_start);
+  if (!((e1len + e2len) >= (LB_SMALL_EXON + 2 * UB_SMALL_EXON))) return;
+  const size_t e1slen = zmin(zmin(e1len, g1len), UB_SMALL_EXON), g1slen = e1slen;
+  const size_t e1sstart = (size_t)p1->EST_end + 1 - e1slen, g1sstart = (size_t)p1->GEN_end + 1 - g1slen;
+  char* e1s = ef_real_substring((int)e1sstart, (int)e1slen, E);
+  char* g1s = ef_real_substring((int)g1sstart, (int)g1slen, G);
+  const size_t e2plen = zmin(zmin(e2len, g2len), UB_SMALL_EXON), g2plen = e2plen;
+  const size_t e2pstart = (size_t)p2->EST_start, g2pstart = (size_t)p2->GEN_start;
+  char* e2p = ef_real_substring((int)e2pstart, (int)e2plen, E);
+  char* g2p = ef_real_substring((int)g2pstart, (int)g2plen, G);
+  const size_t sed = ef_compute_edit_distance(be, e1s, e1slen, g1s, g1slen);
+  const size_t ped = ef_compute_edit_distance(be, e2p, e2plen, g2p, g2plen);
+  bool go = false;
+  const int orig_class = ef_classify_intron(G, p1->GEN_end + 1, p2->GEN_start - 1);
+  if (sed + ped > MAX_ERRORS_AS_SMALL) go = true;
+  if (orig_class == INTRON_ND) go = true;
+  if (go) {
+    size_t e1socc = 0, g1socc = 0, f1slen = e1slen;
+    ef_dp_res r;
+    if (sed > 0) { dp(be, EF_DP_LCF, e1s, e1slen, g1s, g1slen, 0, 0, 0, 0, &r); f1slen = (size_t)r.v[0]; e1socc = (size_t)r.v[1]; g1socc = (size_t)r.v[2]; }
+    size_t e2pocc = 0, g2pocc = 0, f2plen = e2plen;
+    if (ped > 0) { dp(be, EF_DP_LCF, e2p, e2plen, g2p, g2plen, 0, 0, 0, 0, &r); f2plen = (size_t)r.v[0]; e2pocc = (size_t)r.v[1]; g2pocc = (size_t)r.v[2]; }
+    if (f1slen == e1slen && e2pocc > 0) {
+      size_t nf = f1slen + 1;
+      while ((nf - f1slen) < e2pocc && E[e1sstart + e1socc + f1slen] == G[g2pstart + nf - f1slen]) ++nf;
+      if (nf - 1 > f1slen) f1slen = nf - 1;
+    }
+    const size_t elen = (e1slen - e1socc) + (e2pocc + f2plen) - (2 * MIN_PERFECT_BORDER);
+    const size_t estart = e1sstart + e1socc + MIN_PERFECT_BORDER;
+    const size_t allgstart = g1sstart + g1socc + MIN_PERFECT_BORDER;
+    const size_t allglen = g2pstart + g2pocc + f2plen - MIN_PERFECT_BORDER - allgstart;
+    const size_t MIL = zmax(4, (size_t)cfg->min_intron_length);
+    if (f1slen < MIN_PERFECT_BORDER) go = false;
+    else if (f2plen < MIN_PERFECT_BORDER) go = false;
+    else if (allglen < 2 * MIL + LB_SMALL_EXON) go = false;
+    else if (elen < LB_SMALL_EXON) go = false;
+    if (go) {
+      char* efact = ef_real_substring((int)estart, (int)elen, E);
+      char* allg = ef_real_substring((int)allgstart, (int)allglen, G);
+      size_t max_len = 0, ecut1 = 0, ecut2 = 0, gcut1_1 = 0, gcut1_2 = 0, gcut2_1 = 0, gcut2_2 = 0;
+      const size_t max_offstart = zmin(zmin(f1slen + 1 - MIN_PERFECT_BORDER, elen + 1 - LB_SMALL_EXON), allglen + 1 - (2 * MIL) - LB_SMALL_EXON);
+      for (size_t os = 0; os < max_offstart; ++os) {
+        const size_t max_offend = zmin(zmin(f2plen + 1 - MIN_PERFECT_BORDER, elen + 1 - os - LB_SMALL_EXON), allglen + 1 - (2 * MIL) - LB_SMALL_EXON - os);
+        for (size_t oe = 0; oe < max_offend; ++oe) {
+          const char sv_e = efact[elen - oe]; efact[elen - oe] = '\0';
+          const char sv_g = allg[allglen - oe - MIL]; allg[allglen - oe - MIL] = '\0';
+          char* occ = allg + os + MIL;
+          while ((occ = strstr(occ, efact + os))) {
+            const size_t i1s = allgstart + os, i1e = allgstart + (size_t)(occ - allg) - 1;
+            const size_t i2s = i1e + 1 + elen - os - oe, i2e = allgstart + allglen - oe - 1;
+            const int t1 = ef_classify_intron(G, (int)i1s, (int)i1e), t2 = ef_classify_intron(G, (int)i2s, (int)i2e);
+            if (t1 != INTRON_ND && t2 != INTRON_ND) {
+              const size_t sl = elen - os - oe;
+              if (sl > max_len) { max_len = sl; ecut1 = estart + os; ecut2 = estart + os + sl; gcut1_1 = i1s; gcut1_2 = i1e + 1; gcut2_1 = i2s; gcut2_2 = i2e + 1; }
+            }
+            ++occ;
+          }
+          efact[elen - oe] = sv_e; allg[allglen - oe - MIL] = sv_g;
+        }
+      }
+      if (max_len >= LB_SMALL_EXON) {
+        ef_factor* nw = factor_new((int)ecut1, (int)ecut2 - 1, (int)gcut1_2, (int)gcut2_1 - 1);
+        p2->EST_start = (int)ecut2; p2->GEN_start = (int)gcut2_2;
+        p1->EST_end = (int)ecut1 - 1; p1->GEN_end = (int)gcut1_1 - 1;
+        efi_insert_before(it, nw);
+      }
+      free(efact); free(allg);
+    }
+  }
+  free(e1s); free(g1s); free(e2p); free(g2p);
+}
+
+/* search_for_new_small_exons (:875-912) */
+static void search_new_small_exons(const ef_seq* gen, ef_est* e, const ef_config* cfg, ef_backend* be) {
+  ef_iter it = efl_begin(e->factorizations);
+  while (efi_has_next(&it)) {
+    ef_list* f = (ef_list*)efi_next(&it);
+    ef_factor *p1 = NULL, *p2 = NULL;
+    ef_iter fi = efl_begin(f);
+    if (efi_has_next(&fi)) {
+      p1 = (ef_factor*)efi_next(&fi);
+      if (p1->EST_start > LB_SMALL_EXON) small_exon_at_prefix(p1, &fi, gen, e, cfg, be);
+    }
+    if (efi_has_next(&fi)) p2 = (ef_factor*)efi_next(&fi);
+    while (p2 != NULL) {
+      small_exon_between(p1, p2, &fi, gen, e, cfg, be);
+      p1 = p2; p2 = NULL;
+      if (efi_has_next(&fi)) p2 = (ef_factor*)efi_next(&fi);
+    }
+  }
+}
+
+/* clean_factorizations (:914-950): cleaning on the ORIGINAL EST sequence */
+static void clean_factorizations(const ef_seq* gen, ef_est* e, const ef_config* cfg, ef_backend* be) {
+  ef_list* cleaned = efl_new();
+  ef_iter it = efl_begin(e->factorizations);
+  while (efi_has_next(&it)) {
+    ef_list* f = (ef_list*)efi_next(&it);
+    f = ef_clean_noisy_exons(f, gen->seq, e->info->original_seq, false, be);
+    f = ef_clean_external_exons(f, gen->seq, e->info->original_seq, be);
+    if (efl_empty(f)) efi_remove(&it, ef_factorization_free);
+    else {
+      bool added;
+      cleaned = ef_add_if_not_exists(f, cleaned, cfg, &added);
+      if (!added) efi_remove(&it, ef_factorization_free);
+    }
+  }
+  efl_free(e->factorizations, NULL);
+  e->factorizations = cleaned;
+}
+
+/* refine_EST_factorizations (:1270-1305) */
+void ef_refine_est_factorizations(const ef_seq* gen, ef_est* e, const ef_config* cfg, ef_backend* be) {
+  remove_invalid(e->factorizations);
+  ef_remove_duplicated_factorizations(e->factorizations);
+  recover_affixes(gen, e, be);
+  remove_false_small_exons(gen, e, be);
+  ef_remove_duplicated_factorizations(e->factorizations);
+  search_new_small_exons(gen, e, cfg, be);
+  clean_factorizations(gen, e, cfg, be);
+}

@@ -82,6 +82,7 @@ typedef struct ef_pairing {
   bool visited;
   ef_list* adjs;
   ef_list* incs;
+  ef_list* emb_memo;      /* embeddings of the subtree rooted here, once computed */
 } ef_pairing;
 
 typedef struct {
@@ -106,17 +107,82 @@ void ef_meg_write(FILE* f, ef_meg* V);                                 /* src/io
 void ef_intronic_edges_write(FILE* f, ef_meg* V);                      /* src/max-emb-graph.c:677 */
 
 /* ---- backend: where pairings and dynamic programs are computed ------------------------------ */
+/* DP request/response in the vocabulary of include/pintron_gpu.h (same kinds, same result slots) */
+enum { EF_DP_ALIGN = 0, EF_DP_GAP = 1, EF_DP_ED = 2, EF_DP_KBAND = 3, EF_DP_LCF = 4,
+       EF_DP_BORDERS = 5, EF_DP_AFFIX = 6 };
+typedef struct {
+  int kind;
+  const char* a; size_t la;      /* first operand  (EST side / s1 / p)       */
+  const char* b; size_t lb;      /* second operand (genomic side / s2 / t)   */
+  uint32_t p0, p1, p2, tail;     /* kind-specific, as in pgpu_dp_job         */
+} ef_dp_req;                     /* operands that point into the genomic sequence are recognised
+                                    by address and sent as PGPU_JOB_*_GENOMIC (no copy) */
+typedef struct {
+  int32_t v[6];
+  char* s0; char* s1;            /* ALIGN/GAP: malloc'ed alignment rows (caller frees) */
+} ef_dp_res;
+
 typedef struct ef_backend {
   void* self;
   /* pairings of one pattern; *out is malloc'ed by the backend, freed by the caller */
   int (*pairings)(void* self, const char* pattern, size_t m, unsigned min_factor_len, double rate,
                   ef_triple** out, size_t* n);
+  /* one dynamic program; returns 0 or aborts the EST (never a CPU fallback in the product) */
+  int (*dp)(void* self, const ef_dp_req* req, ef_dp_res* res);
 } ef_backend;
+
+/* ---- factorizations (include/types.h:160-180) ------------------------------------------------ */
+typedef struct { int EST_start, EST_end, GEN_start, GEN_end; } ef_factor;   /* 0-based inclusive */
+/* a factorization = ef_list of ef_factor*; a list of factorizations = ef_list of ef_list* */
+
+typedef struct {
+  const ef_seq* info;
+  ef_list* factorizations;       /* may be empty */
+  ef_list* polyA_signals;        /* parallel lists of (void*)(intptr_t)0/1 */
+  ef_list* polyadenil_signals;
+} ef_est;
+
+void ef_factorization_free(void* fact);
+void ef_est_free(ef_est* e);
+
+/* get_EST_factorizations (src/est-factorizations.c:126-594) */
+ef_est* ef_get_est_factorizations(const ef_seq* est, ef_meg* V, const ef_config* cfg,
+                                  const ef_seq* gen, ef_backend* be);
+/* refine_EST_factorizations & co (src/factorization-refinement.c) */
+void ef_refine_est_factorizations(const ef_seq* gen, ef_est* e, const ef_config* cfg, ef_backend* be);
+void ef_remove_factorizations_with_very_small_exons(ef_list* facts);
+void ef_remove_duplicated_factorizations(ef_list* facts);
+/* refine_intron (src/refine-intron.c:47-265) */
+bool ef_refine_intron(const ef_config* cfg, const ef_seq* gen, const ef_seq* est, ef_factor* donor,
+                      ef_factor* acceptor, bool first_intron, ef_backend* be);
+/* intron classification (src/classify-intron.c:95): 0 = U12, 1 = U2, 2 = not classified */
+int ef_classify_intron(const char* gen_seq, int start, int end);
+/* Burset frequencies (src/refine-intron.c:346-556) */
+int ef_burset_frequency(const char* donor, const char* acceptor);
+int ef_burset_adaptor(const char* t, size_t cut1, size_t cut2);
+int ef_check_burset_patterns(const char* gen, int donor_left_on_gen, int acceptor_right_on_gen);
+/* helpers shared by the modules */
+char* ef_real_substring(int index, int length, const char* s);               /* src/util.c:138 */
+ef_list* ef_clean_noisy_exons(ef_list* fact, const char* gen, const char* est, bool only_internals, ef_backend* be);
+ef_list* ef_clean_external_exons(ef_list* fact, const char* gen, const char* est, ef_backend* be);
+ef_list* ef_add_if_not_exists(ef_list* to_add, ef_list* list, const ef_config* cfg, bool* added);
+uint32_t ef_edit_distance(ef_backend* be, const char* a, size_t la, const char* b, size_t lb);
+/* compute_edit_distance (src/compute-alignments.c:240): equal strings short-cut on the host */
+uint32_t ef_compute_edit_distance(ef_backend* be, const char* a, size_t la, const char* b, size_t lb);
+/* write_multifasta_output (src/io-multifasta.c:187-246) */
+void ef_write_multifasta_output(const ef_seq* gen, const ef_est* e, FILE* f, char retain_externals);
+/* compute_est_fact (src/compute-est-fact.c:192-293) without the diagnostics side files */
+typedef struct { FILE *fmeg, *fpmeg, *ftmeg, *fintronic; } ef_side_files;
+ef_est* ef_compute_est_fact(const ef_seq* gen, const ef_seq* est, ef_backend* be, const ef_config* cfg,
+                            const ef_side_files* side);
 
 /* build_meg (src/compute-est-fact.c:90-152): vertex set, edges, simplification, reduction,
  * compaction, complexity retry loop.  *inc_pairing_len is updated like the reference's. */
 ef_meg* ef_build_meg(const ef_seq* est, ef_backend* be, const ef_config* shared_cfg, size_t* inc_pairing_len);
 
 void ef_write_single_est_info(FILE* f, const ef_seq* s);              /* src/io-multifasta.c:270 */
+
+/* the whole est-fact process (src/main-est-fact.c:90-339); the caller supplies the backend */
+int ef_run(int argc, char** argv, ef_backend* (*open_backend)(const ef_seq* gen), void (*close_backend)(ef_backend*));
 
 #endif
