@@ -83,6 +83,8 @@ static void load_all(void) {
   loaded = 1;
 }
 
+void ef_classify_init(void) { load_all(); }
+
 /* GetMatInspectorScoreOfaMotif (:620-663).  A character outside ACGTN indexes row -1 in the
  * reference (out of bounds under NDEBUG); we return a score no motif can reach instead. */
 static double motif_score(const char* s, int k) {

@@ -70,57 +70,86 @@ ef_est* ef_compute_est_fact(const ef_seq* gen, const ef_seq* est, ef_backend* be
   return fe;
 }
 
-/* main of est-fact (src/main-est-fact.c:90-339) with the backend supplied by the caller */
-int ef_run(int argc, char** argv, ef_backend* (*open_backend)(const ef_seq* gen), void (*close_backend)(ef_backend*)) {
-  ef_config cfg;
-  if (ef_config_load(&cfg, argc, argv) != 0) return 2;
-  char buf[64];
-  snprintf(buf, sizeof buf, "info-pid-%u.log", (unsigned)getpid());
-  FILE* flog = fopen(buf, "w");
-  if (!flog) { fprintf(stderr, "* FATAL Cannot create file info.log! Terminating\n"); return 1; }
-  fprintf(flog, "start\n");
+/* inputs of one est-fact run: configuration, genomic, prepared EST list (siblings interleaved) */
+int ef_load_inputs(int argc, char** argv, ef_inputs* in) {
+  memset(in, 0, sizeof(*in));
+  if (ef_config_load(&in->cfg, argc, argv) != 0) return 2;
   ef_seq** gens = NULL; ef_seq** ests = NULL;
   const long ng = ef_read_multifasta("genomic.txt", &gens);
   if (ng < 0) { fprintf(stderr, "* FATAL File genomic.txt not found! Terminating\n"); return 1; }
   if (ng != 1) { fprintf(stderr, "* FATAL genomic.txt must hold exactly one sequence\n"); return 1; }
-  ef_seq* gen = gens[0];
-  ef_parse_genomic_header(gen);
-  if (ef_ntails_removal(gen) != 0) { fprintf(stderr, "* FATAL The sequence is only composed by Ns.\n"); return 1; }
+  in->gen = gens[0];
+  free(gens);
+  ef_parse_genomic_header(in->gen);
+  if (ef_ntails_removal(in->gen) != 0) { fprintf(stderr, "* FATAL The sequence is only composed by Ns.\n"); return 1; }
   const long n_in = ef_read_multifasta("ests.txt", &ests);
   if (n_in < 0) { fprintf(stderr, "* FATAL File ests.txt not found! Terminating\n"); return 1; }
-  FILE* fout = fopen("raw-multifasta-out.txt", "w");
-  ef_side_files side = { fopen("megs.txt", "w"), fopen("processed-megs.txt", "w"),
-                         fopen("processed-megs-info.txt", "w"), fopen("meg-edges.txt", "w") };
-  FILE* fests = fopen("processed-ests.txt", "w");
-  if (!fout || !fests || !side.fmeg || !side.fpmeg || !side.ftmeg || !side.fintronic) {
-    fprintf(stderr, "* FATAL Cannot create an output file! Terminating\n");
-    return 1;
-  }
-  /* preparation loop (:190-213) */
-  ef_seq** list = (ef_seq**)malloc((size_t)(2 * n_in + 1) * sizeof(ef_seq*));
-  size_t n = 0;
+  /* preparation loop (src/main-est-fact.c:190-213) */
+  in->list = (ef_seq**)malloc((size_t)(2 * n_in + 1) * sizeof(ef_seq*));
   for (long i = 0; i < n_in; ++i) {
     ef_seq* est = ests[i];
     ef_set_gb_identification(est);
     ef_set_strand_and_rc(est);
-    list[n++] = est;
+    in->list[in->n++] = est;
     ef_polyAT_substitution(est);
     if (!est->fixed_strand) {
       ef_seq* rev = ef_copy_and_reverse(est);
-      list[n++] = rev;
+      in->list[in->n++] = rev;
       ef_polyAT_substitution(rev);
     }
   }
-  ef_backend* be = open_backend(gen);
+  free(ests);
+  return 0;
+}
+
+void ef_free_inputs(ef_inputs* in) {
+  for (size_t k = 0; k < in->n; ++k) ef_seq_free(in->list[k]);
+  free(in->list);
+  ef_seq_free(in->gen);
+}
+
+int ef_open_outputs(ef_outputs* o) {
+  char buf[64];
+  snprintf(buf, sizeof buf, "info-pid-%u.log", (unsigned)getpid());
+  o->flog = fopen(buf, "w");
+  o->fout = fopen("raw-multifasta-out.txt", "w");
+  o->side.fmeg = fopen("megs.txt", "w");
+  o->side.fpmeg = fopen("processed-megs.txt", "w");
+  o->side.ftmeg = fopen("processed-megs-info.txt", "w");
+  o->fests = fopen("processed-ests.txt", "w");
+  o->side.fintronic = fopen("meg-edges.txt", "w");
+  if (!o->flog || !o->fout || !o->fests || !o->side.fmeg || !o->side.fpmeg || !o->side.ftmeg || !o->side.fintronic) {
+    fprintf(stderr, "* FATAL Cannot create an output file! Terminating\n");
+    return 1;
+  }
+  fprintf(o->flog, "start\n");
+  return 0;
+}
+
+void ef_close_outputs(ef_outputs* o) {
+  fprintf(o->flog, "end\n");
+  fclose(o->flog); fclose(o->fout); fclose(o->fests);
+  fclose(o->side.fmeg); fclose(o->side.fpmeg); fclose(o->side.ftmeg); fclose(o->side.fintronic);
+}
+
+/* main of est-fact (src/main-est-fact.c:90-339), one EST after the other, with the backend
+ * supplied by the caller */
+int ef_run(int argc, char** argv, ef_backend* (*open_backend)(const ef_seq* gen), void (*close_backend)(ef_backend*)) {
+  ef_inputs in;
+  int rc = ef_load_inputs(argc, argv, &in);
+  if (rc) return rc;
+  ef_outputs out;
+  if (ef_open_outputs(&out)) return 1;
+  ef_backend* be = open_backend(in.gen);
   if (!be) { fprintf(stderr, "* FATAL cannot initialise the compute backend (no MI355X / library)\n"); return 1; }
   /* per-EST loop (:249-291) */
   bool reversed = false;
-  for (size_t k = 0; k < n; ++k) {
-    ef_seq* est = list[k];
-    ef_est* fe = ef_compute_est_fact(gen, est, be, &cfg, &side);
+  for (size_t k = 0; k < in.n; ++k) {
+    ef_seq* est = in.list[k];
+    ef_est* fe = ef_compute_est_fact(in.gen, est, be, &in.cfg, &out.side);
     if (!efl_empty(fe->factorizations)) {
-      ef_write_multifasta_output(gen, fe, fout, cfg.retain_externals);
-      ef_write_single_est_info(fests, fe->info);
+      ef_write_multifasta_output(in.gen, fe, out.fout, in.cfg.retain_externals);
+      ef_write_single_est_info(out.fests, fe->info);
       if (!est->fixed_strand && !reversed) ++k;        /* skip the reverse-complement sibling */
       reversed = false;
     } else if (reversed || est->fixed_strand) {
@@ -131,11 +160,7 @@ int ef_run(int argc, char** argv, ef_backend* (*open_backend)(const ef_seq* gen)
     ef_est_free(fe);
   }
   close_backend(be);
-  fclose(fout); fclose(fests); fclose(side.fmeg); fclose(side.fpmeg); fclose(side.ftmeg); fclose(side.fintronic);
-  fprintf(flog, "end\n");
-  fclose(flog);
-  for (size_t k = 0; k < n; ++k) ef_seq_free(list[k]);
-  free(list); free(ests);
-  ef_seq_free(gen); free(gens);
+  ef_close_outputs(&out);
+  ef_free_inputs(&in);
   return 0;
 }

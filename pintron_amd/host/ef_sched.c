@@ -1,0 +1,319 @@
+/* Batched execution of est-fact on the GPU.
+ *
+ * The per-EST algorithm (ef_compute_est_fact) is a sequential program whose pairing request and
+ * dynamic programs depend on earlier results.  To keep one GPU busy with tens of thousands of
+ * small, data-dependent requests, every input EST (the sequence and, when the strand is not fixed,
+ * its reverse-complement sibling, tried only if the first fails: src/main-est-fact.c:249-291) runs
+ * as a FIBRE (ucontext): a request enqueues a job and yields; when no fibre of a worker can run,
+ * the worker submits all pending requests as ONE batch through the C-ABI
+ * (pgpu_pairing_plan_* / pgpu_dp_plan_*), hands the results back and resumes the fibres.
+ * Workers are host threads (one pgpu_ctx = one HIP stream each), ESTs are dealt to them from a
+ * shared counter, and the per-EST output records are written in input order at the end, so the
+ * files are byte-identical to a sequential run.
+ */
+#define _GNU_SOURCE
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+#include <ucontext.h>
+#include <unistd.h>
+
+#include "estfact.h"
+#include "ef_gpu.h"
+#include "ef_sched.h"
+
+enum { F_RUNNABLE, F_WAIT_DP, F_WAIT_PAIR, F_DONE };
+
+struct worker;
+
+typedef struct fiber {
+  ucontext_t ctx;
+  char* stack;
+  struct worker* w;
+  int state;
+  size_t unit;
+  /* pending request */
+  ef_dp_req req; ef_dp_res* res; int rc;
+  const char* pat; size_t pat_len; unsigned pat_L; double pat_rate; ef_triple** pat_out; size_t* pat_n;
+  ef_backend be;
+} fiber;
+
+/* one input EST: entry `first` of the prepared list, plus the sibling at first+1 if any */
+typedef struct {
+  size_t first; bool has_sibling;
+  char* buf[6]; size_t len[6];         /* raw, processed-ests, megs, processed-megs, megs-info, meg-edges */
+} unit;
+
+typedef struct shared {
+  ef_inputs* in;
+  pgpu_index* idx;
+  unit* units; size_t n_units;
+  size_t next_unit;                    /* protected by mu */
+  pthread_mutex_t mu;
+  size_t max_fibers, stack_size;
+  int failed;
+  ef_sched_stats stats;
+} shared;
+
+typedef struct worker {
+  shared* sh;
+  pgpu_ctx* ctx;
+  ucontext_t sched;
+  fiber** fibers; size_t n_fibers;
+  ef_jobbuf jb;
+  char* strings; size_t strings_cap;
+  pgpu_dp_result* results; size_t results_cap;
+  ef_sched_stats stats;
+} worker;
+
+/* ---- fibre side ---------------------------------------------------------------------------------- */
+static int fiber_dp(void* self, const ef_dp_req* q, ef_dp_res* res) {
+  fiber* f = (fiber*)self;
+  f->req = *q; f->res = res; f->state = F_WAIT_DP;
+  swapcontext(&f->ctx, &f->w->sched);
+  return f->rc;
+}
+
+static int fiber_pairings(void* self, const char* pattern, size_t m, unsigned L, double rate, ef_triple** out, size_t* n) {
+  fiber* f = (fiber*)self;
+  f->pat = pattern; f->pat_len = m; f->pat_L = L; f->pat_rate = rate; f->pat_out = out; f->pat_n = n;
+  f->state = F_WAIT_PAIR;
+  swapcontext(&f->ctx, &f->w->sched);
+  return f->rc;
+}
+
+static void fiber_main(unsigned hi, unsigned lo) {
+  fiber* f = (fiber*)(((uintptr_t)hi << 32) | (uintptr_t)lo);
+  shared* sh = f->w->sh;
+  unit* u = &sh->units[f->unit];
+  FILE* fs[6];
+  for (int k = 0; k < 6; ++k) fs[k] = open_memstream(&u->buf[k], &u->len[k]);
+  ef_side_files side = { fs[2], fs[3], fs[4], fs[5] };
+  const ef_inputs* in = sh->in;
+  for (size_t k = u->first; k <= u->first + (u->has_sibling ? 1 : 0); ++k) {
+    ef_est* fe = ef_compute_est_fact(in->gen, in->list[k], &f->be, &in->cfg, &side);
+    const bool aligned = !efl_empty(fe->factorizations);
+    if (aligned) {
+      ef_write_multifasta_output(in->gen, fe, fs[0], in->cfg.retain_externals);
+      ef_write_single_est_info(fs[1], fe->info);
+    }
+    ef_est_free(fe);
+    if (aligned) break;
+  }
+  for (int k = 0; k < 6; ++k) fclose(fs[k]);
+  f->state = F_DONE;
+  swapcontext(&f->ctx, &f->w->sched);
+}
+
+/* ---- worker side --------------------------------------------------------------------------------- */
+static bool start_fiber(worker* w) {
+  shared* sh = w->sh;
+  pthread_mutex_lock(&sh->mu);
+  const size_t u = sh->next_unit < sh->n_units ? sh->next_unit++ : (size_t)-1;
+  pthread_mutex_unlock(&sh->mu);
+  if (u == (size_t)-1) return false;
+  fiber* f = (fiber*)calloc(1, sizeof(fiber));
+  f->stack = (char*)malloc(sh->stack_size);
+  f->w = w; f->unit = u; f->state = F_RUNNABLE;
+  f->be.self = f; f->be.pairings = fiber_pairings; f->be.dp = fiber_dp;
+  getcontext(&f->ctx);
+  f->ctx.uc_stack.ss_sp = f->stack; f->ctx.uc_stack.ss_size = sh->stack_size; f->ctx.uc_link = &w->sched;
+  const uintptr_t p = (uintptr_t)f;
+  makecontext(&f->ctx, (void (*)(void))fiber_main, 2, (unsigned)(p >> 32), (unsigned)(p & 0xffffffffu));
+  w->fibers[w->n_fibers++] = f;
+  return true;
+}
+
+static int submit_pairings(worker* w) {
+  /* group the waiting fibres by (L, rate): a retry with a longer min_factor_len runs separately */
+  fiber** wait = (fiber**)malloc(w->n_fibers * sizeof(fiber*));
+  size_t nw = 0;
+  for (size_t i = 0; i < w->n_fibers; ++i) if (w->fibers[i]->state == F_WAIT_PAIR) wait[nw++] = w->fibers[i];
+  int rc = 0;
+  while (nw > 0 && rc == 0) {
+    const unsigned L = wait[0]->pat_L; const double rate = wait[0]->pat_rate;
+    size_t ng = 0, total = 0;
+    for (size_t i = 0; i < nw; ++i) if (wait[i]->pat_L == L && wait[i]->pat_rate == rate) { ++ng; total += wait[i]->pat_len; }
+    char* blob = (char*)malloc(total + 1);
+    uint64_t* off = (uint64_t*)malloc((ng + 1) * sizeof(uint64_t));
+    fiber** grp = (fiber**)malloc(ng * sizeof(fiber*));
+    size_t g = 0, pos = 0, rest = 0;
+    for (size_t i = 0; i < nw; ++i) {
+      fiber* f = wait[i];
+      if (f->pat_L == L && f->pat_rate == rate) { off[g] = pos; memcpy(blob + pos, f->pat, f->pat_len); pos += f->pat_len; grp[g++] = f; }
+      else wait[rest++] = f;
+    }
+    off[ng] = pos;
+    pgpu_pairing_plan* plan = NULL;
+    pgpu_pairing_params prm = { L, 0, rate };
+    rc = pgpu_pairing_plan_create(w->ctx, w->sh->idx, blob, off, ng, &plan);
+    if (rc == PGPU_OK) rc = pgpu_pairing_plan_run(w->ctx, plan, &prm);
+    if (rc == PGPU_OK) {
+      const size_t cnt = (size_t)pgpu_pairing_plan_count(plan);
+      pgpu_pairing* out = (pgpu_pairing*)malloc((cnt + 1) * sizeof(pgpu_pairing));
+      uint64_t* first = (uint64_t*)malloc((ng + 1) * sizeof(uint64_t));
+      rc = pgpu_pairing_plan_fetch(w->ctx, plan, out, cnt, first);
+      if (rc == PGPU_OK) {
+        for (size_t i = 0; i < ng; ++i) {
+          const size_t n = (size_t)(first[i + 1] - first[i]);
+          ef_triple* t = (ef_triple*)malloc((n + 1) * sizeof(ef_triple));
+          memcpy(t, out + first[i], n * sizeof(ef_triple));
+          *grp[i]->pat_out = t; *grp[i]->pat_n = n;
+          grp[i]->rc = 0; grp[i]->state = F_RUNNABLE;
+        }
+        w->stats.pairing_batches++; w->stats.pairing_requests += ng;
+      }
+      free(out); free(first);
+    }
+    if (plan) pgpu_pairing_plan_destroy(w->ctx, plan);
+    if (rc != PGPU_OK) fprintf(stderr, "* FATAL pairing batch failed: %s\n", pgpu_last_error(w->ctx));
+    free(blob); free(off); free(grp);
+    nw = rest;
+  }
+  free(wait);
+  return rc;
+}
+
+static int submit_dp(worker* w) {
+  shared* sh = w->sh;
+  const char* gen = sh->in->gen->seq;
+  const size_t gen_len = strlen(gen);
+  ef_jobbuf_reset(&w->jb);
+  fiber** wait = (fiber**)malloc(w->n_fibers * sizeof(fiber*));
+  size_t nw = 0;
+  for (size_t i = 0; i < w->n_fibers; ++i) {
+    fiber* f = w->fibers[i];
+    if (f->state != F_WAIT_DP) continue;
+    ef_jobbuf_add(&w->jb, &f->req, gen, gen_len);
+    wait[nw++] = f;
+  }
+  if (nw == 0) { free(wait); return 0; }
+  if (nw > w->results_cap) { w->results_cap = nw * 2; w->results = (pgpu_dp_result*)realloc(w->results, w->results_cap * sizeof(pgpu_dp_result)); }
+  pgpu_dp_plan* plan = NULL;
+  int rc = pgpu_dp_plan_create(w->ctx, sh->idx, w->jb.jobs, nw, w->jb.arena, w->jb.arena_len, &plan);
+  if (rc == PGPU_OK) rc = pgpu_dp_plan_launch(w->ctx, plan);
+  if (rc == PGPU_OK) rc = pgpu_dp_plan_sync(w->ctx, plan);
+  if (rc == PGPU_OK) {
+    const size_t sb = pgpu_dp_plan_string_bytes(plan);
+    if (sb + 16 > w->strings_cap) { w->strings_cap = (sb + 16) * 2; w->strings = (char*)realloc(w->strings, w->strings_cap); }
+    rc = pgpu_dp_plan_fetch(w->ctx, plan, w->results, w->strings, w->strings_cap);
+  }
+  if (plan) pgpu_dp_plan_destroy(w->ctx, plan);
+  if (rc != PGPU_OK) { fprintf(stderr, "* FATAL DP batch failed: %s\n", pgpu_last_error(w->ctx)); free(wait); return rc; }
+  for (size_t i = 0; i < nw; ++i) {
+    fiber* f = wait[i];
+    f->rc = ef_decode_result(f->req.kind, &w->results[i], w->strings, f->res);
+    if (f->rc != 0) fprintf(stderr, "* FATAL DP job of kind %d (%zu x %zu) exceeds the device limits\n", f->req.kind, f->req.la, f->req.lb);
+    f->state = F_RUNNABLE;
+  }
+  w->stats.dp_batches++; w->stats.dp_jobs += nw;
+  free(wait);
+  return 0;
+}
+
+static void* worker_main(void* arg) {
+  worker* w = (worker*)arg;
+  shared* sh = w->sh;
+  if (pgpu_init(ef_gpu_device_from_env(), &w->ctx) != PGPU_OK) { sh->failed = 1; return NULL; }
+  w->fibers = (fiber**)malloc(sh->max_fibers * sizeof(fiber*));
+  ef_jobbuf_init(&w->jb);
+  bool more = true;
+  while (!sh->failed) {
+    while (more && w->n_fibers < sh->max_fibers) more = start_fiber(w);
+    if (w->n_fibers == 0) break;
+    /* run every runnable fibre until it blocks or ends */
+    for (size_t i = 0; i < w->n_fibers; ++i) {
+      fiber* f = w->fibers[i];
+      if (f->state == F_RUNNABLE) swapcontext(&w->sched, &f->ctx);
+    }
+    /* retire finished fibres */
+    size_t keep = 0;
+    for (size_t i = 0; i < w->n_fibers; ++i) {
+      fiber* f = w->fibers[i];
+      if (f->state == F_DONE) { free(f->stack); free(f); w->stats.units++; }
+      else w->fibers[keep++] = f;
+    }
+    w->n_fibers = keep;
+    if (submit_pairings(w) != 0 || submit_dp(w) != 0) { sh->failed = 1; break; }
+  }
+  ef_jobbuf_free(&w->jb);
+  free(w->strings); free(w->results); free(w->fibers);
+  pgpu_destroy(w->ctx);
+  return NULL;
+}
+
+static size_t env_size(const char* name, size_t dflt) {
+  const char* v = getenv(name);
+  return (v && atol(v) > 0) ? (size_t)atol(v) : dflt;
+}
+
+int ef_run_batched_stats(int argc, char** argv, ef_sched_stats* stats_out) {
+  ef_inputs in;
+  int rc = ef_load_inputs(argc, argv, &in);
+  if (rc) return rc;
+  ef_outputs out;
+  if (ef_open_outputs(&out)) return 1;
+  ef_classify_init();
+  pgpu_ctx* ctx0 = NULL;
+  if (pgpu_init(ef_gpu_device_from_env(), &ctx0) != PGPU_OK) {
+    fprintf(stderr, "* FATAL no usable MI355X (gfx950) device / libpintron_gpu.so: est-fact has no CPU fallback\n");
+    return 1;
+  }
+  shared sh;
+  memset(&sh, 0, sizeof sh);
+  sh.in = &in;
+  if (pgpu_index_build(ctx0, in.gen->seq, strlen(in.gen->seq), &sh.idx) != PGPU_OK) {
+    fprintf(stderr, "* FATAL pgpu_index_build: %s\n", pgpu_last_error(ctx0));
+    return 1;
+  }
+  /* units: forward entry (+ sibling) */
+  sh.units = (unit*)calloc(in.n + 1, sizeof(unit));
+  for (size_t k = 0; k < in.n;) {
+    unit* u = &sh.units[sh.n_units++];
+    u->first = k;
+    u->has_sibling = !in.list[k]->fixed_strand;
+    k += u->has_sibling ? 2 : 1;
+  }
+  pthread_mutex_init(&sh.mu, NULL);
+  const long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
+  size_t nthreads = env_size("PINTRON_THREADS", ncpu > 0 ? (size_t)ncpu : 1);
+  if (nthreads > sh.n_units) nthreads = sh.n_units ? sh.n_units : 1;
+  sh.max_fibers = env_size("PINTRON_FIBERS", 2048);
+  sh.stack_size = env_size("PINTRON_FIBER_STACK_KB", 256) * 1024;
+  worker* ws = (worker*)calloc(nthreads, sizeof(worker));
+  pthread_t* th = (pthread_t*)malloc(nthreads * sizeof(pthread_t));
+  for (size_t t = 0; t < nthreads; ++t) { ws[t].sh = &sh; pthread_create(&th[t], NULL, worker_main, &ws[t]); }
+  for (size_t t = 0; t < nthreads; ++t) pthread_join(th[t], NULL);
+  ef_sched_stats st;
+  memset(&st, 0, sizeof st);
+  st.threads = nthreads;
+  for (size_t t = 0; t < nthreads; ++t) {
+    st.units += ws[t].stats.units; st.dp_batches += ws[t].stats.dp_batches; st.dp_jobs += ws[t].stats.dp_jobs;
+    st.pairing_batches += ws[t].stats.pairing_batches; st.pairing_requests += ws[t].stats.pairing_requests;
+  }
+  if (stats_out) *stats_out = st;
+  rc = sh.failed ? 1 : 0;
+  if (!rc) {
+    FILE* dst[6] = { out.fout, out.fests, out.side.fmeg, out.side.fpmeg, out.side.ftmeg, out.side.fintronic };
+    for (size_t u = 0; u < sh.n_units; ++u)
+      for (int k = 0; k < 6; ++k) {
+        if (sh.units[u].len[k]) fwrite(sh.units[u].buf[k], 1, sh.units[u].len[k], dst[k]);
+        free(sh.units[u].buf[k]);
+      }
+  }
+  free(ws); free(th); free(sh.units);
+  pgpu_index_destroy(ctx0, sh.idx);
+  pgpu_destroy(ctx0);
+  ef_close_outputs(&out);
+  ef_free_inputs(&in);
+  return rc;
+}
+
+int ef_run_batched(int argc, char** argv) {
+  ef_sched_stats st;
+  const int rc = ef_run_batched_stats(argc, argv, &st);
+  if (rc == 0 && getenv("PINTRON_VERBOSE"))
+    fprintf(stderr, "est-fact: %zu ESTs, %zu threads, %zu pairing batches (%zu requests), %zu DP batches (%zu jobs)\n",
+            st.units, st.threads, st.pairing_batches, st.pairing_requests, st.dp_batches, st.dp_jobs);
+  return rc;
+}

@@ -182,6 +182,14 @@ ef_meg* ef_build_meg(const ef_seq* est, ef_backend* be, const ef_config* shared_
 
 void ef_write_single_est_info(FILE* f, const ef_seq* s);              /* src/io-multifasta.c:270 */
 
+typedef struct { ef_config cfg; ef_seq* gen; ef_seq** list; size_t n; } ef_inputs;
+typedef struct { FILE *flog, *fout, *fests; ef_side_files side; } ef_outputs;
+int ef_load_inputs(int argc, char** argv, ef_inputs* in);
+void ef_free_inputs(ef_inputs* in);
+int ef_open_outputs(ef_outputs* o);
+void ef_close_outputs(ef_outputs* o);
+void ef_classify_init(void);     /* loads the PWM tables once (call before threads start) */
+
 /* the whole est-fact process (src/main-est-fact.c:90-339); the caller supplies the backend */
 int ef_run(int argc, char** argv, ef_backend* (*open_backend)(const ef_seq* gen), void (*close_backend)(ef_backend*));
 

@@ -1,0 +1,116 @@
+/* TEST INFRASTRUCTURE (tests/): a CPU stand-in for the part of the C-ABI (include/pintron_gpu.h)
+ * that the est-fact host program calls, implemented with the ORACLE.  It exists so that the host
+ * program's batching/fibre scheduler -- which is ordinary host code -- can be exercised in a
+ * container without a GPU (tests/test_host_estfact.py).  It is linked ONLY into
+ * tests/hostcheck/estfact_sched_check; the product links libpintron_gpu.so and nothing else. */
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/pintron_gpu.h"
+#include "../../oracle/dp_oracle.h"
+#include "../../oracle/pairing_oracle.h"
+
+uint64_t orc_dp_batch(const pgpu_dp_job* jobs, size_t n, const char* arena, const char* genomic,
+                      pgpu_dp_result* results, char* strings, size_t strings_cap, size_t* strings_used);
+
+struct pgpu_ctx { char err[64]; };
+struct pgpu_index { orc_index* ix; char* gen; size_t len; };
+struct pgpu_dp_plan { pgpu_dp_job* jobs; size_t n; char* arena; const pgpu_index* idx; pgpu_dp_result* res; char* strs; size_t strs_bytes; };
+struct pgpu_pairing_plan { const pgpu_index* idx; char* pats; uint64_t* off; size_t n; int32_t* out; uint64_t* first; size_t cnt; };
+
+int pgpu_init(int device, pgpu_ctx** ctx) { (void)device; *ctx = (pgpu_ctx*)calloc(1, sizeof(pgpu_ctx)); return PGPU_OK; }
+int pgpu_destroy(pgpu_ctx* ctx) { free(ctx); return PGPU_OK; }
+const char* pgpu_last_error(const pgpu_ctx* ctx) { (void)ctx; return "fake"; }
+int pgpu_index_build(pgpu_ctx* ctx, const char* g, size_t len, pgpu_index** idx) {
+  (void)ctx;
+  pgpu_index* x = (pgpu_index*)calloc(1, sizeof(*x));
+  x->gen = (char*)calloc(len + 8, 1); memcpy(x->gen, g, len); x->len = len;
+  x->ix = orc_index_create(g, len);
+  *idx = x; return PGPU_OK;
+}
+int pgpu_index_destroy(pgpu_ctx* ctx, pgpu_index* idx) { (void)ctx; orc_index_destroy(idx->ix); free(idx->gen); free(idx); return PGPU_OK; }
+
+int pgpu_pairing_plan_create(pgpu_ctx* ctx, const pgpu_index* idx, const char* patterns, const uint64_t* off, size_t n, pgpu_pairing_plan** out) {
+  (void)ctx;
+  pgpu_pairing_plan* p = (pgpu_pairing_plan*)calloc(1, sizeof(*p));
+  p->idx = idx; p->n = n;
+  p->pats = (char*)malloc(off[n] + 1); memcpy(p->pats, patterns, off[n]);
+  p->off = (uint64_t*)malloc((n + 1) * sizeof(uint64_t)); memcpy(p->off, off, (n + 1) * sizeof(uint64_t));
+  *out = p; return PGPU_OK;
+}
+int pgpu_pairing_plan_run(pgpu_ctx* ctx, pgpu_pairing_plan* p, const pgpu_pairing_params* prm) {
+  (void)ctx;
+  free(p->out); free(p->first);
+  size_t cap = 1 << 16;
+  p->out = (int32_t*)malloc(3 * cap * sizeof(int32_t));
+  p->first = (uint64_t*)malloc((p->n + 1) * sizeof(uint64_t));
+  size_t tot = 0;
+  for (size_t i = 0; i < p->n; ++i) {
+    p->first[i] = tot;
+    const size_t m = (size_t)(p->off[i + 1] - p->off[i]);
+    char* pat = (char*)malloc(m + 1); memcpy(pat, p->pats + p->off[i], m); pat[m] = '\0';
+    long c = orc_pairings(p->idx->ix, pat, m, prm->min_factor_len, prm->min_string_depth_rate, p->out + 3 * tot, (long)(cap - tot), NULL);
+    if ((size_t)c > cap - tot) {
+      cap = (tot + (size_t)c) * 2; p->out = (int32_t*)realloc(p->out, 3 * cap * sizeof(int32_t));
+      c = orc_pairings(p->idx->ix, pat, m, prm->min_factor_len, prm->min_string_depth_rate, p->out + 3 * tot, (long)(cap - tot), NULL);
+    }
+    free(pat);
+    tot += (size_t)c;
+  }
+  p->first[p->n] = tot; p->cnt = tot;
+  return PGPU_OK;
+}
+uint64_t pgpu_pairing_plan_count(const pgpu_pairing_plan* p) { return p->cnt; }
+int pgpu_pairing_plan_fetch(pgpu_ctx* ctx, pgpu_pairing_plan* p, pgpu_pairing* out, size_t cap, uint64_t* first) {
+  (void)ctx;
+  if (cap < p->cnt) return PGPU_ENOSPC;
+  memcpy(out, p->out, p->cnt * sizeof(pgpu_pairing));
+  memcpy(first, p->first, (p->n + 1) * sizeof(uint64_t));
+  return PGPU_OK;
+}
+int pgpu_pairing_plan_destroy(pgpu_ctx* ctx, pgpu_pairing_plan* p) { (void)ctx; free(p->pats); free(p->off); free(p->out); free(p->first); free(p); return PGPU_OK; }
+int pgpu_pairings(pgpu_ctx* ctx, const pgpu_index* idx, const char* patterns, const uint64_t* off, size_t n, const pgpu_pairing_params* prm,
+                  pgpu_pairing* out, size_t cap, uint64_t* first, size_t* n_out) {
+  pgpu_pairing_plan* p; pgpu_pairing_plan_create(ctx, idx, patterns, off, n, &p);
+  pgpu_pairing_plan_run(ctx, p, prm);
+  if (n_out) *n_out = p->cnt;
+  const int rc = pgpu_pairing_plan_fetch(ctx, p, out, cap, first);
+  pgpu_pairing_plan_destroy(ctx, p);
+  return rc;
+}
+
+int pgpu_dp_plan_create(pgpu_ctx* ctx, const pgpu_index* idx, const pgpu_dp_job* jobs, size_t n, const char* arena, size_t alen, pgpu_dp_plan** out) {
+  (void)ctx;
+  pgpu_dp_plan* p = (pgpu_dp_plan*)calloc(1, sizeof(*p));
+  p->jobs = (pgpu_dp_job*)malloc((n + 1) * sizeof(pgpu_dp_job)); memcpy(p->jobs, jobs, n * sizeof(pgpu_dp_job));
+  p->n = n; p->arena = (char*)calloc(alen + 8, 1); memcpy(p->arena, arena, alen); p->idx = idx;
+  for (size_t i = 0; i < n; ++i) if (jobs[i].kind <= PGPU_DP_GAP) p->strs_bytes += 2 * ((size_t)jobs[i].a_len + jobs[i].b_len + 1);
+  *out = p; return PGPU_OK;
+}
+int pgpu_dp_plan_launch(pgpu_ctx* ctx, pgpu_dp_plan* p) {
+  (void)ctx;
+  p->res = (pgpu_dp_result*)malloc((p->n + 1) * sizeof(pgpu_dp_result));
+  p->strs = (char*)malloc(p->strs_bytes + 16);
+  size_t used;
+  orc_dp_batch(p->jobs, p->n, p->arena, p->idx ? p->idx->gen : NULL, p->res, p->strs, p->strs_bytes + 16, &used);
+  return PGPU_OK;
+}
+int pgpu_dp_plan_sync(pgpu_ctx* ctx, pgpu_dp_plan* p) { (void)ctx; (void)p; return PGPU_OK; }
+size_t pgpu_dp_plan_string_bytes(const pgpu_dp_plan* p) { return p->strs_bytes; }
+int pgpu_dp_plan_fetch(pgpu_ctx* ctx, pgpu_dp_plan* p, pgpu_dp_result* res, char* strings, size_t cap) {
+  (void)ctx;
+  if (cap < p->strs_bytes) return PGPU_ENOSPC;
+  memcpy(res, p->res, p->n * sizeof(pgpu_dp_result));
+  if (p->strs_bytes) memcpy(strings, p->strs, p->strs_bytes);
+  return PGPU_OK;
+}
+int pgpu_dp_plan_destroy(pgpu_ctx* ctx, pgpu_dp_plan* p) { (void)ctx; free(p->jobs); free(p->arena); free(p->res); free(p->strs); free(p); return PGPU_OK; }
+int pgpu_dp_batch(pgpu_ctx* ctx, const pgpu_index* idx, const pgpu_dp_job* jobs, size_t n, const char* arena, size_t alen,
+                  pgpu_dp_result* res, char* strings, size_t cap, size_t* used) {
+  pgpu_dp_plan* p; pgpu_dp_plan_create(ctx, idx, jobs, n, arena, alen, &p);
+  pgpu_dp_plan_launch(ctx, p);
+  if (used) *used = p->strs_bytes;
+  const int rc = pgpu_dp_plan_fetch(ctx, p, res, strings, cap);
+  pgpu_dp_plan_destroy(ctx, p);
+  return rc;
+}

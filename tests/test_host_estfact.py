@@ -1,0 +1,69 @@
+"""CPU: the complete est-fact host program (pintron_amd/host/) against the reference's outputs.
+
+Two check builds (tests/hostcheck/Makefile), both with the CPU oracle where the product has the GPU:
+  estfact_check        one EST after the other, oracle as the backend
+  estfact_sched_check  the product's own main + fibre scheduler + GPU backend code, linked against
+                       a CPU stand-in of the C-ABI (fake_pgpu.c), 1 and 4 threads
+Goldens: tests/golden/ambn/expected-* (reference est-fact on regressionTest/test-AMBN); on a
+seeded synthetic C2-shaped sample the compiled reference (oracle/_ref) is run side by side."""
+import filecmp
+import os
+import shutil
+import subprocess
+
+import pytest
+
+import oracle_lib as O
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden", "ambn")
+FILES = ["raw-multifasta-out.txt", "processed-ests.txt", "megs.txt", "processed-megs.txt", "meg-edges.txt"]
+
+
+@pytest.fixture(scope="module")
+def bins():
+    subprocess.run(["make", "-s", "-C", os.path.join(HERE, "hostcheck"), "all"], check=True)
+    return {n: os.path.join(HERE, "hostcheck", n) for n in ("estfact_check", "estfact_sched_check")}
+
+
+def run(exe, cwd, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    subprocess.run([exe], cwd=cwd, env=e, check=True, stderr=subprocess.DEVNULL)
+
+
+@pytest.mark.parametrize("which,env", [("estfact_check", {}),
+                                       ("estfact_sched_check", {"PINTRON_THREADS": "1"}),
+                                       ("estfact_sched_check", {"PINTRON_THREADS": "4", "PINTRON_FIBERS": "7"}),
+                                       ("estfact_sched_check", {"PINTRON_ESTFACT_MODE": "direct"})])
+def test_ambn_outputs_match_reference(bins, tmp_path, which, env):
+    for f in ("genomic.txt", "ests.txt"):
+        shutil.copy(os.path.join(GOLD, f), tmp_path)
+    run(bins[which], tmp_path, env)
+    for f in FILES:
+        assert filecmp.cmp(os.path.join(tmp_path, f), os.path.join(GOLD, "expected-" + f), shallow=False), f
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
+def test_synthetic_sample_matches_compiled_reference(bins, tmp_path):
+    from pintron_amd import synth
+    w = synth.make("C2", n_est=300)
+    ref_dir, my_dir = tmp_path / "ref", tmp_path / "mine"
+    for d in (ref_dir, my_dir):
+        synth.write_files(w, str(d))
+    subprocess.run([os.path.join(O.REF_DIR, "est-fact-ref")], cwd=ref_dir, check=True, stderr=subprocess.DEVNULL)
+    run(bins["estfact_sched_check"], my_dir, {"PINTRON_THREADS": "3"})
+    for f in FILES:
+        assert filecmp.cmp(my_dir / f, ref_dir / f, shallow=False), f
+    assert os.path.getsize(my_dir / "raw-multifasta-out.txt") > 10000
+
+
+def test_cli_options_and_config_dump(bins, tmp_path):
+    for f in ("genomic.txt", "ests.txt"):
+        shutil.copy(os.path.join(GOLD, f), tmp_path)
+    subprocess.run([bins["estfact_check"], "-l", "18", "--min-intron-length=60", "--retain-externals", "false"],
+                   cwd=tmp_path, check=True, stderr=subprocess.DEVNULL)
+    dump = open(os.path.join(tmp_path, "config-dump.ini")).read()
+    assert 'min-factor-length="18"' in dump and 'min-intron-length="60"' in dump and 'retain-externals="false"' in dump
+    bad = subprocess.run([bins["estfact_check"], "--min-string-depth-rate", "1.5"], cwd=tmp_path, stderr=subprocess.DEVNULL)
+    assert bad.returncode != 0
