@@ -41,6 +41,9 @@ int pgpu_destroy(pgpu_ctx* ctx);
 const char* pgpu_last_error(const pgpu_ctx* ctx);
 /* ABI version of the loaded library */
 int pgpu_abi_version(void);
+/* HIP-event timing of every kernel group of the plans created afterwards (off by default; the
+ * measurement hooks below return 0 without it) */
+int pgpu_set_timing(pgpu_ctx* ctx, int enabled);
 
 /* ------------------------------------------------------------------------------------------ */
 /* genomic index -- replaces lst_stree_new (stree_src/lst_stree.c:816) + preprocess_text /     */

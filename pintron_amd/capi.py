@@ -42,7 +42,7 @@ assert C.sizeof(DpJob) == 48 and C.sizeof(DpResult) == 48
 
 # every symbol include/pintron_gpu.h declares
 EXPORTS = [
-    "pgpu_init", "pgpu_destroy", "pgpu_last_error", "pgpu_abi_version",
+    "pgpu_init", "pgpu_destroy", "pgpu_last_error", "pgpu_abi_version", "pgpu_set_timing",
     "pgpu_index_build", "pgpu_index_destroy", "pgpu_index_suffix_array", "pgpu_pairings",
     "pgpu_pairing_plan_create", "pgpu_pairing_plan_run", "pgpu_pairing_plan_count",
     "pgpu_pairing_plan_positions", "pgpu_pairing_plan_kernel_ms", "pgpu_pairing_plan_fetch",
@@ -74,6 +74,7 @@ def lib():
         vp, u64, sz = C.c_void_p, C.c_uint64, C.c_size_t
         L.pgpu_init.argtypes = [C.c_int, C.POINTER(vp)]
         L.pgpu_destroy.argtypes = [vp]
+        L.pgpu_set_timing.argtypes = [vp, C.c_int]
         L.pgpu_last_error.argtypes = [vp]
         L.pgpu_last_error.restype = C.c_char_p
         L.pgpu_index_build.argtypes = [vp, C.c_char_p, sz, C.POINTER(vp)]
@@ -123,6 +124,7 @@ class Context:
         rc = self.L.pgpu_init(device, C.byref(self.h))
         if rc != PGPU_OK:
             raise PgpuError(rc, "pgpu_init(%d) failed (no usable gfx950 device?)" % device)
+        self.L.pgpu_set_timing(self.h, 1)      # tests and bench read the per-kernel timings
 
     def check(self, rc):
         if rc != PGPU_OK:

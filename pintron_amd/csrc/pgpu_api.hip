@@ -12,11 +12,52 @@
 #include "pgpu_internal.h"
 #include "pgpu_index.h"
 
+// Device scratch that outlives a plan: the batched host program creates and destroys a plan per
+// round, and hipMalloc/hipFree (the latter synchronises the device) would dominate.  A context
+// keeps one grow-only set of buffers per plan type; a plan borrows the set when it is free.
+struct BufPool {
+  static constexpr int SLOTS = 24;
+  void* ptr[SLOTS] = {nullptr};
+  size_t cap[SLOTS] = {0};
+  bool busy = false;
+};
+
 struct pgpu_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   char err[512] = {0};
+  BufPool pools[2];          // 0: DP plans, 1: pairing plans
+  bool timing = false;       // HIP events around every kernel group (bench / profiling)
 };
+
+bool pgpu_ctx_pool_acquire(pgpu_ctx* ctx, int pool) {
+  if (ctx->pools[pool].busy) return false;
+  ctx->pools[pool].busy = true;
+  return true;
+}
+void pgpu_ctx_pool_release(pgpu_ctx* ctx, int pool) { ctx->pools[pool].busy = false; }
+// returns a buffer of at least `bytes` from the (acquired) pool, growing it when needed
+void* pgpu_ctx_pool_get(pgpu_ctx* ctx, int pool, int slot, size_t bytes) {
+  BufPool& p = ctx->pools[pool];
+  if (bytes == 0) bytes = 16;
+  if (p.cap[slot] < bytes) {
+    if (p.ptr[slot]) (void)hipFree(p.ptr[slot]);
+    p.ptr[slot] = nullptr; p.cap[slot] = 0;
+    const size_t want = bytes + bytes / 2 + 4096;
+    if (hipMalloc(&p.ptr[slot], want) != hipSuccess) {
+      if (hipMalloc(&p.ptr[slot], bytes) != hipSuccess) return nullptr;
+      p.cap[slot] = bytes;
+    } else p.cap[slot] = want;
+  }
+  return p.ptr[slot];
+}
+bool pgpu_ctx_timing(const pgpu_ctx* ctx) { return ctx->timing; }
+
+extern "C" int pgpu_set_timing(pgpu_ctx* ctx, int enabled) {
+  if (!ctx) return PGPU_EINVAL;
+  ctx->timing = enabled != 0;
+  return PGPU_OK;
+}
 
 static int set_err(pgpu_ctx* ctx, int code, const char* fmt, ...) {
   if (ctx) {
@@ -66,6 +107,7 @@ extern "C" int pgpu_destroy(pgpu_ctx* ctx) {
   if (!ctx) return PGPU_EINVAL;
   hipSetDevice(ctx->device);
   hipStreamSynchronize(ctx->stream);
+  for (auto& pl : ctx->pools) for (auto& q : pl.ptr) if (q) hipFree(q);
   hipStreamDestroy(ctx->stream);
   delete ctx;
   return PGPU_OK;
@@ -114,6 +156,9 @@ struct pgpu_dp_plan {
   double ms[PGPU_DP_NKINDS] = {0};
   uint64_t launches[PGPU_DP_NKINDS] = {0};
   bool launched = false;
+  bool pooled = false;                      // device buffers borrowed from the context's pool
+  pgpu_ctx* owner = nullptr;
+  std::vector<DevJob> host_jobs;            // kept alive until the uploads have been consumed
 };
 
 static void plan_free(pgpu_dp_plan* p) {
@@ -122,8 +167,11 @@ static void plan_free(pgpu_dp_plan* p) {
     if (g.ev0) hipEventDestroy(g.ev0);
     if (g.ev1) hipEventDestroy(g.ev1);
   }
-  hipFree(p->d_jobs); hipFree(p->d_results); hipFree(p->d_arena);
-  hipFree(p->d_ws); hipFree(p->d_strs); hipFree(p->d_keys);
+  if (p->pooled) pgpu_ctx_pool_release(p->owner, 0);
+  else {
+    hipFree(p->d_jobs); hipFree(p->d_results); hipFree(p->d_arena);
+    hipFree(p->d_ws); hipFree(p->d_strs); hipFree(p->d_keys);
+  }
   delete p;
 }
 
@@ -144,7 +192,15 @@ extern "C" int pgpu_dp_plan_create(pgpu_ctx* ctx, const pgpu_index* idx, const p
 
   // operands live in one HBM arena; resolve every job to device pointers once the arena exists
   const size_t arena_alloc = arena_len + 16;
-  if (hipMalloc(&p->d_arena, arena_alloc) != hipSuccess) { plan_free(p); return set_err(ctx, PGPU_ENOMEM, "hipMalloc arena (%zu B)", arena_alloc); }
+  p->owner = ctx;
+  p->pooled = pgpu_ctx_pool_acquire(ctx, 0);
+  auto dev_alloc = [&](int slot, size_t bytes) -> void* {
+    if (p->pooled) return pgpu_ctx_pool_get(ctx, 0, slot, bytes);
+    void* q = nullptr;
+    return hipMalloc(&q, bytes ? bytes : 16) == hipSuccess ? q : nullptr;
+  };
+  p->d_arena = (uint8_t*)dev_alloc(0, arena_alloc);
+  if (!p->d_arena) { plan_free(p); return set_err(ctx, PGPU_ENOMEM, "hipMalloc arena (%zu B)", arena_alloc); }
 
   struct Keyed { DevJob j; int family; int kind; uint32_t R; uint64_t size; };
   std::vector<Keyed> v;
@@ -278,7 +334,7 @@ extern "C" int pgpu_dp_plan_create(pgpu_ctx* ctx, const pgpu_index* idx, const p
   for (auto& g : p->groups) {
     p->cells[g.kind] += g.cells;
     p->algo_bytes[g.kind] += g.algo_bytes;
-    if (hipEventCreate(&g.ev0) != hipSuccess || hipEventCreate(&g.ev1) != hipSuccess) {
+    if (ctx->timing && (hipEventCreate(&g.ev0) != hipSuccess || hipEventCreate(&g.ev1) != hipSuccess)) {
       plan_free(p);
       return set_err(ctx, PGPU_EDEVICE, "hipEventCreate failed");
     }
@@ -290,13 +346,14 @@ extern "C" int pgpu_dp_plan_create(pgpu_ctx* ctx, const pgpu_index* idx, const p
     return set_err(ctx, PGPU_ENOMEM, "hipMalloc %s (%zu B) failed", what, bytes);
   };
   const size_t nd = std::max<size_t>(v.size(), 1);
-  if (hipMalloc(&p->d_jobs, nd * sizeof(DevJob)) != hipSuccess) return fail_mem("jobs", nd * sizeof(DevJob));
-  if (hipMalloc(&p->d_results, std::max<size_t>(n_jobs, 1) * sizeof(DevResult)) != hipSuccess) return fail_mem("results", n_jobs * sizeof(DevResult));
-  if (hipMalloc(&p->d_ws, ws + 16) != hipSuccess) return fail_mem("workspace", ws);
-  if (hipMalloc(&p->d_strs, strs + 16) != hipSuccess) return fail_mem("strings", strs);
-  if (hipMalloc(&p->d_keys, (nkeys + 1) * sizeof(unsigned long long)) != hipSuccess) return fail_mem("lcf keys", nkeys * 8);
+  if (!(p->d_jobs = (DevJob*)dev_alloc(1, nd * sizeof(DevJob)))) return fail_mem("jobs", nd * sizeof(DevJob));
+  if (!(p->d_results = (DevResult*)dev_alloc(2, std::max<size_t>(n_jobs, 1) * sizeof(DevResult)))) return fail_mem("results", n_jobs * sizeof(DevResult));
+  if (!(p->d_ws = (uint8_t*)dev_alloc(3, ws + 16))) return fail_mem("workspace", ws);
+  if (!(p->d_strs = (uint8_t*)dev_alloc(4, strs + 16))) return fail_mem("strings", strs);
+  if (!(p->d_keys = (unsigned long long*)dev_alloc(5, (nkeys + 1) * sizeof(unsigned long long)))) return fail_mem("lcf keys", nkeys * 8);
 
-  std::vector<DevJob> hj(v.size());
+  std::vector<DevJob>& hj = p->host_jobs;
+  hj.resize(v.size());
   for (size_t q = 0; q < v.size(); ++q) hj[q] = v[q].j;
   hipError_t e = hipSuccess;
   if (arena_len) e = hipMemcpyAsync(p->d_arena, arena, arena_len, hipMemcpyHostToDevice, ctx->stream);
@@ -304,7 +361,7 @@ extern "C" int pgpu_dp_plan_create(pgpu_ctx* ctx, const pgpu_index* idx, const p
     e = hipMemcpyAsync(p->d_jobs, hj.data(), hj.size() * sizeof(DevJob), hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess && n_jobs)
     e = hipMemcpyAsync(p->d_results, p->prefill.data(), n_jobs * sizeof(DevResult), hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);     // hj / prefill are host temporaries
+  // (host_jobs and prefill stay alive in the plan; the caller's arrays were staged by the copies)
   if (e != hipSuccess) { plan_free(p); return set_err(ctx, PGPU_EDEVICE, "upload failed: %s", hipGetErrorString(e)); }
   *out = p;
   return PGPU_OK;
@@ -319,7 +376,7 @@ extern "C" int pgpu_dp_plan_launch(pgpu_ctx* ctx, pgpu_dp_plan* p) {
   for (auto& g : p->groups) {
     const DevJob* jobs = p->d_jobs + g.first;
     const int n = (int)g.count;
-    HIP_TRY(ctx, hipEventRecord(g.ev0, st));
+    if (g.ev0) HIP_TRY(ctx, hipEventRecord(g.ev0, st));
     if (g.traceback) {
       if (g.family == KF_ALIGN) launch_align_traceback(jobs, n, p->d_results, p->d_ws, p->d_strs, st);
       else launch_gap_traceback(jobs, n, p->d_results, p->d_ws, p->d_strs, st);
@@ -337,7 +394,7 @@ extern "C" int pgpu_dp_plan_launch(pgpu_ctx* ctx, pgpu_dp_plan* p) {
         key_base += g.count; break;
       default: break;
     }
-    HIP_TRY(ctx, hipEventRecord(g.ev1, st));
+    if (g.ev1) HIP_TRY(ctx, hipEventRecord(g.ev1, st));
     HIP_TRY(ctx, hipGetLastError());
   }
   p->launched = true;
@@ -351,7 +408,7 @@ extern "C" int pgpu_dp_plan_sync(pgpu_ctx* ctx, pgpu_dp_plan* p) {
     for (int k = 0; k < PGPU_DP_NKINDS; ++k) { p->ms[k] = 0; p->launches[k] = 0; }
     for (auto& g : p->groups) {
       float ms = 0.f;
-      if (hipEventElapsedTime(&ms, g.ev0, g.ev1) == hipSuccess) g.ms = ms;
+      if (g.ev0 && g.ev1 && hipEventElapsedTime(&ms, g.ev0, g.ev1) == hipSuccess) g.ms = ms;
       p->ms[g.kind] += g.ms;
       p->launches[g.kind] += 1;
     }

@@ -11,3 +11,7 @@ size_t pgpu_index_length(const pgpu_index* idx);
 // context helpers implemented in pgpu_api.hip
 hipStream_t pgpu_ctx_stream(pgpu_ctx* ctx);
 int pgpu_ctx_fail(pgpu_ctx* ctx, int code, const char* msg);
+bool pgpu_ctx_pool_acquire(pgpu_ctx* ctx, int pool);
+void pgpu_ctx_pool_release(pgpu_ctx* ctx, int pool);
+void* pgpu_ctx_pool_get(pgpu_ctx* ctx, int pool, int slot, size_t bytes);
+bool pgpu_ctx_timing(const pgpu_ctx* ctx);

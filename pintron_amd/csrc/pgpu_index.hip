@@ -429,14 +429,27 @@ struct pgpu_pairing_plan {
   unsigned long long n_cand = 0, n_out = 0;
   hipEvent_t ev[8] = {nullptr};
   float ms[7] = {0};
+  bool pooled = false;
+  pgpu_ctx* owner = nullptr;
 };
+
+// device buffer for a pairing plan: from the context's pool when the plan holds it
+template <class T> static T* plan_alloc(pgpu_pairing_plan* p, int slot, size_t count) {
+  const size_t bytes = (count ? count : 1) * sizeof(T);
+  if (p->pooled) return (T*)pgpu_ctx_pool_get(p->owner, 1, slot, bytes);
+  void* q = nullptr;
+  return hipMalloc(&q, bytes) == hipSuccess ? (T*)q : nullptr;
+}
 
 static void pairing_plan_free(pgpu_pairing_plan* p) {
   if (!p) return;
-  hipFree(p->d_pats); hipFree(p->d_pat_off); hipFree(p->d_lo); hipFree(p->d_hi); hipFree(p->d_a);
-  hipFree(p->d_thr); hipFree(p->d_cnt); hipFree(p->d_cnt_a); hipFree(p->d_cnt_b);
-  hipFree(p->d_cand_off); hipFree(p->d_out_off); hipFree(p->d_out_first); hipFree(p->d_cand);
-  hipFree(p->d_keep); hipFree(p->d_out); hipFree(p->d_tmp);
+  if (p->pooled) pgpu_ctx_pool_release(p->owner, 1);
+  else {
+    hipFree(p->d_pats); hipFree(p->d_pat_off); hipFree(p->d_lo); hipFree(p->d_hi); hipFree(p->d_a);
+    hipFree(p->d_thr); hipFree(p->d_cnt); hipFree(p->d_cnt_a); hipFree(p->d_cnt_b);
+    hipFree(p->d_cand_off); hipFree(p->d_out_off); hipFree(p->d_out_first); hipFree(p->d_cand);
+    hipFree(p->d_keep); hipFree(p->d_out); hipFree(p->d_tmp);
+  }
   for (auto& e : p->ev) if (e) hipEventDestroy(e);
   delete p;
 }
@@ -453,20 +466,25 @@ extern "C" int pgpu_pairing_plan_create(pgpu_ctx* ctx, const pgpu_index* idx, co
   hipStream_t st = pgpu_ctx_stream(ctx);
   p->idx = idx; p->n_pat = n_pat; p->total_pos = n_pat ? pat_off[n_pat] : 0;
   const size_t tp = (size_t)p->total_pos;
-  TRY_HIP(hipMalloc((void**)&p->d_pats, tp + 64));
-  TRY_HIP(dmalloc(&p->d_pat_off, n_pat + 1));
-  TRY_HIP(dmalloc(&p->d_lo, tp)); TRY_HIP(dmalloc(&p->d_hi, tp)); TRY_HIP(dmalloc(&p->d_a, tp));
-  TRY_HIP(dmalloc(&p->d_thr, tp)); TRY_HIP(dmalloc(&p->d_cnt, tp + 1)); TRY_HIP(dmalloc(&p->d_cnt_a, tp + 1));
-  TRY_HIP(dmalloc(&p->d_cnt_b, tp + 1));
-  TRY_HIP(dmalloc(&p->d_cand_off, tp + 1)); TRY_HIP(dmalloc(&p->d_out_off, tp + 1));
-  TRY_HIP(dmalloc(&p->d_out_first, n_pat + 1));
+  p->owner = ctx;
+  p->pooled = pgpu_ctx_pool_acquire(ctx, 1);
+#define NEED(ptr) do { if (!(ptr)) { rc = pgpu_ctx_fail(ctx, PGPU_ENOMEM, "out of device memory (pairing plan)"); goto done; } } while (0)
+  NEED(p->d_pats = plan_alloc<uint8_t>(p, 0, tp + 64));
+  NEED(p->d_pat_off = plan_alloc<unsigned long long>(p, 1, n_pat + 1));
+  NEED(p->d_lo = plan_alloc<uint32_t>(p, 2, tp)); NEED(p->d_hi = plan_alloc<uint32_t>(p, 3, tp));
+  NEED(p->d_a = plan_alloc<uint32_t>(p, 4, tp)); NEED(p->d_thr = plan_alloc<uint32_t>(p, 5, tp));
+  NEED(p->d_cnt = plan_alloc<uint32_t>(p, 6, tp + 1)); NEED(p->d_cnt_a = plan_alloc<uint32_t>(p, 7, tp + 1));
+  NEED(p->d_cnt_b = plan_alloc<uint32_t>(p, 8, tp + 1));
+  NEED(p->d_cand_off = plan_alloc<unsigned long long>(p, 9, tp + 1));
+  NEED(p->d_out_off = plan_alloc<unsigned long long>(p, 10, tp + 1));
+  NEED(p->d_out_first = plan_alloc<unsigned long long>(p, 11, n_pat + 1));
   {
     size_t b = 0;
     TRY_HIP(rocprim::exclusive_scan(nullptr, b, p->d_cnt, p->d_cand_off, 0ull, tp + 1, rocprim::plus<unsigned long long>(), st));
     p->tmp_bytes = b;
-    TRY_HIP(hipMalloc(&p->d_tmp, b ? b : 16));
+    NEED(p->d_tmp = plan_alloc<uint8_t>(p, 12, b ? b : 16));
   }
-  for (auto& e : p->ev) TRY_HIP(hipEventCreate(&e));
+  if (pgpu_ctx_timing(ctx)) for (auto& e : p->ev) TRY_HIP(hipEventCreate(&e));
   if (tp) TRY_HIP(hipMemcpyAsync(p->d_pats, patterns, tp, hipMemcpyHostToDevice, st));
   TRY_HIP(hipMemcpyAsync(p->d_pat_off, pat_off, (n_pat + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
   TRY_HIP(hipStreamSynchronize(st));
@@ -490,46 +508,48 @@ extern "C" int pgpu_pairing_plan_run(pgpu_ctx* ctx, pgpu_pairing_plan* p, const 
   p->n_cand = p->n_out = 0;
   if (p->n_pat == 0) return PGPU_OK;
   size_t b;
-  TRY_HIP(hipEventRecord(p->ev[0], st));
+  if (p->ev[0]) TRY_HIP(hipEventRecord(p->ev[0], st));
   hipLaunchKernelGGL(pair_locate_kernel, pgrid, pblk, 0, st, ix->d_gen, n, ix->d_sa, p->d_pats, p->d_pat_off, prm, p->d_lo, p->d_hi, p->d_a);
-  TRY_HIP(hipEventRecord(p->ev[1], st));
+  if (p->ev[1]) TRY_HIP(hipEventRecord(p->ev[1], st));
   hipLaunchKernelGGL(pair_chain_kernel, dim3((unsigned)((p->n_pat + 63) / 64)), pblk, 0, st, ix->d_gen, n, ix->d_sa, ix->d_lcp,
                      p->d_pats, p->d_pat_off, (uint32_t)p->n_pat, prm, p->d_lo, p->d_hi, p->d_a, p->d_thr);
-  TRY_HIP(hipEventRecord(p->ev[2], st));
+  if (p->ev[2]) TRY_HIP(hipEventRecord(p->ev[2], st));
   hipLaunchKernelGGL(pair_count_kernel, pgrid, pblk, 0, st, ix->d_gen, n, ix->d_sa, p->d_pats, p->d_pat_off, prm, p->d_lo, p->d_hi, p->d_thr, p->d_cnt);
   TRY_HIP(hipMemsetAsync(p->d_cnt + tp, 0, sizeof(uint32_t), st));
   b = p->tmp_bytes;
   TRY_HIP(rocprim::exclusive_scan(p->d_tmp, b, p->d_cnt, p->d_cand_off, 0ull, tp + 1, rocprim::plus<unsigned long long>(), st));
-  TRY_HIP(hipEventRecord(p->ev[3], st));
+  if (p->ev[3]) TRY_HIP(hipEventRecord(p->ev[3], st));
   TRY_HIP(hipMemcpyAsync(&p->n_cand, p->d_cand_off + tp, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
   TRY_HIP(hipStreamSynchronize(st));
-  if (p->n_cand > p->cand_cap) {
-    hipFree(p->d_cand); hipFree(p->d_keep); p->d_cand = nullptr; p->d_keep = nullptr;
+  if (p->n_cand > p->cand_cap || !p->d_cand) {
+    if (!p->pooled) { hipFree(p->d_cand); hipFree(p->d_keep); }
+    p->d_cand = nullptr; p->d_keep = nullptr;
     p->cand_cap = (size_t)(p->n_cand + p->n_cand / 8 + 1024);
-    TRY_HIP(dmalloc(&p->d_cand, p->cand_cap));
-    TRY_HIP(dmalloc(&p->d_keep, p->cand_cap));
+    NEED(p->d_cand = plan_alloc<Cand>(p, 13, p->cand_cap));
+    NEED(p->d_keep = plan_alloc<uint8_t>(p, 14, p->cand_cap));
   }
   hipLaunchKernelGGL(pair_fill_kernel, pgrid, pblk, 0, st, ix->d_gen, n, ix->d_sa, p->d_pats, p->d_pat_off, prm, p->d_lo, p->d_hi, p->d_thr,
                      p->d_cand_off, p->d_cand, p->d_cnt_a);
-  TRY_HIP(hipEventRecord(p->ev[4], st));
+  if (p->ev[4]) TRY_HIP(hipEventRecord(p->ev[4], st));
   hipLaunchKernelGGL(pair_cross_kernel, pgrid, pblk, 0, st, p->d_pat_off, p->d_cand_off, p->d_cand, p->d_cnt_a, p->d_keep, p->d_cnt_b);
   TRY_HIP(hipMemsetAsync(p->d_cnt_b + tp, 0, sizeof(uint32_t), st));
   b = p->tmp_bytes;
   TRY_HIP(rocprim::exclusive_scan(p->d_tmp, b, p->d_cnt_b, p->d_out_off, 0ull, tp + 1, rocprim::plus<unsigned long long>(), st));
-  TRY_HIP(hipEventRecord(p->ev[5], st));
+  if (p->ev[5]) TRY_HIP(hipEventRecord(p->ev[5], st));
   TRY_HIP(hipMemcpyAsync(&p->n_out, p->d_out_off + tp, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
   TRY_HIP(hipStreamSynchronize(st));
-  if (p->n_out > p->out_cap) {
-    hipFree(p->d_out); p->d_out = nullptr;
+  if (p->n_out > p->out_cap || !p->d_out) {
+    if (!p->pooled) hipFree(p->d_out);
+    p->d_out = nullptr;
     p->out_cap = (size_t)(p->n_out + p->n_out / 8 + 1024);
-    TRY_HIP(dmalloc(&p->d_out, p->out_cap));
+    NEED(p->d_out = plan_alloc<pgpu_pairing>(p, 15, p->out_cap));
   }
   hipLaunchKernelGGL(pair_emit_kernel, pgrid, pblk, 0, st, p->d_pat_off, p->d_cand_off, p->d_cand, p->d_cnt_a, p->d_keep, p->d_out_off,
                      p->d_out, p->d_out_first, (uint32_t)p->n_pat, p->total_pos);
-  TRY_HIP(hipEventRecord(p->ev[6], st));
+  if (p->ev[6]) TRY_HIP(hipEventRecord(p->ev[6], st));
   TRY_HIP(hipStreamSynchronize(st));
   TRY_HIP(hipGetLastError());
-  for (int k = 0; k < 6; ++k) hipEventElapsedTime(&p->ms[k], p->ev[k], p->ev[k + 1]);
+  if (p->ev[0]) for (int k = 0; k < 6; ++k) hipEventElapsedTime(&p->ms[k], p->ev[k], p->ev[k + 1]);
 done:
   return rc;
 }

@@ -13,6 +13,7 @@
  */
 #define _GNU_SOURCE
 #include <pthread.h>
+#include <time.h>
 #include <stdlib.h>
 #include <string.h>
 #include <ucontext.h>
@@ -24,6 +25,8 @@
 
 enum { F_RUNNABLE, F_WAIT_DP, F_WAIT_PAIR, F_DONE };
 
+static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+
 struct worker;
 
 typedef struct fiber {
@@ -32,6 +35,7 @@ typedef struct fiber {
   struct worker* w;
   int state;
   size_t unit;
+  size_t cur_entry;          /* entry of the prepared list being factorized */
   /* pending request */
   ef_dp_req req; ef_dp_res* res; int rc;
   const char* pat; size_t pat_len; unsigned pat_L; double pat_rate; ef_triple** pat_out; size_t* pat_n;
@@ -51,6 +55,9 @@ typedef struct shared {
   size_t next_unit;                    /* protected by mu */
   pthread_mutex_t mu;
   size_t max_fibers, stack_size;
+  /* pairings of every list entry at the configured (min_factor_len, rate), computed in ONE
+   * resident batch before the fibres start; retries with a longer factor go through batches */
+  pgpu_pairing* pre_tri; uint64_t* pre_first;
   int failed;
   ef_sched_stats stats;
 } shared;
@@ -76,6 +83,15 @@ static int fiber_dp(void* self, const ef_dp_req* q, ef_dp_res* res) {
 
 static int fiber_pairings(void* self, const char* pattern, size_t m, unsigned L, double rate, ef_triple** out, size_t* n) {
   fiber* f = (fiber*)self;
+  const shared* sh = f->w->sh;
+  if (sh->pre_first && L == sh->in->cfg.min_factor_len && rate == sh->in->cfg.min_string_depth_rate &&
+      pattern == sh->in->list[f->cur_entry]->seq) {
+    const uint64_t a = sh->pre_first[f->cur_entry], b = sh->pre_first[f->cur_entry + 1];
+    ef_triple* t = (ef_triple*)malloc((size_t)(b - a + 1) * sizeof(ef_triple));
+    memcpy(t, sh->pre_tri + a, (size_t)(b - a) * sizeof(ef_triple));
+    *out = t; *n = (size_t)(b - a);
+    return 0;
+  }
   f->pat = pattern; f->pat_len = m; f->pat_L = L; f->pat_rate = rate; f->pat_out = out; f->pat_n = n;
   f->state = F_WAIT_PAIR;
   swapcontext(&f->ctx, &f->w->sched);
@@ -91,6 +107,7 @@ static void fiber_main(unsigned hi, unsigned lo) {
   ef_side_files side = { fs[2], fs[3], fs[4], fs[5] };
   const ef_inputs* in = sh->in;
   for (size_t k = u->first; k <= u->first + (u->has_sibling ? 1 : 0); ++k) {
+    f->cur_entry = k;
     ef_est* fe = ef_compute_est_fact(in->gen, in->list[k], &f->be, &in->cfg, &side);
     const bool aligned = !efl_empty(fe->factorizations);
     if (aligned) {
@@ -222,10 +239,12 @@ static void* worker_main(void* arg) {
     while (more && w->n_fibers < sh->max_fibers) more = start_fiber(w);
     if (w->n_fibers == 0) break;
     /* run every runnable fibre until it blocks or ends */
+    double t0 = now_s();
     for (size_t i = 0; i < w->n_fibers; ++i) {
       fiber* f = w->fibers[i];
       if (f->state == F_RUNNABLE) swapcontext(&w->sched, &f->ctx);
     }
+    w->stats.host_s += now_s() - t0;
     /* retire finished fibres */
     size_t keep = 0;
     for (size_t i = 0; i < w->n_fibers; ++i) {
@@ -234,7 +253,13 @@ static void* worker_main(void* arg) {
       else w->fibers[keep++] = f;
     }
     w->n_fibers = keep;
-    if (submit_pairings(w) != 0 || submit_dp(w) != 0) { sh->failed = 1; break; }
+    t0 = now_s();
+    int brc = submit_pairings(w);
+    w->stats.pairing_s += now_s() - t0;
+    t0 = now_s();
+    if (brc == 0) brc = submit_dp(w);
+    w->stats.dp_s += now_s() - t0;
+    if (brc != 0) { sh->failed = 1; break; }
   }
   ef_jobbuf_free(&w->jb);
   free(w->strings); free(w->results); free(w->fibers);
@@ -248,12 +273,14 @@ static size_t env_size(const char* name, size_t dflt) {
 }
 
 int ef_run_batched_stats(int argc, char** argv, ef_sched_stats* stats_out) {
+  const double t_start = now_s();
   ef_inputs in;
   int rc = ef_load_inputs(argc, argv, &in);
   if (rc) return rc;
   ef_outputs out;
   if (ef_open_outputs(&out)) return 1;
   ef_classify_init();
+  const double t_loaded = now_s();
   pgpu_ctx* ctx0 = NULL;
   if (pgpu_init(ef_gpu_device_from_env(), &ctx0) != PGPU_OK) {
     fprintf(stderr, "* FATAL no usable MI355X (gfx950) device / libpintron_gpu.so: est-fact has no CPU fallback\n");
@@ -266,6 +293,30 @@ int ef_run_batched_stats(int argc, char** argv, ef_sched_stats* stats_out) {
     fprintf(stderr, "* FATAL pgpu_index_build: %s\n", pgpu_last_error(ctx0));
     return 1;
   }
+  /* pairing prefetch: all prepared sequences (both strands) in one batch */
+  if (!getenv("PINTRON_NO_PREFETCH") && in.n > 0) {
+    size_t total = 0;
+    for (size_t k = 0; k < in.n; ++k) total += strlen(in.list[k]->seq);
+    char* blob = (char*)malloc(total + 1);
+    uint64_t* off = (uint64_t*)malloc((in.n + 1) * sizeof(uint64_t));
+    size_t pos = 0;
+    for (size_t k = 0; k < in.n; ++k) { const size_t m = strlen(in.list[k]->seq); off[k] = pos; memcpy(blob + pos, in.list[k]->seq, m); pos += m; }
+    off[in.n] = pos;
+    pgpu_pairing_plan* pp = NULL;
+    pgpu_pairing_params prm = { in.cfg.min_factor_len, 0, in.cfg.min_string_depth_rate };
+    int prc = pgpu_pairing_plan_create(ctx0, sh.idx, blob, off, in.n, &pp);
+    if (prc == PGPU_OK) prc = pgpu_pairing_plan_run(ctx0, pp, &prm);
+    if (prc == PGPU_OK) {
+      const size_t cnt = (size_t)pgpu_pairing_plan_count(pp);
+      sh.pre_tri = (pgpu_pairing*)malloc((cnt + 1) * sizeof(pgpu_pairing));
+      sh.pre_first = (uint64_t*)malloc((in.n + 1) * sizeof(uint64_t));
+      prc = pgpu_pairing_plan_fetch(ctx0, pp, sh.pre_tri, cnt, sh.pre_first);
+    }
+    if (pp) pgpu_pairing_plan_destroy(ctx0, pp);
+    free(blob); free(off);
+    if (prc != PGPU_OK) { fprintf(stderr, "* FATAL pairing prefetch failed: %s\n", pgpu_last_error(ctx0)); return 1; }
+  }
+  const double t_index = now_s();
   /* units: forward entry (+ sibling) */
   sh.units = (unit*)calloc(in.n + 1, sizeof(unit));
   for (size_t k = 0; k < in.n;) {
@@ -276,7 +327,8 @@ int ef_run_batched_stats(int argc, char** argv, ef_sched_stats* stats_out) {
   }
   pthread_mutex_init(&sh.mu, NULL);
   const long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
-  size_t nthreads = env_size("PINTRON_THREADS", ncpu > 0 ? (size_t)ncpu : 1);
+  /* default: the host share of one GPU on an 8-GPU node (the GPU boxes expose far more cores) */
+  size_t nthreads = env_size("PINTRON_THREADS", ncpu > 16 ? 16 : (ncpu > 0 ? (size_t)ncpu : 1));
   if (nthreads > sh.n_units) nthreads = sh.n_units ? sh.n_units : 1;
   sh.max_fibers = env_size("PINTRON_FIBERS", 2048);
   sh.stack_size = env_size("PINTRON_FIBER_STACK_KB", 256) * 1024;
@@ -290,7 +342,9 @@ int ef_run_batched_stats(int argc, char** argv, ef_sched_stats* stats_out) {
   for (size_t t = 0; t < nthreads; ++t) {
     st.units += ws[t].stats.units; st.dp_batches += ws[t].stats.dp_batches; st.dp_jobs += ws[t].stats.dp_jobs;
     st.pairing_batches += ws[t].stats.pairing_batches; st.pairing_requests += ws[t].stats.pairing_requests;
+    st.host_s += ws[t].stats.host_s; st.pairing_s += ws[t].stats.pairing_s; st.dp_s += ws[t].stats.dp_s;
   }
+  st.load_s = t_loaded - t_start; st.index_s = t_index - t_loaded; st.workers_s = now_s() - t_index;
   if (stats_out) *stats_out = st;
   rc = sh.failed ? 1 : 0;
   if (!rc) {
@@ -301,7 +355,7 @@ int ef_run_batched_stats(int argc, char** argv, ef_sched_stats* stats_out) {
         free(sh.units[u].buf[k]);
       }
   }
-  free(ws); free(th); free(sh.units);
+  free(ws); free(th); free(sh.units); free(sh.pre_tri); free(sh.pre_first);
   pgpu_index_destroy(ctx0, sh.idx);
   pgpu_destroy(ctx0);
   ef_close_outputs(&out);
@@ -313,7 +367,9 @@ int ef_run_batched(int argc, char** argv) {
   ef_sched_stats st;
   const int rc = ef_run_batched_stats(argc, argv, &st);
   if (rc == 0 && getenv("PINTRON_VERBOSE"))
-    fprintf(stderr, "est-fact: %zu ESTs, %zu threads, %zu pairing batches (%zu requests), %zu DP batches (%zu jobs)\n",
-            st.units, st.threads, st.pairing_batches, st.pairing_requests, st.dp_batches, st.dp_jobs);
+    fprintf(stderr, "est-fact: %zu ESTs, %zu threads, %zu pairing batches (%zu requests), %zu DP batches (%zu jobs); "
+                    "load %.2fs index %.2fs workers %.2fs [per-thread avg: host %.2fs pairing %.2fs dp %.2fs]\n",
+            st.units, st.threads, st.pairing_batches, st.pairing_requests, st.dp_batches, st.dp_jobs,
+            st.load_s, st.index_s, st.workers_s, st.host_s / st.threads, st.pairing_s / st.threads, st.dp_s / st.threads);
   return rc;
 }

@@ -5,6 +5,8 @@
 
 typedef struct {
   size_t threads, units, dp_batches, dp_jobs, pairing_batches, pairing_requests;
+  double load_s, index_s, workers_s;      /* wall-clock phases */
+  double host_s, pairing_s, dp_s;         /* summed over threads: fibres / pairing batches / DP batches */
 } ef_sched_stats;
 
 /* environment: PINTRON_THREADS (default: online CPUs), PINTRON_FIBERS (fibres per thread, 2048),
