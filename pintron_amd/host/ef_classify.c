@@ -105,50 +105,61 @@ static double motif_score(const char* s, int k) {
   return num / den;
 }
 
-/* SearchBPSinIntronSequenceWithMathInspector (:575-618) */
-static int search_bps(const char* intron, int k, double* score, int range_start, int range_end) {
+/* SearchBPSinIntronSequenceWithMathInspector (:575-618) over intron[0..length) */
+static int search_bps(const char* intron, size_t length, int k, double* score, int range_start, int range_end) {
   *score = 0.0f;
-  const size_t length = strlen(intron);
   if (length < (unsigned)range_start) return -1;
   int start_w = (int)length - range_end, end_w = (int)length - range_start;
   if (start_w < 0) start_w = 0;
   int start_bps = -1;
   bool first = true;
+  char win[13];
   for (int i = start_w; i <= end_w; ++i) {
-    char* bps = ef_real_substring(i, 12, intron);
-    const double sc = motif_score(bps, k);
+    /* real_substring(i, 12, intronSequence): NUL-padded when the window passes the end */
+    for (int c = 0; c < 12; ++c) win[c] = (size_t)(i + c) < length ? intron[i + c] : '\0';
+    win[12] = '\0';
+    const double sc = motif_score(win, k);
     if (first || sc >= *score) { *score = sc; start_bps = i; first = false; }
-    free(bps);
   }
   return start_bps;
 }
 
 /* ExistsGoodBPSinIntronSequenceWithMathInspector (:535-573) */
-static int good_bps(const char* intron, int range_start, int range_end) {
-  if (range_end > (int)strlen(intron)) return -1;
+static int good_bps(const char* intron, size_t length, int range_start, int range_end) {
+  if (range_end > (int)length) return -1;
   double s9 = 0.0f, s10 = 0.0f;
-  const int b9 = search_bps(intron, 0, &s9, range_start, range_end);
-  const int b10 = search_bps(intron, 1, &s10, range_start, range_end);
+  const int b9 = search_bps(intron, length, 0, &s9, range_start, range_end);
+  const int b10 = search_bps(intron, length, 1, &s10, range_start, range_end);
   if (s9 > s10) return s9 > 0.75f ? b9 : -1;
   return s10 > 0.75f ? b10 : -1;
 }
 
 static double score5(const char* gen, int splice5, int k) {           /* GetScoreOf5Prime*BySS */
-  char* s = ef_real_substring(splice5 - 3, pwm_len[k], gen);
-  const double r = motif_score(s, k);
-  free(s);
-  return r;
+  char win[24];
+  int idx = splice5 - 3, len = pwm_len[k];
+  if (idx < 0) { len += idx; idx = 0; }                     /* real_substring clamps a negative index */
+  if (len < 0) len = 0;
+  int c = 0;
+  for (; c < len && gen[idx + c] != '\0'; ++c) win[c] = gen[idx + c];
+  for (; c < 24; ++c) win[c] = '\0';
+  return motif_score(win, k);
 }
 
-/* classify_genomic_intron_start_end (:95-229), class only */
+/* classify_genomic_intron_start_end (:95-229), class only.  The reference copies the intron
+ * (real_substring); we read it in place: intron = gen[start .. start+il) */
 int ef_classify_intron(const char* gen, int start, int end) {
   load_all();
-  char* intron = ef_real_substring(start, end - start + 1, gen);
-  const int bps = good_bps(intron, 14, 30);
-  const size_t il = strlen(intron);
+  int idx = start, want = end - start + 1;
+  if (idx < 0) { want += idx; idx = 0; }
+  if (want < 0) want = 0;
+  const char* intron = gen + idx;
+  const char* nul = (const char*)memchr(intron, 0, (size_t)want);
+  const size_t il = nul ? (size_t)(nul - intron) : (size_t)want;
+  const int bps = good_bps(intron, il, 14, 30);
   char p5[3] = { 0, 0, 0 }, p3[3] = { 0, 0, 0 };
-  strncpy(p5, intron, 2);
-  if (il >= 2) strncpy(p3, intron + il - 2, 2);
+  for (size_t c = 0; c < 2 && c < il; ++c) p5[c] = intron[c];
+  if (il >= 2) { p3[0] = intron[il - 2]; p3[1] = intron[il - 1]; }
+  else for (size_t c = 0; c < il; ++c) p3[c] = intron[c];
   double u12 = 0.0f, u2 = 0.0f, t;
   int pt_type = 1;
   const bool ag = !strcmp(p3, "ag") || !strcmp(p3, "AG");
@@ -175,6 +186,5 @@ int ef_classify_intron(const char* gen, int start, int end) {
   if (bps != -1) type = u12 > u2 ? 0 : 1;
   else if (pt_type == 0) type = 1;
   else if (u12 - u2 > 0.25 && u12 >= 0.75) type = 0;
-  free(intron);
   return type;
 }

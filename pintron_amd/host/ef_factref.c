@@ -195,6 +195,30 @@ static void remove_false_small_exons(const ef_seq* gen, ef_est* e, ef_backend* b
   }
 }
 
+/* positions of every ACGT 6-mer of a text, grouped by 6-mer code (12 bits), ascending */
+typedef struct { uint32_t first[4097]; uint32_t* pos; } kmer_index;
+
+static int base2(char c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : -1; }
+static int kmer_code(const char* s) {
+  int code = 0;
+  for (int k = 0; k < LB_SMALL_EXON; ++k) { const int b = base2(s[k]); if (b < 0) return -1; code = (code << 2) | b; }
+  return code;
+}
+static void kmer_index_build(kmer_index* kx, const char* t, size_t n) {
+  memset(kx->first, 0, sizeof kx->first);
+  kx->pos = (uint32_t*)malloc((n + 1) * sizeof(uint32_t));
+  if (n < LB_SMALL_EXON) return;
+  int* codes = (int*)malloc(n * sizeof(int));
+  const size_t nk = n - LB_SMALL_EXON + 1;
+  for (size_t i = 0; i < nk; ++i) { codes[i] = kmer_code(t + i); if (codes[i] >= 0) ++kx->first[codes[i] + 1]; }
+  for (int c = 0; c < 4096; ++c) kx->first[c + 1] += kx->first[c];
+  uint32_t* fill = (uint32_t*)malloc(4096 * sizeof(uint32_t));
+  memcpy(fill, kx->first, 4096 * sizeof(uint32_t));
+  for (size_t i = 0; i < nk; ++i) if (codes[i] >= 0) kx->pos[fill[codes[i]]++] = (uint32_t)i;
+  free(fill); free(codes);
+}
+static void kmer_index_free(kmer_index* kx) { free(kx->pos); }
+
 static bool canonical_intron(const char* G, size_t s, size_t e) {           /* :481-494 */
   return (G[s] == 'G' && G[s + 1] == 'T' && G[e - 1] == 'A' && G[e] == 'G') ||
          (G[s] == 'g' && G[s + 1] == 't' && G[e - 1] == 'a' && G[e] == 'g');
@@ -284,25 +308,56 @@ static void small_exon_between(ef_factor* p1, ef_factor* p2, ef_iter* it, const 
       char* allg = ef_real_substring((int)allgstart, (int)allglen, G);
       size_t max_len = 0, ecut1 = 0, ecut2 = 0, gcut1_1 = 0, gcut1_2 = 0, gcut2_1 = 0, gcut2_2 = 0;
       const size_t max_offstart = zmin(zmin(f1slen + 1 - MIN_PERFECT_BORDER, elen + 1 - LB_SMALL_EXON), allglen + 1 - (2 * MIL) - LB_SMALL_EXON);
+      /* The reference runs strstr() over the whole intron for every (offstart, offend) pair
+       * (:781-834).  Same occurrences, same order, found through a 6-mer index of the genomic
+       * window built once (every pattern is at least LB_SMALL_EXON = 6 long); patterns whose first
+       * six characters are not all ACGT fall back to strstr(). */
+      kmer_index kx;
+      kmer_index_build(&kx, allg, allglen);
       for (size_t os = 0; os < max_offstart; ++os) {
         const size_t max_offend = zmin(zmin(f2plen + 1 - MIN_PERFECT_BORDER, elen + 1 - os - LB_SMALL_EXON), allglen + 1 - (2 * MIL) - LB_SMALL_EXON - os);
+        const int code = kmer_code(efact + os);
         for (size_t oe = 0; oe < max_offend; ++oe) {
-          const char sv_e = efact[elen - oe]; efact[elen - oe] = '\0';
-          const char sv_g = allg[allglen - oe - MIL]; allg[allglen - oe - MIL] = '\0';
-          char* occ = allg + os + MIL;
-          while ((occ = strstr(occ, efact + os))) {
-            const size_t i1s = allgstart + os, i1e = allgstart + (size_t)(occ - allg) - 1;
+          const size_t plen = elen - os - oe;                 /* pattern efact[os .. elen-oe) */
+          const size_t text_lo = os + MIL, text_hi = allglen - oe - MIL;   /* text allg[text_lo .. text_hi) */
+          size_t cursor = 0;                                   /* next candidate (index mode) */
+          char sv_e = 0, sv_g = 0;
+          char* occ = NULL;
+          if (code < 0) {
+            sv_e = efact[elen - oe]; efact[elen - oe] = '\0';
+            sv_g = allg[text_hi]; allg[text_hi] = '\0';
+            occ = allg + text_lo;
+          }
+          for (;;) {
+            size_t q;
+            if (code < 0) {
+              occ = strstr(occ, efact + os);
+              if (!occ) break;
+              q = (size_t)(occ - allg);
+              ++occ;
+            } else {
+              bool found = false;
+              const uint32_t* cand = kx.pos + kx.first[code];
+              const size_t nc = kx.first[code + 1] - kx.first[code];
+              while (cursor < nc) {
+                q = cand[cursor++];
+                if (q < text_lo || plen > text_hi || q > text_hi - plen) continue;
+                if (memcmp(allg + q + LB_SMALL_EXON, efact + os + LB_SMALL_EXON, plen - LB_SMALL_EXON) == 0) { found = true; break; }
+              }
+              if (!found) break;
+            }
+            const size_t i1s = allgstart + os, i1e = allgstart + q - 1;
             const size_t i2s = i1e + 1 + elen - os - oe, i2e = allgstart + allglen - oe - 1;
             const int t1 = ef_classify_intron(G, (int)i1s, (int)i1e), t2 = ef_classify_intron(G, (int)i2s, (int)i2e);
             if (t1 != INTRON_ND && t2 != INTRON_ND) {
               const size_t sl = elen - os - oe;
               if (sl > max_len) { max_len = sl; ecut1 = estart + os; ecut2 = estart + os + sl; gcut1_1 = i1s; gcut1_2 = i1e + 1; gcut2_1 = i2s; gcut2_2 = i2e + 1; }
             }
-            ++occ;
           }
-          efact[elen - oe] = sv_e; allg[allglen - oe - MIL] = sv_g;
+          if (code < 0) { efact[elen - oe] = sv_e; allg[text_hi] = sv_g; }
         }
       }
+      kmer_index_free(&kx);
       if (max_len >= LB_SMALL_EXON) {
         ef_factor* nw = factor_new((int)ecut1, (int)ecut2 - 1, (int)gcut1_2, (int)gcut2_1 - 1);
         p2->EST_start = (int)ecut2; p2->GEN_start = (int)gcut2_2;
