@@ -1,184 +1,158 @@
 #!/usr/bin/env python3
-"""bench.py -- est-fact hot path on MI355X: one step = one pass of the accelerated stages over one
-C3 batch (BASELINE.json configs[2]: 200 kb genomic x 100 000 ESTs ~600 bp, 3 % errors).
+"""bench.py -- est-fact on MI355X: one step = one pass of the WHOLE est-fact hot path over one C3
+batch (BASELINE.json configs[2]: 200 kb genomic x 100 000 ESTs ~600 bp, 3 % errors) per GPU.
 
-What a step runs TODAY (round 1), all through the C-ABI (libpintron_gpu.so), inputs resident in HBM:
-  1. the pairing stage (build_vertex_set replacement) for the 100 000 ESTs of the batch over the
-     device suffix-array index of the 200 kb genomic;
-  2. the batched DP stage -- every dynamic-programming call the reference est-fact makes for the
-     batch (ALIGN, GAP, ED/EDM, KBAND, BORDERS, LCF; AFFIX when present).  The job mix is the
-reference's own: tests/golden/c3_sample_jobs.jsonl.gz holds the DP calls of the unmodified
-reference on a seeded 400-EST C3 sample (tools/make_bench_fixture.py), tiled to 100 000 ESTs.
-The MEG/embedding/filter host logic of est-fact is NOT in the step yet; `config.stages` says so
-and the value must be read as the throughput of the accelerated stages, not of the whole program.
+A step runs the product code path (pintron_amd/host/*.c = the est-fact program, as a library):
+pairings of all prepared sequences over the device suffix-array index (resident patterns), then
+per EST: MEG construction, embedding enumeration, candidate cleaning, filters, intron refinement,
+post-refinement -- host C on the worker threads -- with EVERY dynamic program (ALIGN, GAP, ED, KBAND,
+LCF, BORDERS, AFFIX) batched across ESTs onto the GPU through the C-ABI (libpintron_gpu.so).  The
+step ends with the per-EST output records in host memory (what est-fact writes to
+raw-multifasta-out.txt); for N > 1 they are gathered to rank 0 over RCCL inside the step.
+Not in the step: reading genomic.txt/ests.txt, strand/polyA preparation, index construction (done
+once, reported as load_s / index_s), writing the files.
+
+The output of the timed steps is checked: a bounded sample of the same workload is run through the
+reference CPU est-fact (oracle/_ref/est-fact-ref, the cpu_baseline) and through this code, and the
+two raw-multifasta-out.txt must be byte-identical.
 
 Contract: python bench.py --gpus N --steps K --warmup W ; one JSON line on rank 0.
 """
 import argparse
 import ctypes as C
-import gzip
+import hashlib
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-
-JOB_DT = np.dtype([("kind", "<u4"), ("flags", "<u4"), ("a_off", "<u8"), ("b_off", "<u8"),
-                   ("a_len", "<u4"), ("b_len", "<u4"), ("p0", "<u4"), ("p1", "<u4"),
-                   ("p2", "<u4"), ("tail", "<u4")], align=True)
-assert JOB_DT.itemsize == 48
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 N_EST_BATCH = 100_000          # C3
-REC_BYTES_PER_EST = 256        # size of the per-EST record block gathered to rank 0 (N > 1)
+CPU_SAMPLE = 3000              # ESTs of the same workload given to the reference CPU est-fact
 
 
-def load_tile(genomic: bytes):
-    """One tile = the reference's DP calls for the fixture's ESTs, as (jobs, arena, n_est).
-    Genomic-side operands that are exact slices of the genomic are addressed in the resident
-    genomic (PGPU_JOB_*_GENOMIC) as the host program does; EST-side strings go to the arena."""
-    import pintron_amd.capi as capi
-    kinds = dict(ALIGN=capi.ALIGN, GAP=capi.GAP, ED=capi.ED, EDM=capi.ED, KBAND=capi.KBAND,
-                 BORDERS=capi.BORDERS, LCF=capi.LCF)
-    rows, chunks, size, meta = [], [], 0, None
-    with gzip.open(os.path.join(ROOT, "tests", "golden", "c3_sample_jobs.jsonl.gz"), "rt") as f:
-        for line in f:
-            r = json.loads(line)
-            if r["k"] == "META":
-                meta = r
-                continue
-            k = kinds[r["k"]]
-            flags = 0
-            b = r["b"].encode("latin1")
-            p0 = p1 = p2 = tail = 0
-            if k == capi.LCF:
-                a_off, a_len, flags = 0, r["a_gen_len"], capi.JOB_A_GENOMIC
-            else:
-                a = r["a"].encode("latin1")
-                a_off, a_len = size, len(a)
-                chunks.append(a)
-                size += len(a)
-            if k == capi.KBAND:
-                p0 = r["ub"]
-            b_tail = b""
-            if k == capi.BORDERS:
-                p0, p1, p2 = r["min_cut"], r["max_cut"], r["max_errs"]
-                b_tail = r["b_tail"].encode("latin1")
-                tail = len(b_tail)
-            g = genomic.find(b + b_tail) if len(b) >= 24 else -1
-            if g >= 0:
-                b_off, flags = g, flags | capi.JOB_B_GENOMIC
-            else:
-                b_off = size
-                chunks.append(b + b_tail)
-                size += len(b) + len(b_tail)
-            rows.append((k, flags, a_off, b_off, a_len, len(b), p0, p1, p2, tail))
-    return np.array(rows, dtype=JOB_DT), b"".join(chunks), meta
+class KernelStat(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("ms", C.c_double), ("launches", C.c_size_t),
+                ("jobs", C.c_size_t), ("cells", C.c_ulonglong), ("algo_bytes", C.c_ulonglong)]
 
 
-def tile_jobs(jobs, arena, n_tiles):
-    import pintron_amd.capi as capi
-    out = np.tile(jobs, n_tiles)
-    t = np.repeat(np.arange(n_tiles, dtype=np.uint64), len(jobs)) * np.uint64(len(arena))
-    out["a_off"] += np.where(out["flags"] & capi.JOB_A_GENOMIC, np.uint64(0), t)
-    out["b_off"] += np.where(out["flags"] & capi.JOB_B_GENOMIC, np.uint64(0), t)
-    return out, arena * n_tiles
+class SchedStats(C.Structure):
+    _fields_ = [(n, C.c_size_t) for n in ("threads", "units", "aligned", "dp_batches", "dp_jobs",
+                                          "pairing_batches", "pairing_requests")] + \
+               [(n, C.c_double) for n in ("load_s", "index_s", "prefetch_s", "workers_s", "host_s",
+                                          "pairing_s", "dp_s")] + \
+               [("n_kernels", C.c_int), ("kernels", KernelStat * 64)]
 
 
-def make_plan(ctx, idx, jobs, arena):
-    import pintron_amd.capi as capi
-    h = C.c_void_p()
-    ctx.check(ctx.L.pgpu_dp_plan_create(ctx.h, idx.h, C.cast(jobs.ctypes.data, C.POINTER(capi.DpJob)),
-                                        len(jobs), arena, len(arena), C.byref(h)))
-    plan = capi.Plan.__new__(capi.Plan)
-    plan.ctx, plan.n, plan.h, plan._jobs, plan._arena = ctx, len(jobs), h, jobs, arena
-    return plan
+def load_host_lib():
+    path = os.path.join(ROOT, "pintron_amd", "lib", "libestfact.so")
+    if not os.path.exists(path):
+        raise SystemExit("%s missing: run __graft_entry__.build() (there is no CPU fallback)" % path)
+    L = C.CDLL(path)
+    L.ef_session_open.restype = C.c_void_p
+    L.ef_session_open.argtypes = [C.c_int, C.POINTER(C.c_char_p)]
+    L.ef_session_step.argtypes = [C.c_void_p, C.POINTER(SchedStats)]
+    L.ef_session_records.restype = C.c_void_p
+    L.ef_session_records.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
+    L.ef_session_n_ests.restype = C.c_size_t
+    L.ef_session_n_ests.argtypes = [C.c_void_p]
+    L.ef_session_write_outputs.argtypes = [C.c_void_p]
+    L.ef_session_close.argtypes = [C.c_void_p]
+    return L
 
 
-def cpu_baseline(jobs, arena, genomic, n_est_tile, passes):
-    """The CPU oracle (our port of the reference DPs, single thread) on the SAME jobs: one tile =
-    the DP calls of `n_est_tile` ESTs.  Checker code, timed here only as the reported baseline."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import oracle_lib as O
-    import pintron_amd.capi as capi
-    L = O.oracle()
-    L.orc_dp_batch.restype = C.c_uint64
-    L.orc_dp_batch.argtypes = [C.c_void_p, C.c_size_t, C.c_char_p, C.c_char_p, C.c_void_p,
-                               C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
-    res = (capi.DpResult * len(jobs))()
-    cap = int(2 * (jobs["a_len"].astype(np.int64) + jobs["b_len"] + 1)[jobs["kind"] <= 1].sum()) + 16
-    sbuf = C.create_string_buffer(cap)
-    used = C.c_size_t()
+class Session:
+    def __init__(self, L, directory):
+        self.L, self.dir = L, directory
+        cwd = os.getcwd()
+        os.chdir(directory)
+        try:
+            argv = (C.c_char_p * 2)(b"est-fact", None)
+            self.h = L.ef_session_open(1, argv)
+        finally:
+            os.chdir(cwd)
+        if not self.h:
+            raise SystemExit("est-fact session could not start (no MI355X / libpintron_gpu.so?)")
+
+    def step(self):
+        st = SchedStats()
+        if self.L.ef_session_step(self.h, C.byref(st)) != 0:
+            raise SystemExit("est-fact step failed")
+        return st
+
+    def records(self) -> bytes:
+        n = C.c_size_t()
+        p = self.L.ef_session_records(self.h, C.byref(n))
+        data = C.string_at(p, n.value)
+        C.CDLL(None).free(C.c_void_p(p))
+        return data
+
+    def close(self):
+        self.L.ef_session_close(self.h)
+
+
+def cpu_reference(sample_dir):
+    """Reference CPU est-fact (oracle/_ref, compiled from /root/reference) on the sample, one core."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "est-fact-ref")
+    if not os.path.exists(exe):
+        return None
     t0 = time.perf_counter()
-    cells = 0
-    for _ in range(passes):
-        cells = L.orc_dp_batch(jobs.ctypes.data, len(jobs), arena, genomic, res, sbuf, cap, C.byref(used))
-    dt = time.perf_counter() - t0
-    return dict(ests_per_s=n_est_tile * passes / dt, cells=int(cells), seconds=dt,
-                mcells_per_s=cells * passes / dt / 1e6), res, sbuf.raw
+    subprocess.run([exe], cwd=sample_dir, check=True, stderr=subprocess.DEVNULL)
+    return time.perf_counter() - t0
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--ests", type=int, default=N_EST_BATCH, help="ESTs per GPU per step (default: C3)")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / parity leg")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ["PINTRON_GPU_DEVICE"] = str(local if world > 1 else 0)
+    os.environ.setdefault("PINTRON_KERNEL_TIMING", "1")
     import torch
     dist = None
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     else:
         torch.cuda.set_device(0)
 
-    import pintron_amd.capi as capi
     from pintron_amd import synth
-    ctx = capi.Context(local if world > 1 else 0)       # raises without the HIP library / a GPU
-    wl = synth.make("C3", n_est=args.ests)                # seeded C3: 200 kb genomic + ESTs
-    genomic = wl.genomic
-    t0 = time.perf_counter()
-    idx = capi.Index(ctx, genomic)
-    t_index = time.perf_counter() - t0
-    # patterns as est-fact sees them after strand handling (src/main-est-fact.c:190-213):
-    # /clone_end=5' ESTs are reverse-complemented
-    comp = bytes.maketrans(b"ACGTN", b"TGCAN")
-    pats = [s.translate(comp)[::-1] if t["rc"] else s for s, t in zip(wl.est_seqs, wl.truth)]
-    pplan = capi.PairingPlan(ctx, idx, pats)
-    tile, tile_arena, meta = load_tile(genomic)
-    n_tiles = max(1, -(-args.ests // meta["n_est"]))
-    n_est = n_tiles * meta["n_est"]
-    jobs, arena = tile_jobs(tile, tile_arena, n_tiles)
-    t0 = time.perf_counter()
-    plan = make_plan(ctx, idx, jobs, arena)
-    t_upload = time.perf_counter() - t0
-
-    rec = None
-    gather_list = None
-    if world > 1:
-        rec = torch.empty(n_est * REC_BYTES_PER_EST, dtype=torch.uint8, device="cuda")
-        if rank == 0:
-            gather_list = [torch.empty_like(rec) for _ in range(world)]
+    L = load_host_lib()
+    # every rank gets its own C3 batch (weak scaling); rank r uses seed 3 + r so batches differ
+    wl = synth.make("C3", n_est=args.ests, seed=synth.CONFIGS["C3"]["seed"] + rank)
+    work = tempfile.mkdtemp(prefix="pintron_bench_r%d_" % rank)
+    synth.write_files(wl, work)
+    sess = Session(L, work)
+    n_est = int(L.ef_session_n_ests(sess.h))
 
     def step():
-        pplan.run(15, 0.2)                 # options.ggo defaults: -l 15, -d 0.2
-        plan.launch()
-        plan.sync()
+        st = sess.step()
         if world > 1:
-            # per-EST record block -> rank 0 over RCCL (the only exchange of the sharded path)
-            ctx.check(ctx.L.pgpu_dp_plan_results_to_device(ctx.h, plan.h, rec.data_ptr(), rec.numel()))
-            dist.gather(rec, gather_list, dst=0)
+            # the only exchange of the sharded path: per-EST output records -> rank 0 (RCCL)
+            rec = sess.records()
+            t = torch.frombuffer(bytearray(rec), dtype=torch.uint8).cuda()
+            n = torch.tensor([t.numel()], dtype=torch.int64, device="cuda")
+            sizes = [torch.zeros_like(n) for _ in range(world)]
+            dist.all_gather(sizes, n)
+            mx = int(max(int(s.item()) for s in sizes))
+            pad = torch.zeros(mx, dtype=torch.uint8, device="cuda")
+            pad[: t.numel()] = t
+            outl = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
+            dist.gather(pad, outl, dst=0)
+        return st
 
     def fence():
         if world > 1:
@@ -187,79 +161,81 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    groups_acc = None
-    pair_ms = {k: 0.0 for k in capi.PairingPlan.STAGES}
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        for k, v in pplan.stage_ms().items():
-            pair_ms[k] += v / args.steps
-        g = plan.groups()
-        if groups_acc is None:
-            groups_acc = g
-        else:
-            for x, y in zip(groups_acc, g):
-                x["ms"] += y["ms"]
+    stats = [step() for _ in range(args.steps)]
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    for x in groups_acc:
-        x["ms"] /= args.steps
 
-    out = None
     if rank == 0:
-        # reference-accurate cell count of one step: from the oracle's own accounting on a tile
-        base = None
-        if world == 1 and not args.no_cpu:
-            base, cres, cstr = cpu_baseline(tile, tile_arena, genomic, meta["n_est"], passes=8)
-            # the same tile on the GPU must agree with what the CPU just computed (bit-exact)
-            res, strings = plan.fetch()
-            for i in range(len(tile)):
-                k = int(tile["kind"][i])
-                a, b = capi.decode(k, res[i], strings), capi.decode(k, cres[i], cstr)
-                if a != b:
-                    raise SystemExit("bench: GPU result %d differs from the oracle: %r vs %r" % (i, a, b))
-        dom = max(groups_acc, key=lambda g: g["ms"])
-        tile_cells = base["cells"] if base else None
-        ms_step = dt / args.steps * 1e3
-        value = n_est * world / (dt / args.steps)
+        st = stats[-1]
+        kernels = {}
+        for s in stats:
+            for k in range(s.n_kernels):
+                ks = s.kernels[k]
+                d = kernels.setdefault(ks.name.decode(), dict(ms=0.0, launches=0, jobs=0, cells=0, algo_bytes=0))
+                d["ms"] += ks.ms / args.steps; d["launches"] += ks.launches / args.steps
+                d["jobs"] += ks.jobs / args.steps; d["cells"] += ks.cells / args.steps
+                d["algo_bytes"] += ks.algo_bytes / args.steps
+        step_s = dt / args.steps
         out = {
             "metric": "ESTs aligned/sec (whole node) + DP Mcells/s; bit-exact factorizations vs ref",
-            "value": value, "unit": "ESTs/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
+            "value": n_est * world / step_s, "unit": "ESTs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": step_s * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8/int32", "data": "synthetic",
             "config": {"workload": "C3: 200 kb genomic x %d ESTs ~600 bp, 3%% errors, per GPU" % n_est,
-                       "stages": "pairing stage (%d pattern positions, %d pairings) + batched DP stage (reference's own DP"
-                                 " call mix, %d calls) per step per GPU; MEG/embedding/filter host logic not yet in the step"
-                                 % (sum(len(x) for x in pats), pplan.ctx.L.pgpu_pairing_plan_count(pplan.h), len(jobs)),
-                       "ests_per_gpu": n_est, "dp_jobs_per_gpu": int(len(jobs)), "parallelism": "est-shard x%d" % world},
-            "dp_mcells_per_s": (tile_cells * n_tiles * world / (dt / args.steps) / 1e6) if tile_cells else None,
-            "roofline": {"bound": "hbm", "kernel": dom["name"], "achieved": dom["algo_bytes"] / (dom["ms"] * 1e-3) / 1e9 if dom["ms"] else None,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (dom["algo_bytes"] / (dom["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if dom["ms"] else None,
-                         "traffic": None, "avg_launch_ms": dom["ms"], "algo_bytes_per_launch": dom["algo_bytes"]},
-            "kernels": [{"name": g["name"], "jobs": g["jobs"], "ms": round(g["ms"], 4),
-                         "algo_GBs": round(g["algo_bytes"] / (g["ms"] * 1e-3) / 1e9, 1) if g["ms"] else None}
-                        for g in groups_acc] +
-                       [{"name": "pair_" + k, "jobs": len(pats), "ms": round(v, 4), "algo_GBs": None}
-                        for k, v in pair_ms.items()],
-            "index_build_s": t_index,
-            "upload_s": t_upload,
+                       "stages": "whole est-fact hot path per step: GPU pairings over the device index + host MEG/"
+                                 "embeddings/filters/refinement (%d threads, fibres) with all DPs batched on the GPU"
+                                 % st.threads,
+                       "ests_per_gpu": n_est, "aligned_per_gpu": int(st.aligned),
+                       "dp_jobs_per_step": int(st.dp_jobs), "dp_batches_per_step": int(st.dp_batches),
+                       "parallelism": "est-shard x%d" % world},
+            "dp_mcells_per_s": sum(k["cells"] for k in kernels.values()) * world / step_s / 1e6,
+            "phases_s": {"load_once": st.load_s, "index_once": st.index_s, "prefetch_pairings": st.prefetch_s,
+                         "workers_wall": st.workers_s, "host_cpu_per_thread": st.host_s / st.threads,
+                         "dp_batches_per_thread": st.dp_s / st.threads},
         }
-        if base:
-            out["cpu_baseline"] = {"value": base["ests_per_s"], "unit": "ESTs/s", "cores": 1, "kind": "port",
-                                   "sample": "DP stage of %d C3 ESTs (one fixture tile, %d DP calls, %.2f Gcells) x8 passes, %.1f s"
-                                             % (meta["n_est"], len(tile), base["cells"] / 1e9, base["seconds"]),
-                                   "mcells_per_s": base["mcells_per_s"]}
+        if kernels:
+            name, dom = max(kernels.items(), key=lambda kv: kv[1]["ms"])
+            per_launch_ms = dom["ms"] / max(dom["launches"], 1)
+            ach = dom["algo_bytes"] / (dom["ms"] * 1e-3) / 1e9 if dom["ms"] and dom["algo_bytes"] else None
+            out["roofline"] = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": ach / HBM_PEAK_GBS if ach else None, "traffic": None,
+                               "avg_launch_ms": per_launch_ms, "launches_per_step": dom["launches"],
+                               "algo_bytes_per_launch": dom["algo_bytes"] / max(dom["launches"], 1)}
+            out["kernels"] = [{"name": n, "ms_per_step": round(k["ms"], 3), "launches": round(k["launches"], 1),
+                               "jobs": int(k["jobs"]),
+                               "algo_GBs": round(k["algo_bytes"] / (k["ms"] * 1e-3) / 1e9, 1) if k["ms"] and k["algo_bytes"] else None}
+                              for n, k in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"])]
+        if world == 1 and not args.no_cpu:
+            # bounded sample of the same workload: reference CPU est-fact vs this code, byte for byte
+            sample = synth.make("C3", n_est=CPU_SAMPLE, seed=synth.CONFIGS["C3"]["seed"] + rank)
+            sdir_ref = tempfile.mkdtemp(prefix="pintron_bench_ref_")
+            sdir_gpu = tempfile.mkdtemp(prefix="pintron_bench_gpu_")
+            synth.write_files(sample, sdir_ref)
+            synth.write_files(sample, sdir_gpu)
+            cpu_s = cpu_reference(sdir_ref)
+            if cpu_s is not None:
+                s2 = Session(L, sdir_gpu)
+                s2.step()
+                got = s2.records()
+                s2.close()
+                ref = open(os.path.join(sdir_ref, "raw-multifasta-out.txt"), "rb").read()
+                if got != ref:
+                    raise SystemExit("bench: GPU est-fact output differs from the reference CPU est-fact on the sample")
+                out["cpu_baseline"] = {"value": CPU_SAMPLE / cpu_s, "unit": "ESTs/s", "cores": 1, "kind": "reference",
+                                       "sample": "first-seed C3 sample of %d ESTs through oracle/_ref/est-fact-ref "
+                                                 "(%.1f s); output byte-identical to this code's" % (CPU_SAMPLE, cpu_s)}
+                out["parity"] = {"sample_ests": CPU_SAMPLE, "raw_multifasta_md5": hashlib.md5(ref).hexdigest(), "identical": True}
+            shutil.rmtree(sdir_ref, ignore_errors=True)
+            shutil.rmtree(sdir_gpu, ignore_errors=True)
         print(json.dumps(out), flush=True)
-    plan.close()
-    pplan.close()
-    idx.close()
-    ctx.close()
+    sess.close()
+    shutil.rmtree(work, ignore_errors=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -58,6 +58,7 @@ typedef struct shared {
   /* pairings of every list entry at the configured (min_factor_len, rate), computed in ONE
    * resident batch before the fibres start; retries with a longer factor go through batches */
   pgpu_pairing* pre_tri; uint64_t* pre_first;
+  bool kernel_timing;
   int failed;
   ef_sched_stats stats;
 } shared;
@@ -72,6 +73,16 @@ typedef struct worker {
   pgpu_dp_result* results; size_t results_cap;
   ef_sched_stats stats;
 } worker;
+
+static void kstat_add(ef_sched_stats* st, const ef_kernel_stat* k) {
+  for (int i = 0; i < st->n_kernels; ++i)
+    if (!strcmp(st->kernels[i].name, k->name)) {
+      st->kernels[i].ms += k->ms; st->kernels[i].launches += k->launches; st->kernels[i].jobs += k->jobs;
+      st->kernels[i].cells += k->cells; st->kernels[i].algo_bytes += k->algo_bytes;
+      return;
+    }
+  if (st->n_kernels < EF_MAX_KERNELS) st->kernels[st->n_kernels++] = *k;
+}
 
 /* ---- fibre side ---------------------------------------------------------------------------------- */
 static int fiber_dp(void* self, const ef_dp_req* q, ef_dp_res* res) {
@@ -215,6 +226,17 @@ static int submit_dp(worker* w) {
     if (sb + 16 > w->strings_cap) { w->strings_cap = (sb + 16) * 2; w->strings = (char*)realloc(w->strings, w->strings_cap); }
     rc = pgpu_dp_plan_fetch(w->ctx, plan, w->results, w->strings, w->strings_cap);
   }
+  if (rc == PGPU_OK && sh->kernel_timing) {
+    const int ng = pgpu_dp_plan_n_groups(plan);
+    for (int g = 0; g < ng; ++g) {
+      pgpu_group_info gi;
+      if (pgpu_dp_plan_group_info(plan, g, &gi) != PGPU_OK) continue;
+      ef_kernel_stat ks; memset(&ks, 0, sizeof ks);
+      snprintf(ks.name, sizeof ks.name, "%s", gi.name);
+      ks.ms = gi.ms; ks.launches = 1; ks.jobs = gi.jobs; ks.cells = gi.cells; ks.algo_bytes = gi.algo_bytes;
+      kstat_add(&w->stats, &ks);
+    }
+  }
   if (plan) pgpu_dp_plan_destroy(w->ctx, plan);
   if (rc != PGPU_OK) { fprintf(stderr, "* FATAL DP batch failed: %s\n", pgpu_last_error(w->ctx)); free(wait); return rc; }
   for (size_t i = 0; i < nw; ++i) {
@@ -232,6 +254,7 @@ static void* worker_main(void* arg) {
   worker* w = (worker*)arg;
   shared* sh = w->sh;
   if (pgpu_init(ef_gpu_device_from_env(), &w->ctx) != PGPU_OK) { sh->failed = 1; return NULL; }
+  if (sh->kernel_timing) pgpu_set_timing(w->ctx, 1);
   w->fibers = (fiber**)malloc(sh->max_fibers * sizeof(fiber*));
   ef_jobbuf_init(&w->jb);
   bool more = true;
@@ -272,104 +295,183 @@ static size_t env_size(const char* name, size_t dflt) {
   return (v && atol(v) > 0) ? (size_t)atol(v) : dflt;
 }
 
-int ef_run_batched_stats(int argc, char** argv, ef_sched_stats* stats_out) {
-  const double t_start = now_s();
+/* ---- sessions: inputs + index + patterns resident; a step = the whole per-EST pipeline ------------ */
+struct ef_session {
   ef_inputs in;
-  int rc = ef_load_inputs(argc, argv, &in);
-  if (rc) return rc;
-  ef_outputs out;
-  if (ef_open_outputs(&out)) return 1;
+  pgpu_ctx* ctx0;
+  shared sh;
+  pgpu_pairing_plan* pplan;     /* all prepared sequences (both strands), resident in HBM */
+  size_t nthreads;
+  double load_s, index_s;
+};
+
+ef_session* ef_session_open(int argc, char** argv) {
+  const double t_start = now_s();
+  ef_session* s = (ef_session*)calloc(1, sizeof(ef_session));
+  if (ef_load_inputs(argc, argv, &s->in) != 0) { free(s); return NULL; }
   ef_classify_init();
   const double t_loaded = now_s();
-  pgpu_ctx* ctx0 = NULL;
-  if (pgpu_init(ef_gpu_device_from_env(), &ctx0) != PGPU_OK) {
+  if (pgpu_init(ef_gpu_device_from_env(), &s->ctx0) != PGPU_OK) {
     fprintf(stderr, "* FATAL no usable MI355X (gfx950) device / libpintron_gpu.so: est-fact has no CPU fallback\n");
-    return 1;
+    free(s); return NULL;
   }
-  shared sh;
-  memset(&sh, 0, sizeof sh);
-  sh.in = &in;
-  if (pgpu_index_build(ctx0, in.gen->seq, strlen(in.gen->seq), &sh.idx) != PGPU_OK) {
-    fprintf(stderr, "* FATAL pgpu_index_build: %s\n", pgpu_last_error(ctx0));
-    return 1;
+  ef_inputs* in = &s->in;
+  shared* sh = &s->sh;
+  sh->in = in;
+  if (getenv("PINTRON_KERNEL_TIMING")) pgpu_set_timing(s->ctx0, 1);
+  if (pgpu_index_build(s->ctx0, in->gen->seq, strlen(in->gen->seq), &sh->idx) != PGPU_OK) {
+    fprintf(stderr, "* FATAL pgpu_index_build: %s\n", pgpu_last_error(s->ctx0));
+    free(s); return NULL;
   }
-  /* pairing prefetch: all prepared sequences (both strands) in one batch */
-  if (!getenv("PINTRON_NO_PREFETCH") && in.n > 0) {
+  if (!getenv("PINTRON_NO_PREFETCH") && in->n > 0) {
     size_t total = 0;
-    for (size_t k = 0; k < in.n; ++k) total += strlen(in.list[k]->seq);
+    for (size_t k = 0; k < in->n; ++k) total += strlen(in->list[k]->seq);
     char* blob = (char*)malloc(total + 1);
-    uint64_t* off = (uint64_t*)malloc((in.n + 1) * sizeof(uint64_t));
+    uint64_t* off = (uint64_t*)malloc((in->n + 1) * sizeof(uint64_t));
     size_t pos = 0;
-    for (size_t k = 0; k < in.n; ++k) { const size_t m = strlen(in.list[k]->seq); off[k] = pos; memcpy(blob + pos, in.list[k]->seq, m); pos += m; }
-    off[in.n] = pos;
-    pgpu_pairing_plan* pp = NULL;
-    pgpu_pairing_params prm = { in.cfg.min_factor_len, 0, in.cfg.min_string_depth_rate };
-    int prc = pgpu_pairing_plan_create(ctx0, sh.idx, blob, off, in.n, &pp);
-    if (prc == PGPU_OK) prc = pgpu_pairing_plan_run(ctx0, pp, &prm);
-    if (prc == PGPU_OK) {
-      const size_t cnt = (size_t)pgpu_pairing_plan_count(pp);
-      sh.pre_tri = (pgpu_pairing*)malloc((cnt + 1) * sizeof(pgpu_pairing));
-      sh.pre_first = (uint64_t*)malloc((in.n + 1) * sizeof(uint64_t));
-      prc = pgpu_pairing_plan_fetch(ctx0, pp, sh.pre_tri, cnt, sh.pre_first);
-    }
-    if (pp) pgpu_pairing_plan_destroy(ctx0, pp);
+    for (size_t k = 0; k < in->n; ++k) { const size_t m = strlen(in->list[k]->seq); off[k] = pos; memcpy(blob + pos, in->list[k]->seq, m); pos += m; }
+    off[in->n] = pos;
+    const int prc = pgpu_pairing_plan_create(s->ctx0, sh->idx, blob, off, in->n, &s->pplan);
     free(blob); free(off);
-    if (prc != PGPU_OK) { fprintf(stderr, "* FATAL pairing prefetch failed: %s\n", pgpu_last_error(ctx0)); return 1; }
+    if (prc != PGPU_OK) { fprintf(stderr, "* FATAL pairing plan: %s\n", pgpu_last_error(s->ctx0)); free(s); return NULL; }
   }
-  const double t_index = now_s();
-  /* units: forward entry (+ sibling) */
-  sh.units = (unit*)calloc(in.n + 1, sizeof(unit));
-  for (size_t k = 0; k < in.n;) {
-    unit* u = &sh.units[sh.n_units++];
+  sh->units = (unit*)calloc(in->n + 1, sizeof(unit));
+  for (size_t k = 0; k < in->n;) {
+    unit* u = &sh->units[sh->n_units++];
     u->first = k;
-    u->has_sibling = !in.list[k]->fixed_strand;
+    u->has_sibling = !in->list[k]->fixed_strand;
     k += u->has_sibling ? 2 : 1;
   }
-  pthread_mutex_init(&sh.mu, NULL);
+  pthread_mutex_init(&sh->mu, NULL);
   const long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
   /* default: the host share of one GPU on an 8-GPU node (the GPU boxes expose far more cores) */
-  size_t nthreads = env_size("PINTRON_THREADS", ncpu > 16 ? 16 : (ncpu > 0 ? (size_t)ncpu : 1));
-  if (nthreads > sh.n_units) nthreads = sh.n_units ? sh.n_units : 1;
-  sh.max_fibers = env_size("PINTRON_FIBERS", 2048);
-  sh.stack_size = env_size("PINTRON_FIBER_STACK_KB", 256) * 1024;
-  worker* ws = (worker*)calloc(nthreads, sizeof(worker));
-  pthread_t* th = (pthread_t*)malloc(nthreads * sizeof(pthread_t));
-  for (size_t t = 0; t < nthreads; ++t) { ws[t].sh = &sh; pthread_create(&th[t], NULL, worker_main, &ws[t]); }
-  for (size_t t = 0; t < nthreads; ++t) pthread_join(th[t], NULL);
+  s->nthreads = env_size("PINTRON_THREADS", ncpu > 16 ? 16 : (ncpu > 0 ? (size_t)ncpu : 1));
+  if (s->nthreads > sh->n_units) s->nthreads = sh->n_units ? sh->n_units : 1;
+  sh->max_fibers = env_size("PINTRON_FIBERS", 2048);
+  sh->stack_size = env_size("PINTRON_FIBER_STACK_KB", 256) * 1024;
+  sh->kernel_timing = getenv("PINTRON_KERNEL_TIMING") != NULL;
+  s->load_s = t_loaded - t_start;
+  s->index_s = now_s() - t_loaded;
+  return s;
+}
+
+static void free_unit_buffers(shared* sh) {
+  for (size_t u = 0; u < sh->n_units; ++u)
+    for (int k = 0; k < 6; ++k) { free(sh->units[u].buf[k]); sh->units[u].buf[k] = NULL; sh->units[u].len[k] = 0; }
+}
+
+/* one pass of the whole hot path over the batch: pairing prefetch (resident patterns), then the
+ * fibres (MEG, embeddings, DP batches, refinement) on all worker threads */
+int ef_session_step(ef_session* s, ef_sched_stats* stats_out) {
+  shared* sh = &s->sh;
+  const double t0 = now_s();
+  free_unit_buffers(sh);
+  free(sh->pre_tri); free(sh->pre_first); sh->pre_tri = NULL; sh->pre_first = NULL;
+  sh->next_unit = 0; sh->failed = 0;
+  if (s->pplan) {
+    pgpu_pairing_params prm = { s->in.cfg.min_factor_len, 0, s->in.cfg.min_string_depth_rate };
+    int prc = pgpu_pairing_plan_run(s->ctx0, s->pplan, &prm);
+    if (prc == PGPU_OK) {
+      const size_t cnt = (size_t)pgpu_pairing_plan_count(s->pplan);
+      sh->pre_tri = (pgpu_pairing*)malloc((cnt + 1) * sizeof(pgpu_pairing));
+      sh->pre_first = (uint64_t*)malloc((s->in.n + 1) * sizeof(uint64_t));
+      prc = pgpu_pairing_plan_fetch(s->ctx0, s->pplan, sh->pre_tri, cnt, sh->pre_first);
+    }
+    if (prc != PGPU_OK) { fprintf(stderr, "* FATAL pairing prefetch failed: %s\n", pgpu_last_error(s->ctx0)); return 1; }
+  }
+  const double t1 = now_s();
+  worker* ws = (worker*)calloc(s->nthreads, sizeof(worker));
+  pthread_t* th = (pthread_t*)malloc(s->nthreads * sizeof(pthread_t));
+  for (size_t t = 0; t < s->nthreads; ++t) { ws[t].sh = sh; pthread_create(&th[t], NULL, worker_main, &ws[t]); }
+  for (size_t t = 0; t < s->nthreads; ++t) pthread_join(th[t], NULL);
   ef_sched_stats st;
   memset(&st, 0, sizeof st);
-  st.threads = nthreads;
-  for (size_t t = 0; t < nthreads; ++t) {
+  st.threads = s->nthreads;
+  for (size_t t = 0; t < s->nthreads; ++t) {
     st.units += ws[t].stats.units; st.dp_batches += ws[t].stats.dp_batches; st.dp_jobs += ws[t].stats.dp_jobs;
     st.pairing_batches += ws[t].stats.pairing_batches; st.pairing_requests += ws[t].stats.pairing_requests;
     st.host_s += ws[t].stats.host_s; st.pairing_s += ws[t].stats.pairing_s; st.dp_s += ws[t].stats.dp_s;
+    for (int k = 0; k < ws[t].stats.n_kernels; ++k) kstat_add(&st, &ws[t].stats.kernels[k]);
   }
-  st.load_s = t_loaded - t_start; st.index_s = t_index - t_loaded; st.workers_s = now_s() - t_index;
+  if (s->pplan) {
+    static const char* nm[6] = { "pair_locate", "pair_chain", "pair_count+scan", "pair_fill", "pair_cross+scan", "pair_emit" };
+    for (int k = 0; k < 6; ++k) {
+      ef_kernel_stat ks; memset(&ks, 0, sizeof ks);
+      snprintf(ks.name, sizeof ks.name, "%s", nm[k]);
+      ks.ms = pgpu_pairing_plan_kernel_ms(s->pplan, k); ks.launches = 1; ks.jobs = s->in.n;
+      if (ks.ms > 0) kstat_add(&st, &ks);
+    }
+  }
+  st.load_s = s->load_s; st.index_s = s->index_s; st.prefetch_s = t1 - t0; st.workers_s = now_s() - t1;
+  for (size_t u = 0; u < sh->n_units; ++u) if (sh->units[u].len[1]) ++st.aligned;
   if (stats_out) *stats_out = st;
-  rc = sh.failed ? 1 : 0;
-  if (!rc) {
-    FILE* dst[6] = { out.fout, out.fests, out.side.fmeg, out.side.fpmeg, out.side.ftmeg, out.side.fintronic };
-    for (size_t u = 0; u < sh.n_units; ++u)
-      for (int k = 0; k < 6; ++k) {
-        if (sh.units[u].len[k]) fwrite(sh.units[u].buf[k], 1, sh.units[u].len[k], dst[k]);
-        free(sh.units[u].buf[k]);
-      }
-  }
-  free(ws); free(th); free(sh.units); free(sh.pre_tri); free(sh.pre_first);
-  pgpu_index_destroy(ctx0, sh.idx);
-  pgpu_destroy(ctx0);
+  free(ws); free(th);
+  return sh->failed ? 1 : 0;
+}
+
+/* the six files of the step, in input order, into the current directory */
+int ef_session_write_outputs(ef_session* s) {
+  ef_outputs out;
+  if (ef_open_outputs(&out)) return 1;
+  shared* sh = &s->sh;
+  FILE* dst[6] = { out.fout, out.fests, out.side.fmeg, out.side.fpmeg, out.side.ftmeg, out.side.fintronic };
+  for (int k = 0; k < 6; ++k) setvbuf(dst[k], NULL, _IOFBF, 1 << 20);
+  for (size_t u = 0; u < sh->n_units; ++u)
+    for (int k = 0; k < 6; ++k)
+      if (sh->units[u].len[k]) fwrite(sh->units[u].buf[k], 1, sh->units[u].len[k], dst[k]);
   ef_close_outputs(&out);
-  ef_free_inputs(&in);
+  return 0;
+}
+
+/* raw-multifasta-out records of the last step (concatenated, input order); caller frees */
+char* ef_session_records(ef_session* s, size_t* len) {
+  shared* sh = &s->sh;
+  size_t total = 0;
+  for (size_t u = 0; u < sh->n_units; ++u) total += sh->units[u].len[0];
+  char* r = (char*)malloc(total + 1);
+  size_t pos = 0;
+  for (size_t u = 0; u < sh->n_units; ++u) { memcpy(r + pos, sh->units[u].buf[0], sh->units[u].len[0]); pos += sh->units[u].len[0]; }
+  r[pos] = '\0';
+  *len = total;
+  return r;
+}
+
+size_t ef_session_n_ests(const ef_session* s) { return s->sh.n_units; }
+
+void ef_session_close(ef_session* s) {
+  if (!s) return;
+  shared* sh = &s->sh;
+  free_unit_buffers(sh);
+  free(sh->units); free(sh->pre_tri); free(sh->pre_first);
+  if (s->pplan) pgpu_pairing_plan_destroy(s->ctx0, s->pplan);
+  pgpu_index_destroy(s->ctx0, sh->idx);
+  pgpu_destroy(s->ctx0);
+  ef_free_inputs(&s->in);
+  free(s);
+}
+
+int ef_run_batched_stats(int argc, char** argv, ef_sched_stats* stats_out) {
+  ef_session* s = ef_session_open(argc, argv);
+  if (!s) return 1;
+  ef_sched_stats st;
+  int rc = ef_session_step(s, &st);
+  if (rc == 0) rc = ef_session_write_outputs(s);
+  if (stats_out) *stats_out = st;
+  ef_session_close(s);
   return rc;
 }
 
 int ef_run_batched(int argc, char** argv) {
   ef_sched_stats st;
   const int rc = ef_run_batched_stats(argc, argv, &st);
-  if (rc == 0 && getenv("PINTRON_VERBOSE"))
-    fprintf(stderr, "est-fact: %zu ESTs, %zu threads, %zu pairing batches (%zu requests), %zu DP batches (%zu jobs); "
-                    "load %.2fs index %.2fs workers %.2fs [per-thread avg: host %.2fs pairing %.2fs dp %.2fs]\n",
-            st.units, st.threads, st.pairing_batches, st.pairing_requests, st.dp_batches, st.dp_jobs,
-            st.load_s, st.index_s, st.workers_s, st.host_s / st.threads, st.pairing_s / st.threads, st.dp_s / st.threads);
+  if (rc == 0 && getenv("PINTRON_VERBOSE")) {
+    fprintf(stderr, "est-fact: %zu ESTs (%zu aligned), %zu threads, %zu pairing batches (%zu requests), %zu DP batches (%zu jobs); "
+                    "load %.2fs index %.2fs prefetch %.2fs workers %.2fs [per-thread avg: host %.2fs pairing %.2fs dp %.2fs]\n",
+            st.units, st.aligned, st.threads, st.pairing_batches, st.pairing_requests, st.dp_batches, st.dp_jobs,
+            st.load_s, st.index_s, st.prefetch_s, st.workers_s, st.host_s / st.threads, st.pairing_s / st.threads, st.dp_s / st.threads);
+    for (int k = 0; k < st.n_kernels; ++k)
+      fprintf(stderr, "  kernel %-28s launches %6zu jobs %9zu  %9.3f ms  %8.1f algo-GB/s\n", st.kernels[k].name, st.kernels[k].launches,
+              st.kernels[k].jobs, st.kernels[k].ms, st.kernels[k].ms > 0 ? st.kernels[k].algo_bytes / (st.kernels[k].ms * 1e-3) / 1e9 : 0.0);
+  }
   return rc;
 }

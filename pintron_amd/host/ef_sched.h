@@ -3,11 +3,31 @@
 #define EF_SCHED_H
 #include <stddef.h>
 
+#define EF_MAX_KERNELS 64
 typedef struct {
-  size_t threads, units, dp_batches, dp_jobs, pairing_batches, pairing_requests;
-  double load_s, index_s, workers_s;      /* wall-clock phases */
+  char name[48];
+  double ms;                               /* summed HIP-event time of all launches */
+  size_t launches, jobs;
+  unsigned long long cells, algo_bytes;
+} ef_kernel_stat;
+
+typedef struct {
+  size_t threads, units, aligned, dp_batches, dp_jobs, pairing_batches, pairing_requests;
+  double load_s, index_s, prefetch_s, workers_s;   /* wall-clock phases */
   double host_s, pairing_s, dp_s;         /* summed over threads: fibres / pairing batches / DP batches */
+  int n_kernels;                          /* filled when PINTRON_KERNEL_TIMING is set */
+  ef_kernel_stat kernels[EF_MAX_KERNELS];
 } ef_sched_stats;
+
+/* session = inputs of the current directory loaded, genomic index and all prepared sequences
+ * resident in HBM; step = one pass of the whole est-fact hot path over the batch */
+typedef struct ef_session ef_session;
+ef_session* ef_session_open(int argc, char** argv);
+int ef_session_step(ef_session* s, ef_sched_stats* stats);
+int ef_session_write_outputs(ef_session* s);
+char* ef_session_records(ef_session* s, size_t* len);
+size_t ef_session_n_ests(const ef_session* s);
+void ef_session_close(ef_session* s);
 
 /* environment: PINTRON_THREADS (default: online CPUs), PINTRON_FIBERS (fibres per thread, 2048),
  * PINTRON_FIBER_STACK_KB (256), PINTRON_GPU_DEVICE (0), PINTRON_VERBOSE */
