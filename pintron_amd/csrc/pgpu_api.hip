@@ -236,13 +236,9 @@ extern "C" int pgpu_dp_plan_create(pgpu_ctx* ctx, const pgpu_index* idx, const p
         k.family = KF_ED; k.R = row_class(std::min(la, lb)); k.size = (uint64_t)la * lb; break;
       case PGPU_DP_KBAND: {
         const uint32_t n = std::max(la, lb), m = std::min(la, lb), ub = in.p0;
-        if (n > PGPU_MAX_COLS) continue;
-        if (ub > 0 && n - m <= ub && 2ull * ub + 1 >= n) {      // full-matrix fallback of the reference
-          if (m > PGPU_MAX_ROWS_LEV) continue;
-          k.family = KF_KBAND_FULL; k.R = row_class(m); k.size = (uint64_t)la * lb;
-        } else {
-          k.family = KF_KBAND; k.R = 0; k.size = (uint64_t)m * (2ull * ub + 1);
-        }
+        if (n > PGPU_MAX_COLS || m > PGPU_MAX_ROWS_LEV) continue;
+        k.family = KF_KBAND; k.R = row_class(m);
+        k.size = (2ull * ub + 1 >= n) ? (uint64_t)la * lb : (uint64_t)m * (2ull * ub + 1);
         break;
       }
       case PGPU_DP_LCF:
@@ -279,8 +275,6 @@ extern "C" int pgpu_dp_plan_create(pgpu_ctx* ctx, const pgpu_index* idx, const p
     } else if (k.family == KF_GAP) {
       k.j.ws_off = ws; ws += ((size_t)lb + 64) * 64 * gap_entry_bytes(k.R);
       k.j.str_off = strs; strs += 2 * ((size_t)la + lb + 1);
-    } else if (k.family == KF_KBAND) {
-      k.j.ws_off = ws; ws += (2 * (2 * (size_t)k.j.p0 + 1) * sizeof(uint32_t) + 15) & ~(size_t)15;
     } else if (k.family == KF_LCF) {
       ++nkeys;
     }
@@ -315,9 +309,9 @@ extern "C" int pgpu_dp_plan_create(pgpu_ctx* ctx, const pgpu_index* idx, const p
     }
     g.count = j - i;
     char nm[64];
-    static const char* fam[] = {"lev_wave<ALIGN", "gap_wave<", "lev_wave<ED", "kband", "lcf",
-                                "lev_wave<BORDERS", "lev_wave<AFFIX", "lev_wave<ED(kband-full)"};
-    if (g.family == KF_KBAND || g.family == KF_LCF) snprintf(nm, sizeof nm, "%s", fam[g.family]);
+    static const char* fam[] = {"lev_wave<ALIGN", "gap_wave<", "lev_wave<ED", "lev_wave<KBAND", "lcf",
+                                "lev_wave<BORDERS", "lev_wave<AFFIX"};
+    if (g.family == KF_LCF) snprintf(nm, sizeof nm, "%s", fam[g.family]);
     else snprintf(nm, sizeof nm, "%s%sR=%d>", fam[g.family], g.family == KF_GAP ? "" : ",", g.R);
     g.name = nm;
     p->groups.push_back(g);
@@ -381,13 +375,9 @@ extern "C" int pgpu_dp_plan_launch(pgpu_ctx* ctx, pgpu_dp_plan* p) {
       if (g.family == KF_ALIGN) launch_align_traceback(jobs, n, p->d_results, p->d_ws, p->d_strs, st);
       else launch_gap_traceback(jobs, n, p->d_results, p->d_ws, p->d_strs, st);
     } else switch (g.family) {
-      case KF_ALIGN: case KF_ED: case KF_BORDERS: case KF_AFFIX:
+      case KF_ALIGN: case KF_ED: case KF_BORDERS: case KF_AFFIX: case KF_KBAND:
         launch_lev(g.family, g.R, jobs, n, p->d_results, p->d_ws, st); break;
-      case KF_KBAND_FULL:
-        launch_lev(KF_ED, g.R, jobs, n, p->d_results, p->d_ws, st);
-        launch_kband_full_fixup(jobs, n, p->d_results, st); break;
       case KF_GAP: launch_gap(g.R, jobs, n, p->d_results, p->d_ws, st); break;
-      case KF_KBAND: launch_kband(jobs, n, p->d_results, p->d_ws, st); break;
       case KF_LCF:
         launch_lcf(jobs, n, g.max_chunks, g.max_l2, p->d_keys + key_base, st);
         launch_lcf_finish(jobs, n, p->d_results, p->d_keys + key_base, st);

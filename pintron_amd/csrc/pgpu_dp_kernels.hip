@@ -115,12 +115,14 @@ struct AffixBest {          // running best cut of find_longest_affix
 };
 
 // One column sweep.  On return cur[r] = M[row(l,r)][nc].
-template <int R, bool WILD, bool DIRS, bool ROWMIN, bool AFFIX>
+constexpr uint32_t BAND_INF = 0x3FFFFFu;   // "outside the band"; stays below the 24-bit value field
+
+template <int R, bool WILD, bool DIRS, bool ROWMIN, bool AFFIX, bool BAND = false>
 __device__ __forceinline__ void lev_sweep(const Operand rows, const uint32_t nr,
                                           const Operand cols, const uint32_t nc,
                                           const uint32_t lane, uint32_t (&cur)[R],
                                           uint32_t (&minv)[R], uint32_t (&minpos)[R],
-                                          AffixBest& best, uint8_t* dir_ws) {
+                                          AffixBest& best, uint8_t* dir_ws, const uint32_t band_k = 0) {
   uint32_t rc[R];                       // row characters of this lane's strip
   const uint32_t row0 = lane * R;       // rows row0+1 .. row0+R
 #pragma unroll
@@ -128,6 +130,7 @@ __device__ __forceinline__ void lev_sweep(const Operand rows, const uint32_t nr,
     const uint32_t i = row0 + r;
     rc[r] = i < nr ? rows.at(i) : PAD_ROW;
     cur[r] = i + 1;                     // M[i+1][0]
+    if constexpr (BAND) { if (i + 1 > band_k) cur[r] = BAND_INF; }
     if constexpr (ROWMIN) { minv[r] = i + 1; minpos[r] = 0; }
   }
   if (nr == 0 || nc == 0) return;
@@ -146,7 +149,11 @@ __device__ __forceinline__ void lev_sweep(const Operand rows, const uint32_t nr,
     }
     uint32_t in = wave_shr1(out);
     const uint32_t ch0 = (uint32_t)__builtin_amdgcn_readlane((int)chunk, (int)t);
-    if (lane == 0) in = (s + 1) | (ch0 << 24);          // M[0][j] = j, j = s+1
+    if (lane == 0) {
+      uint32_t top = s + 1;                                // M[0][j] = j, j = s+1
+      if constexpr (BAND) { if (top > band_k) top = BAND_INF; }
+      in = top | (ch0 << 24);
+    }
     const uint32_t j = s - lane + 1;                     // column of this lane (wraps when idle)
     if (j - 1u < nc) {
       const uint32_t ch = in >> 24;
@@ -170,6 +177,12 @@ __device__ __forceinline__ void lev_sweep(const Operand rows, const uint32_t nr,
           dp.set(r, d);
         } else {
           v = min(v, min(up + 1, left + 1));
+        }
+        if constexpr (BAND) {
+          // K_band_edit_distance keeps cells with |column - row| <= k only; neighbours outside
+          // the band do not take part in the minimum (src/compute-alignments.c:375-443)
+          const uint32_t row = row0 + r + 1;
+          v = (j + band_k >= row && row + band_k >= j) ? min(v, BAND_INF) : BAND_INF;
         }
         if constexpr (ROWMIN) {
           if (minv[r] > v) { minv[r] = v; minpos[r] = j; }   // strict: first arg-min
@@ -202,7 +215,7 @@ __device__ __forceinline__ void store_row_value(const uint32_t (&a)[R], uint32_t
     if (lane * R + r + 1 == row) *dst = (int32_t)a[r];
 }
 
-enum { MODE_ED = 0, MODE_ALIGN = 1, MODE_BORDERS = 2, MODE_AFFIX = 3 };
+enum { MODE_ED = 0, MODE_ALIGN = 1, MODE_BORDERS = 2, MODE_AFFIX = 3, MODE_KBAND = 4 };
 
 // MODE_ED      edit_distance last cell (src/refine.c:50-83) / compute_edit_distance
 //              (src/compute-alignments.c:240-249)
@@ -289,6 +302,33 @@ void lev_wave_kernel(const DevJob* __restrict__ jobs, int njobs, DevResult* __re
       res->v[1] = (int32_t)off_p; res->v[2] = (int32_t)off_t1;
       res->v[3] = (int32_t)(len_t - off_t2); res->v[4] = (int32_t)bestv;
     }
+  } else if constexpr (MODE == MODE_KBAND) {
+    // K_band_edit_distance (src/compute-alignments.c:319-453): early exits in the reference's
+    // order, then the banded DP (or the full matrix when 2k+1 >= n, :370-373).  rows = shorter.
+    const uint32_t ub = job.p0;
+    const bool swap = job.la < job.lb;                       // reference: seq1 becomes the longer
+    const uint8_t* lng = swap ? job.b : job.a; const uint8_t* sht = swap ? job.a : job.b;
+    const uint32_t n = swap ? job.lb : job.la, m = swap ? job.la : job.lb;
+    bool same = n == m;
+    if (same) for (uint32_t i = lane; i < n; i += 64) same = same && lng[i] == sht[i];
+    same = __all(same);
+    if (same || ub == 0 || n - m > ub) {
+      if (lane == 0) {
+        res->status = 0;
+        if (same) { res->v[0] = 1; res->v[1] = 0; }
+        else if (ub == 0) { res->v[0] = 0; res->v[1] = 1; }
+        else { res->v[0] = 0; res->v[1] = (int32_t)(n - m); }
+      }
+      return;
+    }
+    const bool banded = !(2ull * ub + 1 >= n);
+    const Operand rows{sht, 0, false}, cols{lng, 0, false};
+    if (banded) lev_sweep<R, false, false, false, false, true>(rows, m, cols, n, lane, cur, minv, minpos, best, nullptr, ub);
+    else        lev_sweep<R, false, false, false, false, false>(rows, m, cols, n, lane, cur, minv, minpos, best, nullptr);
+    if (m == 0) { if (lane == 0) { res->status = 0; res->v[1] = (int32_t)n; res->v[0] = n <= ub ? 1 : 0; } return; }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      if (lane * R + r + 1 == m) { res->status = 0; res->v[1] = (int32_t)cur[r]; res->v[0] = cur[r] <= ub ? 1 : 0; }
   } else {  // MODE_AFFIX
     const Operand rows{job.a, 0, false}, cols{job.b, 0, false};
     lev_sweep<R, false, false, false, true>(rows, job.la, cols, job.lb, lane, cur, minv, minpos, best, nullptr);
@@ -497,104 +537,6 @@ void gap_traceback_kernel(const DevJob* __restrict__ jobs, int njobs,
 }
 
 // ---------------------------------------------------------------------------------------------
-// K-band edit distance: K_band_edit_distance (src/compute-alignments.c:319-453).
-// One thread per job (bands are 2k+1 <= a few dozen cells wide and there are ~10 jobs per EST);
-// the two rolling band rows live in a per-job HBM scratch (L1/L2 resident).  The loops mirror
-// the reference's three row ranges exactly, including which slots each row writes.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64)
-void kband_kernel(const DevJob* __restrict__ jobs, int njobs, DevResult* __restrict__ results,
-                  uint8_t* __restrict__ ws) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= njobs) return;
-  const DevJob job = jobs[t];
-  DevResult* res = &results[job.out_idx];
-  res->status = 0;
-  const uint32_t ub = job.p0;
-  uint32_t n = job.la, m = job.lb;
-  const uint8_t* lng = job.a; const uint8_t* sht = job.b;
-  bool same = n == m;
-  for (uint32_t i = 0; same && i < n; ++i) same = lng[i] == sht[i];
-  if (same) { res->v[0] = 1; res->v[1] = 0; return; }
-  if (ub == 0) { res->v[0] = 0; res->v[1] = 1; return; }
-  if (n < m) { const uint8_t* p = lng; lng = sht; sht = p; const uint32_t x = n; n = m; m = x; }
-  if (n - m > ub) { res->v[0] = 0; res->v[1] = (int32_t)(n - m); return; }
-  const uint32_t k = ub;
-  // (2k+1 >= n falls back to the full matrix in the reference; the host routes those jobs to the
-  //  Levenshtein wave kernel and patches v[0], so they never reach this kernel)
-  const uint32_t W = 2 * k + 1;
-  uint32_t* A = reinterpret_cast<uint32_t*>(ws + job.ws_off);
-  uint32_t* B = A + W;
-  for (uint32_t c = 0; c < W; ++c) { A[c] = 0; B[c] = k + 1; }
-  for (uint32_t c = 0; c <= k; ++c) A[k + c] = c;
-  uint32_t d;
-  for (uint32_t r = 1; r <= k; ++r) {
-    const uint32_t sc = sht[r - 1];
-    B[k - r] = r;
-    for (uint32_t c = 1; c < r + k; ++c) {
-      d = A[k - r + c] + (lng[c - 1] != sc);
-      d = min(d, B[k - r + c - 1] + 1);
-      d = min(d, A[k - r + c + 1] + 1);
-      B[k - r + c] = d;
-    }
-    d = A[2 * k] + (lng[r + k - 1] != sc);
-    d = min(d, B[2 * k - 1] + 1);
-    B[2 * k] = d;
-    uint32_t* x = A; A = B; B = x;
-  }
-  for (uint32_t r = k + 1; r <= n - k; ++r) {
-    const uint32_t sc = sht[r - 1];
-    d = A[0] + (lng[r - k - 1] != sc);
-    B[0] = min(d, A[1] + 1);
-    for (uint32_t c = r + 1 - k; c < r + k; ++c) {
-      d = A[c + k - r] + (lng[c - 1] != sc);
-      d = min(d, B[c + k - r - 1] + 1);
-      d = min(d, A[c + k - r + 1] + 1);
-      B[c + k - r] = d;
-    }
-    d = A[2 * k] + (lng[r + k - 1] != sc);
-    d = min(d, B[2 * k - 1] + 1);
-    B[2 * k] = d;
-    uint32_t* x = A; A = B; B = x;
-  }
-  for (uint32_t r = n + 1 - k; r <= m; ++r) {
-    const uint32_t sc = sht[r - 1];
-    d = A[0] + (lng[r - k - 1] != sc);
-    B[0] = min(d, A[1] + 1);
-    for (uint32_t c = r + 1 - k; c <= n; ++c) {
-      d = A[c + k - r] + (lng[c - 1] != sc);
-      d = min(d, B[c + k - r - 1] + 1);
-      d = min(d, A[c + k - r + 1] + 1);
-      B[c + k - r] = d;
-    }
-    uint32_t* x = A; A = B; B = x;
-  }
-  const uint32_t result = A[n + k - m];
-  res->v[0] = result <= ub ? 1 : 0;
-  res->v[1] = (int32_t)result;
-}
-
-// K_band_edit_distance jobs with 2k+1 >= n use the full matrix in the reference
-// (src/compute-alignments.c:370-373).  They run through the Levenshtein wave kernel (v[0] =
-// distance); this pass rewrites the result the way the reference's early exits order it:
-// equal strings -> (0,true); upper_bound 0 -> (1,false); |n-m| > ub -> (|n-m|,false).
-__global__ void kband_full_fixup_kernel(const DevJob* __restrict__ jobs, int njobs,
-                                        DevResult* __restrict__ results) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= njobs) return;
-  const DevJob job = jobs[t];
-  DevResult* res = &results[job.out_idx];
-  const uint32_t dist = (uint32_t)res->v[0], ub = job.p0;
-  const uint32_t diff = job.la > job.lb ? job.la - job.lb : job.lb - job.la;
-  uint32_t edit; int ok;
-  if (dist == 0) { edit = 0; ok = 1; }
-  else if (ub == 0) { edit = 1; ok = 0; }
-  else if (diff > ub) { edit = diff; ok = 0; }
-  else { edit = dist; ok = dist <= ub; }
-  res->v[0] = ok; res->v[1] = (int32_t)edit;
-}
-
-// ---------------------------------------------------------------------------------------------
 // Longest common factor with N wildcard: find_longest_common_factor_dp
 // (src/factorization-refinement.c:255-316).  curr[i2+1] = match ? prev[i2]+1 : 0 only couples
 // cells of one diagonal, so the l1+l2-1 diagonals are independent: one thread per diagonal,
@@ -716,6 +658,7 @@ void launch_lev(int family, int R, const DevJob* jobs, int njobs, DevResult* res
     case KF_ALIGN:   launch_lev_mode<MODE_ALIGN>(R, jobs, njobs, res, ws, st); break;
     case KF_BORDERS: launch_lev_mode<MODE_BORDERS>(R, jobs, njobs, res, ws, st); break;
     case KF_AFFIX:   launch_lev_mode<MODE_AFFIX>(R, jobs, njobs, res, ws, st); break;
+    case KF_KBAND:   launch_lev_mode<MODE_KBAND>(R, jobs, njobs, res, ws, st); break;
     default: break;
   }
 }
@@ -745,11 +688,6 @@ void launch_gap_traceback(const DevJob* jobs, int njobs, DevResult* res, const u
   hipLaunchKernelGGL(gap_traceback_kernel, dim3((njobs + 63) / 64), dim3(64), 0, st, jobs, njobs, res, ws, strs);
 }
 
-void launch_kband(const DevJob* jobs, int njobs, DevResult* res, uint8_t* ws, hipStream_t st) {
-  if (njobs <= 0) return;
-  hipLaunchKernelGGL(kband_kernel, dim3((njobs + 63) / 64), dim3(64), 0, st, jobs, njobs, res, ws);
-}
-
 void launch_lcf(const DevJob* jobs, int njobs, uint32_t max_chunks, uint32_t max_l2,
                 unsigned long long* keys, hipStream_t st) {
   if (njobs <= 0) return;
@@ -758,11 +696,6 @@ void launch_lcf(const DevJob* jobs, int njobs, uint32_t max_chunks, uint32_t max
   // LDS: s2 (rounded to 16) + s1 tile (256 + l2 - 1), sized for the largest l2 of the launch
   const size_t lds = ((max_l2 + 15u) & ~15u) + LCF_BLOCK + max_l2;
   hipLaunchKernelGGL(lcf_kernel, dim3(gx, njobs), dim3(LCF_BLOCK), lds, st, jobs, njobs, keys);
-}
-
-void launch_kband_full_fixup(const DevJob* jobs, int njobs, DevResult* res, hipStream_t st) {
-  if (njobs <= 0) return;
-  hipLaunchKernelGGL(kband_full_fixup_kernel, dim3((njobs + 255) / 256), dim3(256), 0, st, jobs, njobs, res);
 }
 
 void launch_lcf_finish(const DevJob* jobs, int njobs, DevResult* res,

@@ -23,7 +23,7 @@ using DevResult = pgpu_dp_result;
 
 // kernel families (one launch group per family and row class)
 enum KernelFamily {
-  KF_ALIGN = 0, KF_GAP, KF_ED, KF_KBAND, KF_LCF, KF_BORDERS, KF_AFFIX, KF_KBAND_FULL, KF_COUNT
+  KF_ALIGN = 0, KF_GAP, KF_ED, KF_KBAND, KF_LCF, KF_BORDERS, KF_AFFIX, KF_COUNT
 };
 
 // launchers (pgpu_dp_kernels.hip)
@@ -34,10 +34,8 @@ void launch_align_traceback(const DevJob* jobs, int njobs, DevResult* res, const
 void launch_gap(int R, const DevJob* jobs, int njobs, DevResult* res, uint8_t* ws, hipStream_t st);
 void launch_gap_traceback(const DevJob* jobs, int njobs, DevResult* res, const uint8_t* ws,
                           uint8_t* strs, hipStream_t st);
-void launch_kband(const DevJob* jobs, int njobs, DevResult* res, uint8_t* ws, hipStream_t st);
 void launch_lcf(const DevJob* jobs, int njobs, uint32_t max_chunks, uint32_t max_l2,
                 unsigned long long* keys, hipStream_t st);
-void launch_kband_full_fixup(const DevJob* jobs, int njobs, DevResult* res, hipStream_t st);
 void launch_lcf_finish(const DevJob* jobs, int njobs, DevResult* res,
                        const unsigned long long* keys, hipStream_t st);
 

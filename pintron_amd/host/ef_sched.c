@@ -36,6 +36,7 @@ typedef struct fiber {
   int state;
   size_t unit;
   size_t cur_entry;          /* entry of the prepared list being factorized */
+  int lane;
   /* pending request */
   ef_dp_req req; ef_dp_res* res; int rc;
   const char* pat; size_t pat_len; unsigned pat_L; double pat_rate; ef_triple** pat_out; size_t* pat_n;
@@ -59,18 +60,28 @@ typedef struct shared {
    * resident batch before the fibres start; retries with a longer factor go through batches */
   pgpu_pairing* pre_tri; uint64_t* pre_first;
   bool kernel_timing;
+  size_t gen_len;
   int failed;
   ef_sched_stats stats;
 } shared;
 
-typedef struct worker {
-  shared* sh;
+/* A worker keeps two independent sets of fibres ("lanes"), each with its own context (stream +
+ * device scratch): while the DP batch of one lane executes on the GPU, the fibres of the other
+ * lane run on the CPU, so host logic and device work of one thread overlap. */
+typedef struct lane {
   pgpu_ctx* ctx;
-  ucontext_t sched;
   fiber** fibers; size_t n_fibers;
   ef_jobbuf jb;
   char* strings; size_t strings_cap;
   pgpu_dp_result* results; size_t results_cap;
+  pgpu_dp_plan* plan;            /* batch in flight (launched, not yet fetched) */
+  fiber** inflight; size_t n_inflight;
+} lane;
+
+typedef struct worker {
+  shared* sh;
+  ucontext_t sched;
+  lane lanes[2];
   ef_sched_stats stats;
 } worker;
 
@@ -134,29 +145,30 @@ static void fiber_main(unsigned hi, unsigned lo) {
 }
 
 /* ---- worker side --------------------------------------------------------------------------------- */
-static bool start_fiber(worker* w) {
+static bool start_fiber(worker* w, int li) {
   shared* sh = w->sh;
+  lane* ln = &w->lanes[li];
   pthread_mutex_lock(&sh->mu);
   const size_t u = sh->next_unit < sh->n_units ? sh->next_unit++ : (size_t)-1;
   pthread_mutex_unlock(&sh->mu);
   if (u == (size_t)-1) return false;
   fiber* f = (fiber*)calloc(1, sizeof(fiber));
   f->stack = (char*)malloc(sh->stack_size);
-  f->w = w; f->unit = u; f->state = F_RUNNABLE;
+  f->w = w; f->unit = u; f->state = F_RUNNABLE; f->lane = li;
   f->be.self = f; f->be.pairings = fiber_pairings; f->be.dp = fiber_dp;
   getcontext(&f->ctx);
   f->ctx.uc_stack.ss_sp = f->stack; f->ctx.uc_stack.ss_size = sh->stack_size; f->ctx.uc_link = &w->sched;
   const uintptr_t p = (uintptr_t)f;
   makecontext(&f->ctx, (void (*)(void))fiber_main, 2, (unsigned)(p >> 32), (unsigned)(p & 0xffffffffu));
-  w->fibers[w->n_fibers++] = f;
+  ln->fibers[ln->n_fibers++] = f;
   return true;
 }
 
-static int submit_pairings(worker* w) {
+static int submit_pairings(worker* w, lane* ln) {
   /* group the waiting fibres by (L, rate): a retry with a longer min_factor_len runs separately */
-  fiber** wait = (fiber**)malloc(w->n_fibers * sizeof(fiber*));
+  fiber** wait = (fiber**)malloc((ln->n_fibers + 1) * sizeof(fiber*));
   size_t nw = 0;
-  for (size_t i = 0; i < w->n_fibers; ++i) if (w->fibers[i]->state == F_WAIT_PAIR) wait[nw++] = w->fibers[i];
+  for (size_t i = 0; i < ln->n_fibers; ++i) if (ln->fibers[i]->state == F_WAIT_PAIR) wait[nw++] = ln->fibers[i];
   int rc = 0;
   while (nw > 0 && rc == 0) {
     const unsigned L = wait[0]->pat_L; const double rate = wait[0]->pat_rate;
@@ -174,13 +186,13 @@ static int submit_pairings(worker* w) {
     off[ng] = pos;
     pgpu_pairing_plan* plan = NULL;
     pgpu_pairing_params prm = { L, 0, rate };
-    rc = pgpu_pairing_plan_create(w->ctx, w->sh->idx, blob, off, ng, &plan);
-    if (rc == PGPU_OK) rc = pgpu_pairing_plan_run(w->ctx, plan, &prm);
+    rc = pgpu_pairing_plan_create(ln->ctx, w->sh->idx, blob, off, ng, &plan);
+    if (rc == PGPU_OK) rc = pgpu_pairing_plan_run(ln->ctx, plan, &prm);
     if (rc == PGPU_OK) {
       const size_t cnt = (size_t)pgpu_pairing_plan_count(plan);
       pgpu_pairing* out = (pgpu_pairing*)malloc((cnt + 1) * sizeof(pgpu_pairing));
       uint64_t* first = (uint64_t*)malloc((ng + 1) * sizeof(uint64_t));
-      rc = pgpu_pairing_plan_fetch(w->ctx, plan, out, cnt, first);
+      rc = pgpu_pairing_plan_fetch(ln->ctx, plan, out, cnt, first);
       if (rc == PGPU_OK) {
         for (size_t i = 0; i < ng; ++i) {
           const size_t n = (size_t)(first[i + 1] - first[i]);
@@ -193,8 +205,8 @@ static int submit_pairings(worker* w) {
       }
       free(out); free(first);
     }
-    if (plan) pgpu_pairing_plan_destroy(w->ctx, plan);
-    if (rc != PGPU_OK) fprintf(stderr, "* FATAL pairing batch failed: %s\n", pgpu_last_error(w->ctx));
+    if (plan) pgpu_pairing_plan_destroy(ln->ctx, plan);
+    if (rc != PGPU_OK) fprintf(stderr, "* FATAL pairing batch failed: %s\n", pgpu_last_error(ln->ctx));
     free(blob); free(off); free(grp);
     nw = rest;
   }
@@ -202,91 +214,118 @@ static int submit_pairings(worker* w) {
   return rc;
 }
 
-static int submit_dp(worker* w) {
+/* enqueue the pending DP requests of a lane as one batch (upload + kernels, asynchronous) */
+static int launch_dp(worker* w, lane* ln) {
   shared* sh = w->sh;
   const char* gen = sh->in->gen->seq;
-  const size_t gen_len = strlen(gen);
-  ef_jobbuf_reset(&w->jb);
-  fiber** wait = (fiber**)malloc(w->n_fibers * sizeof(fiber*));
-  size_t nw = 0;
-  for (size_t i = 0; i < w->n_fibers; ++i) {
-    fiber* f = w->fibers[i];
+  const size_t gen_len = sh->gen_len;
+  ef_jobbuf_reset(&ln->jb);
+  ln->n_inflight = 0;
+  for (size_t i = 0; i < ln->n_fibers; ++i) {
+    fiber* f = ln->fibers[i];
     if (f->state != F_WAIT_DP) continue;
-    ef_jobbuf_add(&w->jb, &f->req, gen, gen_len);
-    wait[nw++] = f;
+    ef_jobbuf_add(&ln->jb, &f->req, gen, gen_len);
+    ln->inflight[ln->n_inflight++] = f;
   }
-  if (nw == 0) { free(wait); return 0; }
-  if (nw > w->results_cap) { w->results_cap = nw * 2; w->results = (pgpu_dp_result*)realloc(w->results, w->results_cap * sizeof(pgpu_dp_result)); }
-  pgpu_dp_plan* plan = NULL;
-  int rc = pgpu_dp_plan_create(w->ctx, sh->idx, w->jb.jobs, nw, w->jb.arena, w->jb.arena_len, &plan);
-  if (rc == PGPU_OK) rc = pgpu_dp_plan_launch(w->ctx, plan);
-  if (rc == PGPU_OK) rc = pgpu_dp_plan_sync(w->ctx, plan);
+  if (ln->n_inflight == 0) return 0;
+  int rc = pgpu_dp_plan_create(ln->ctx, sh->idx, ln->jb.jobs, ln->n_inflight, ln->jb.arena, ln->jb.arena_len, &ln->plan);
+  if (rc == PGPU_OK) rc = pgpu_dp_plan_launch(ln->ctx, ln->plan);
+  if (rc != PGPU_OK) fprintf(stderr, "* FATAL DP batch failed: %s\n", pgpu_last_error(ln->ctx));
+  return rc;
+}
+
+/* wait for the lane's batch, hand the results to its fibres */
+static int collect_dp(worker* w, lane* ln) {
+  shared* sh = w->sh;
+  if (!ln->plan) return 0;
+  const size_t nw = ln->n_inflight;
+  if (nw > ln->results_cap) { ln->results_cap = nw * 2; ln->results = (pgpu_dp_result*)realloc(ln->results, ln->results_cap * sizeof(pgpu_dp_result)); }
+  int rc = pgpu_dp_plan_sync(ln->ctx, ln->plan);
   if (rc == PGPU_OK) {
-    const size_t sb = pgpu_dp_plan_string_bytes(plan);
-    if (sb + 16 > w->strings_cap) { w->strings_cap = (sb + 16) * 2; w->strings = (char*)realloc(w->strings, w->strings_cap); }
-    rc = pgpu_dp_plan_fetch(w->ctx, plan, w->results, w->strings, w->strings_cap);
+    const size_t sb = pgpu_dp_plan_string_bytes(ln->plan);
+    if (sb + 16 > ln->strings_cap) { ln->strings_cap = (sb + 16) * 2; ln->strings = (char*)realloc(ln->strings, ln->strings_cap); }
+    rc = pgpu_dp_plan_fetch(ln->ctx, ln->plan, ln->results, ln->strings, ln->strings_cap);
   }
   if (rc == PGPU_OK && sh->kernel_timing) {
-    const int ng = pgpu_dp_plan_n_groups(plan);
+    const int ng = pgpu_dp_plan_n_groups(ln->plan);
     for (int g = 0; g < ng; ++g) {
       pgpu_group_info gi;
-      if (pgpu_dp_plan_group_info(plan, g, &gi) != PGPU_OK) continue;
+      if (pgpu_dp_plan_group_info(ln->plan, g, &gi) != PGPU_OK) continue;
       ef_kernel_stat ks; memset(&ks, 0, sizeof ks);
       snprintf(ks.name, sizeof ks.name, "%s", gi.name);
       ks.ms = gi.ms; ks.launches = 1; ks.jobs = gi.jobs; ks.cells = gi.cells; ks.algo_bytes = gi.algo_bytes;
       kstat_add(&w->stats, &ks);
     }
   }
-  if (plan) pgpu_dp_plan_destroy(w->ctx, plan);
-  if (rc != PGPU_OK) { fprintf(stderr, "* FATAL DP batch failed: %s\n", pgpu_last_error(w->ctx)); free(wait); return rc; }
+  pgpu_dp_plan_destroy(ln->ctx, ln->plan);
+  ln->plan = NULL;
+  if (rc != PGPU_OK) { fprintf(stderr, "* FATAL DP batch failed: %s\n", pgpu_last_error(ln->ctx)); return rc; }
   for (size_t i = 0; i < nw; ++i) {
-    fiber* f = wait[i];
-    f->rc = ef_decode_result(f->req.kind, &w->results[i], w->strings, f->res);
+    fiber* f = ln->inflight[i];
+    f->rc = ef_decode_result(f->req.kind, &ln->results[i], ln->strings, f->res);
     if (f->rc != 0) fprintf(stderr, "* FATAL DP job of kind %d (%zu x %zu) exceeds the device limits\n", f->req.kind, f->req.la, f->req.lb);
     f->state = F_RUNNABLE;
   }
   w->stats.dp_batches++; w->stats.dp_jobs += nw;
-  free(wait);
+  ln->n_inflight = 0;
   return 0;
 }
 
 static void* worker_main(void* arg) {
   worker* w = (worker*)arg;
   shared* sh = w->sh;
-  if (pgpu_init(ef_gpu_device_from_env(), &w->ctx) != PGPU_OK) { sh->failed = 1; return NULL; }
-  if (sh->kernel_timing) pgpu_set_timing(w->ctx, 1);
-  w->fibers = (fiber**)malloc(sh->max_fibers * sizeof(fiber*));
-  ef_jobbuf_init(&w->jb);
+  const size_t per_lane = sh->max_fibers / 2 ? sh->max_fibers / 2 : 1;
+  for (int li = 0; li < 2; ++li) {
+    lane* ln = &w->lanes[li];
+    if (pgpu_init(ef_gpu_device_from_env(), &ln->ctx) != PGPU_OK) { sh->failed = 1; return NULL; }
+    if (sh->kernel_timing) pgpu_set_timing(ln->ctx, 1);
+    ln->fibers = (fiber**)malloc(per_lane * sizeof(fiber*));
+    ln->inflight = (fiber**)malloc(per_lane * sizeof(fiber*));
+    ef_jobbuf_init(&ln->jb);
+  }
   bool more = true;
   while (!sh->failed) {
-    while (more && w->n_fibers < sh->max_fibers) more = start_fiber(w);
-    if (w->n_fibers == 0) break;
-    /* run every runnable fibre until it blocks or ends */
-    double t0 = now_s();
-    for (size_t i = 0; i < w->n_fibers; ++i) {
-      fiber* f = w->fibers[i];
-      if (f->state == F_RUNNABLE) swapcontext(&w->sched, &f->ctx);
+    bool any = false;
+    for (int li = 0; li < 2 && !sh->failed; ++li) {
+      lane* ln = &w->lanes[li];
+      double t0 = now_s();
+      if (collect_dp(w, ln) != 0) { sh->failed = 1; break; }        /* blocks only on THIS lane's batch */
+      w->stats.dp_s += now_s() - t0;
+      while (more && ln->n_fibers < per_lane) more = start_fiber(w, li);
+      if (ln->n_fibers == 0) continue;
+      any = true;
+      /* run every runnable fibre of the lane until it blocks or ends (the other lane's batch,
+       * if any, is executing on the GPU meanwhile) */
+      t0 = now_s();
+      for (size_t i = 0; i < ln->n_fibers; ++i) {
+        fiber* f = ln->fibers[i];
+        if (f->state == F_RUNNABLE) swapcontext(&w->sched, &f->ctx);
+      }
+      size_t keep = 0;
+      for (size_t i = 0; i < ln->n_fibers; ++i) {
+        fiber* f = ln->fibers[i];
+        if (f->state == F_DONE) { free(f->stack); free(f); w->stats.units++; }
+        else ln->fibers[keep++] = f;
+      }
+      ln->n_fibers = keep;
+      w->stats.host_s += now_s() - t0;
+      t0 = now_s();
+      int brc = submit_pairings(w, ln);
+      w->stats.pairing_s += now_s() - t0;
+      t0 = now_s();
+      if (brc == 0) brc = launch_dp(w, ln);
+      w->stats.dp_s += now_s() - t0;
+      if (brc != 0) { sh->failed = 1; break; }
     }
-    w->stats.host_s += now_s() - t0;
-    /* retire finished fibres */
-    size_t keep = 0;
-    for (size_t i = 0; i < w->n_fibers; ++i) {
-      fiber* f = w->fibers[i];
-      if (f->state == F_DONE) { free(f->stack); free(f); w->stats.units++; }
-      else w->fibers[keep++] = f;
-    }
-    w->n_fibers = keep;
-    t0 = now_s();
-    int brc = submit_pairings(w);
-    w->stats.pairing_s += now_s() - t0;
-    t0 = now_s();
-    if (brc == 0) brc = submit_dp(w);
-    w->stats.dp_s += now_s() - t0;
-    if (brc != 0) { sh->failed = 1; break; }
+    if (!any && !more) break;
   }
-  ef_jobbuf_free(&w->jb);
-  free(w->strings); free(w->results); free(w->fibers);
-  pgpu_destroy(w->ctx);
+  for (int li = 0; li < 2; ++li) {
+    lane* ln = &w->lanes[li];
+    if (ln->plan) { pgpu_dp_plan_sync(ln->ctx, ln->plan); pgpu_dp_plan_destroy(ln->ctx, ln->plan); }
+    ef_jobbuf_free(&ln->jb);
+    free(ln->strings); free(ln->results); free(ln->fibers); free(ln->inflight);
+    pgpu_destroy(ln->ctx);
+  }
   return NULL;
 }
 
@@ -350,6 +389,7 @@ ef_session* ef_session_open(int argc, char** argv) {
   sh->max_fibers = env_size("PINTRON_FIBERS", 2048);
   sh->stack_size = env_size("PINTRON_FIBER_STACK_KB", 256) * 1024;
   sh->kernel_timing = getenv("PINTRON_KERNEL_TIMING") != NULL;
+  sh->gen_len = strlen(in->gen->seq);
   s->load_s = t_loaded - t_start;
   s->index_s = now_s() - t_loaded;
   return s;
