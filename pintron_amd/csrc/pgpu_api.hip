@@ -28,6 +28,11 @@ struct pgpu_ctx {
   char err[512] = {0};
   BufPool pools[2];          // 0: DP plans, 1: pairing plans
   bool timing = false;       // HIP events around every kernel group (bench / profiling)
+  // the kernel groups of one DP plan are independent of each other: they are spread over a few
+  // auxiliary streams so that a batch costs max(group) instead of sum(group) in latency
+  static constexpr int NAUX = 8;
+  hipStream_t aux[NAUX] = {nullptr};
+  hipEvent_t ev_upload = nullptr;
 };
 
 bool pgpu_ctx_pool_acquire(pgpu_ctx* ctx, int pool) {
@@ -99,6 +104,9 @@ extern "C" int pgpu_init(int device, pgpu_ctx** out) {
     delete ctx;
     return PGPU_EDEVICE;
   }
+  for (auto& a : ctx->aux)
+    if (hipStreamCreateWithFlags(&a, hipStreamNonBlocking) != hipSuccess) { delete ctx; return PGPU_EDEVICE; }
+  if (hipEventCreateWithFlags(&ctx->ev_upload, hipEventDisableTiming) != hipSuccess) { delete ctx; return PGPU_EDEVICE; }
   *out = ctx;
   return PGPU_OK;
 }
@@ -108,6 +116,8 @@ extern "C" int pgpu_destroy(pgpu_ctx* ctx) {
   hipSetDevice(ctx->device);
   hipStreamSynchronize(ctx->stream);
   for (auto& pl : ctx->pools) for (auto& q : pl.ptr) if (q) hipFree(q);
+  for (auto& a : ctx->aux) if (a) { hipStreamSynchronize(a); hipStreamDestroy(a); }
+  if (ctx->ev_upload) hipEventDestroy(ctx->ev_upload);
   hipStreamDestroy(ctx->stream);
   delete ctx;
   return PGPU_OK;
@@ -364,12 +374,17 @@ extern "C" int pgpu_dp_plan_create(pgpu_ctx* ctx, const pgpu_index* idx, const p
 extern "C" int pgpu_dp_plan_launch(pgpu_ctx* ctx, pgpu_dp_plan* p) {
   if (!ctx || !p) return set_err(ctx, PGPU_EINVAL, "bad argument");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  hipStream_t st = ctx->stream;
-  if (p->n_keys) HIP_TRY(ctx, hipMemsetAsync(p->d_keys, 0, p->n_keys * sizeof(unsigned long long), st));
+  if (p->n_keys) HIP_TRY(ctx, hipMemsetAsync(p->d_keys, 0, p->n_keys * sizeof(unsigned long long), ctx->stream));
+  // uploads (plan_create) and the key reset are on the main stream; the groups fan out
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_upload, ctx->stream));
+  for (auto& a : ctx->aux) HIP_TRY(ctx, hipStreamWaitEvent(a, ctx->ev_upload, 0));
   size_t key_base = 0;
+  int slot = 0;
+  hipStream_t st = ctx->aux[0];
   for (auto& g : p->groups) {
     const DevJob* jobs = p->d_jobs + g.first;
     const int n = (int)g.count;
+    if (!g.traceback) st = ctx->aux[slot++ % pgpu_ctx::NAUX];      // a traceback follows its DP kernel
     if (g.ev0) HIP_TRY(ctx, hipEventRecord(g.ev0, st));
     if (g.traceback) {
       if (g.family == KF_ALIGN) launch_align_traceback(jobs, n, p->d_results, p->d_ws, p->d_strs, st);
@@ -394,6 +409,7 @@ extern "C" int pgpu_dp_plan_launch(pgpu_ctx* ctx, pgpu_dp_plan* p) {
 extern "C" int pgpu_dp_plan_sync(pgpu_ctx* ctx, pgpu_dp_plan* p) {
   if (!ctx || !p) return set_err(ctx, PGPU_EINVAL, "bad argument");
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (p->launched) for (auto& a : ctx->aux) HIP_TRY(ctx, hipStreamSynchronize(a));
   if (p->launched) {
     for (int k = 0; k < PGPU_DP_NKINDS; ++k) { p->ms[k] = 0; p->launches[k] = 0; }
     for (auto& g : p->groups) {
@@ -435,6 +451,7 @@ extern "C" int pgpu_dp_plan_destroy(pgpu_ctx* ctx, pgpu_dp_plan* p) {
   if (!ctx || !p) return PGPU_EINVAL;
   hipSetDevice(ctx->device);
   hipStreamSynchronize(ctx->stream);
+  for (auto& a : ctx->aux) hipStreamSynchronize(a);
   plan_free(p);
   return PGPU_OK;
 }

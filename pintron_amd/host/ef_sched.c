@@ -61,6 +61,7 @@ typedef struct shared {
   pgpu_pairing* pre_tri; uint64_t* pre_first;
   bool kernel_timing;
   size_t gen_len;
+  int n_lanes;
   int failed;
   ef_sched_stats stats;
 } shared;
@@ -274,8 +275,9 @@ static int collect_dp(worker* w, lane* ln) {
 static void* worker_main(void* arg) {
   worker* w = (worker*)arg;
   shared* sh = w->sh;
-  const size_t per_lane = sh->max_fibers / 2 ? sh->max_fibers / 2 : 1;
-  for (int li = 0; li < 2; ++li) {
+  const int n_lanes = sh->n_lanes;
+  const size_t per_lane = sh->max_fibers / n_lanes ? sh->max_fibers / n_lanes : 1;
+  for (int li = 0; li < n_lanes; ++li) {
     lane* ln = &w->lanes[li];
     if (pgpu_init(ef_gpu_device_from_env(), &ln->ctx) != PGPU_OK) { sh->failed = 1; return NULL; }
     if (sh->kernel_timing) pgpu_set_timing(ln->ctx, 1);
@@ -286,7 +288,7 @@ static void* worker_main(void* arg) {
   bool more = true;
   while (!sh->failed) {
     bool any = false;
-    for (int li = 0; li < 2 && !sh->failed; ++li) {
+    for (int li = 0; li < n_lanes && !sh->failed; ++li) {
       lane* ln = &w->lanes[li];
       double t0 = now_s();
       if (collect_dp(w, ln) != 0) { sh->failed = 1; break; }        /* blocks only on THIS lane's batch */
@@ -319,7 +321,7 @@ static void* worker_main(void* arg) {
     }
     if (!any && !more) break;
   }
-  for (int li = 0; li < 2; ++li) {
+  for (int li = 0; li < n_lanes; ++li) {
     lane* ln = &w->lanes[li];
     if (ln->plan) { pgpu_dp_plan_sync(ln->ctx, ln->plan); pgpu_dp_plan_destroy(ln->ctx, ln->plan); }
     ef_jobbuf_free(&ln->jb);
@@ -390,6 +392,7 @@ ef_session* ef_session_open(int argc, char** argv) {
   sh->stack_size = env_size("PINTRON_FIBER_STACK_KB", 256) * 1024;
   sh->kernel_timing = getenv("PINTRON_KERNEL_TIMING") != NULL;
   sh->gen_len = strlen(in->gen->seq);
+  sh->n_lanes = env_size("PINTRON_LANES", 2) >= 2 ? 2 : 1;
   s->load_s = t_loaded - t_start;
   s->index_s = now_s() - t_loaded;
   return s;
