@@ -33,7 +33,30 @@ struct pgpu_ctx {
   static constexpr int NAUX = 8;
   hipStream_t aux[NAUX] = {nullptr};
   hipEvent_t ev_upload = nullptr;
+  bool fanout = false;       // PGPU_FANOUT=1: spread groups over the auxiliary streams
+  // waiting: a blocking-sync event lets the calling thread SLEEP until the batch is done (the
+  // default HIP wait spins and would burn a host core that other EST fibres could use)
+  hipEvent_t ev_done = nullptr;
+  // pinned staging for the device->host result copies (pageable copies block and spin inside HIP)
+  void* pin[2] = {nullptr, nullptr};
+  size_t pin_cap[2] = {0, 0};
 };
+
+static int wait_stream(pgpu_ctx* ctx, hipStream_t st) {
+  if (hipEventRecord(ctx->ev_done, st) != hipSuccess) return -1;
+  return hipEventSynchronize(ctx->ev_done) == hipSuccess ? 0 : -1;
+}
+
+static void* pinned(pgpu_ctx* ctx, int slot, size_t bytes) {
+  if (ctx->pin_cap[slot] < bytes) {
+    if (ctx->pin[slot]) (void)hipHostFree(ctx->pin[slot]);
+    ctx->pin[slot] = nullptr; ctx->pin_cap[slot] = 0;
+    const size_t want = bytes + bytes / 2 + 4096;
+    if (hipHostMalloc(&ctx->pin[slot], want, hipHostMallocDefault) != hipSuccess) return nullptr;
+    ctx->pin_cap[slot] = want;
+  }
+  return ctx->pin[slot];
+}
 
 bool pgpu_ctx_pool_acquire(pgpu_ctx* ctx, int pool) {
   if (ctx->pools[pool].busy) return false;
@@ -107,6 +130,8 @@ extern "C" int pgpu_init(int device, pgpu_ctx** out) {
   for (auto& a : ctx->aux)
     if (hipStreamCreateWithFlags(&a, hipStreamNonBlocking) != hipSuccess) { delete ctx; return PGPU_EDEVICE; }
   if (hipEventCreateWithFlags(&ctx->ev_upload, hipEventDisableTiming) != hipSuccess) { delete ctx; return PGPU_EDEVICE; }
+  if (hipEventCreateWithFlags(&ctx->ev_done, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) { delete ctx; return PGPU_EDEVICE; }
+  ctx->fanout = getenv("PGPU_FANOUT") != nullptr;
   *out = ctx;
   return PGPU_OK;
 }
@@ -118,6 +143,8 @@ extern "C" int pgpu_destroy(pgpu_ctx* ctx) {
   for (auto& pl : ctx->pools) for (auto& q : pl.ptr) if (q) hipFree(q);
   for (auto& a : ctx->aux) if (a) { hipStreamSynchronize(a); hipStreamDestroy(a); }
   if (ctx->ev_upload) hipEventDestroy(ctx->ev_upload);
+  if (ctx->ev_done) hipEventDestroy(ctx->ev_done);
+  for (auto& q : ctx->pin) if (q) hipHostFree(q);
   hipStreamDestroy(ctx->stream);
   delete ctx;
   return PGPU_OK;
@@ -376,15 +403,17 @@ extern "C" int pgpu_dp_plan_launch(pgpu_ctx* ctx, pgpu_dp_plan* p) {
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   if (p->n_keys) HIP_TRY(ctx, hipMemsetAsync(p->d_keys, 0, p->n_keys * sizeof(unsigned long long), ctx->stream));
   // uploads (plan_create) and the key reset are on the main stream; the groups fan out
-  HIP_TRY(ctx, hipEventRecord(ctx->ev_upload, ctx->stream));
-  for (auto& a : ctx->aux) HIP_TRY(ctx, hipStreamWaitEvent(a, ctx->ev_upload, 0));
+  if (ctx->fanout) {
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_upload, ctx->stream));
+    for (auto& a : ctx->aux) HIP_TRY(ctx, hipStreamWaitEvent(a, ctx->ev_upload, 0));
+  }
   size_t key_base = 0;
   int slot = 0;
-  hipStream_t st = ctx->aux[0];
+  hipStream_t st = ctx->stream;
   for (auto& g : p->groups) {
     const DevJob* jobs = p->d_jobs + g.first;
     const int n = (int)g.count;
-    if (!g.traceback) st = ctx->aux[slot++ % pgpu_ctx::NAUX];      // a traceback follows its DP kernel
+    if (!g.traceback) st = ctx->fanout ? ctx->aux[slot++ % pgpu_ctx::NAUX] : ctx->stream;   // a traceback follows its DP kernel
     if (g.ev0) HIP_TRY(ctx, hipEventRecord(g.ev0, st));
     if (g.traceback) {
       if (g.family == KF_ALIGN) launch_align_traceback(jobs, n, p->d_results, p->d_ws, p->d_strs, st);
@@ -408,8 +437,8 @@ extern "C" int pgpu_dp_plan_launch(pgpu_ctx* ctx, pgpu_dp_plan* p) {
 
 extern "C" int pgpu_dp_plan_sync(pgpu_ctx* ctx, pgpu_dp_plan* p) {
   if (!ctx || !p) return set_err(ctx, PGPU_EINVAL, "bad argument");
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  if (p->launched) for (auto& a : ctx->aux) HIP_TRY(ctx, hipStreamSynchronize(a));
+  if (ctx->fanout && p->launched) for (auto& a : ctx->aux) HIP_TRY(ctx, hipStreamSynchronize(a));
+  if (wait_stream(ctx, ctx->stream) != 0) return set_err(ctx, PGPU_EDEVICE, "waiting for the batch failed");
   if (p->launched) {
     for (int k = 0; k < PGPU_DP_NKINDS; ++k) { p->ms[k] = 0; p->launches[k] = 0; }
     for (auto& g : p->groups) {
@@ -429,11 +458,15 @@ extern "C" int pgpu_dp_plan_fetch(pgpu_ctx* ctx, pgpu_dp_plan* p, pgpu_dp_result
   if (!ctx || !p || (p->n_jobs && !results)) return set_err(ctx, PGPU_EINVAL, "bad argument");
   if (p->strs_bytes && strings && cap < p->strs_bytes) return set_err(ctx, PGPU_ENOSPC, "string buffer too small: need %zu", p->strs_bytes);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  if (p->n_jobs)
-    HIP_TRY(ctx, hipMemcpyAsync(results, p->d_results, p->n_jobs * sizeof(DevResult), hipMemcpyDeviceToHost, ctx->stream));
-  if (p->strs_bytes && strings)
-    HIP_TRY(ctx, hipMemcpyAsync(strings, p->d_strs, p->strs_bytes, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  const size_t rb = p->n_jobs * sizeof(DevResult), sb = (p->strs_bytes && strings) ? p->strs_bytes : 0;
+  void* pr = rb ? pinned(ctx, 0, rb) : nullptr;
+  void* ps = sb ? pinned(ctx, 1, sb) : nullptr;
+  if ((rb && !pr) || (sb && !ps)) return set_err(ctx, PGPU_ENOMEM, "pinned staging buffer");
+  if (rb) HIP_TRY(ctx, hipMemcpyAsync(pr, p->d_results, rb, hipMemcpyDeviceToHost, ctx->stream));
+  if (sb) HIP_TRY(ctx, hipMemcpyAsync(ps, p->d_strs, sb, hipMemcpyDeviceToHost, ctx->stream));
+  if (wait_stream(ctx, ctx->stream) != 0) return set_err(ctx, PGPU_EDEVICE, "result download failed");
+  if (rb) memcpy(results, pr, rb);
+  if (sb) memcpy(strings, ps, sb);
   return PGPU_OK;
 }
 
