@@ -33,7 +33,8 @@ struct pgpu_ctx {
   static constexpr int NAUX = 8;
   hipStream_t aux[NAUX] = {nullptr};
   hipEvent_t ev_upload = nullptr;
-  bool fanout = false;       // PGPU_FANOUT=1: spread groups over the auxiliary streams
+  hipEvent_t ev_aux[NAUX] = {nullptr};
+  bool fanout = true;        // spread groups over the auxiliary streams (PGPU_FANOUT=0 disables)
   // waiting: a blocking-sync event lets the calling thread SLEEP until the batch is done (the
   // default HIP wait spins and would burn a host core that other EST fibres could use)
   hipEvent_t ev_done = nullptr;
@@ -131,7 +132,9 @@ extern "C" int pgpu_init(int device, pgpu_ctx** out) {
     if (hipStreamCreateWithFlags(&a, hipStreamNonBlocking) != hipSuccess) { delete ctx; return PGPU_EDEVICE; }
   if (hipEventCreateWithFlags(&ctx->ev_upload, hipEventDisableTiming) != hipSuccess) { delete ctx; return PGPU_EDEVICE; }
   if (hipEventCreateWithFlags(&ctx->ev_done, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) { delete ctx; return PGPU_EDEVICE; }
-  ctx->fanout = getenv("PGPU_FANOUT") != nullptr;
+  for (auto& e : ctx->ev_aux)
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete ctx; return PGPU_EDEVICE; }
+  { const char* f = getenv("PGPU_FANOUT"); ctx->fanout = !(f && f[0] == '0'); }
   *out = ctx;
   return PGPU_OK;
 }
@@ -144,6 +147,7 @@ extern "C" int pgpu_destroy(pgpu_ctx* ctx) {
   for (auto& a : ctx->aux) if (a) { hipStreamSynchronize(a); hipStreamDestroy(a); }
   if (ctx->ev_upload) hipEventDestroy(ctx->ev_upload);
   if (ctx->ev_done) hipEventDestroy(ctx->ev_done);
+  for (auto& e : ctx->ev_aux) if (e) hipEventDestroy(e);
   for (auto& q : ctx->pin) if (q) hipHostFree(q);
   hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -431,13 +435,19 @@ extern "C" int pgpu_dp_plan_launch(pgpu_ctx* ctx, pgpu_dp_plan* p) {
     if (g.ev1) HIP_TRY(ctx, hipEventRecord(g.ev1, st));
     HIP_TRY(ctx, hipGetLastError());
   }
+  if (ctx->fanout) {            // join: the main stream continues after every auxiliary stream
+    const int used = slot < pgpu_ctx::NAUX ? slot : pgpu_ctx::NAUX;
+    for (int i = 0; i < used; ++i) {
+      HIP_TRY(ctx, hipEventRecord(ctx->ev_aux[i], ctx->aux[i]));
+      HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_aux[i], 0));
+    }
+  }
   p->launched = true;
   return PGPU_OK;
 }
 
 extern "C" int pgpu_dp_plan_sync(pgpu_ctx* ctx, pgpu_dp_plan* p) {
   if (!ctx || !p) return set_err(ctx, PGPU_EINVAL, "bad argument");
-  if (ctx->fanout && p->launched) for (auto& a : ctx->aux) HIP_TRY(ctx, hipStreamSynchronize(a));
   if (wait_stream(ctx, ctx->stream) != 0) return set_err(ctx, PGPU_EDEVICE, "waiting for the batch failed");
   if (p->launched) {
     for (int k = 0; k < PGPU_DP_NKINDS; ++k) { p->ms[k] = 0; p->launches[k] = 0; }
@@ -484,7 +494,6 @@ extern "C" int pgpu_dp_plan_destroy(pgpu_ctx* ctx, pgpu_dp_plan* p) {
   if (!ctx || !p) return PGPU_EINVAL;
   hipSetDevice(ctx->device);
   hipStreamSynchronize(ctx->stream);
-  for (auto& a : ctx->aux) hipStreamSynchronize(a);
   plan_free(p);
   return PGPU_OK;
 }
