@@ -6,6 +6,7 @@
  * the reference's DATA (GetPWMfor* at :665-1100), each entry + 0.00001f as there. */
 #include <math.h>
 #include <stdlib.h>
+#include <stdint.h>
 #include <string.h>
 
 #include "estfact.h"
@@ -147,7 +148,22 @@ static double score5(const char* gen, int splice5, int k) {           /* GetScor
 
 /* classify_genomic_intron_start_end (:95-229), class only.  The reference copies the intron
  * (real_substring); we read it in place: intron = gen[start .. start+il) */
+static int classify_uncached(const char* gen, int start, int end);
+
+/* The class depends only on (genomic, start, end) and the ESTs of a gene keep proposing the same
+ * few introns, so each thread remembers recent answers (direct-mapped; the genomic sequence is
+ * immutable for the whole run). */
 int ef_classify_intron(const char* gen, int start, int end) {
+  typedef struct { const char* gen; int start, end, type; } slot;
+  static _Thread_local slot memo[1024];
+  slot* m = &memo[((uint32_t)start * 2654435761u ^ (uint32_t)end * 40503u) >> 7 & 1023u];
+  if (m->gen == gen && m->start == start && m->end == end) return m->type;
+  const int type = classify_uncached(gen, start, end);
+  m->gen = gen; m->start = start; m->end = end; m->type = type;
+  return type;
+}
+
+static int classify_uncached(const char* gen, int start, int end) {
   load_all();
   int idx = start, want = end - start + 1;
   if (idx < 0) { want += idx; idx = 0; }

@@ -685,7 +685,7 @@ static bool check_gap_errors(ef_list* fact, const char* est, const char* gen, co
 static void correct_tail(ef_list* fact, const char* gen, const char* est) {
   ef_factor* tail = (ef_factor*)efl_tail(fact);
   size_t i = (size_t)(tail->EST_end + 1), j = (size_t)(tail->GEN_end + 1);
-  const size_t el = strlen(est), gl = strlen(gen);
+  const size_t el = strlen(est), gl = ef_genomic_len(gen);
   while (i < el && j < gl && gen[j] == est[i]) { ++i; ++j; }
   tail->EST_end = (int)i - 1; tail->GEN_end = (int)j - 1;
 }

@@ -30,7 +30,7 @@ static void dp(ef_backend* be, int kind, const char* a, size_t la, const char* b
 
 /* valid bytes after t[len] (0..2) when t points into the NUL-terminated string s */
 static uint32_t tail_of(const char* s, const char* t, size_t len) {
-  const size_t total = strlen(s), end = (size_t)(t - s) + len;
+  const size_t total = ef_genomic_len(s), end = (size_t)(t - s) + len;
   if (end >= total) return 0;
   return total - end >= 2 ? 2u : 1u;
 }
@@ -91,7 +91,7 @@ void ef_remove_duplicated_factorizations(ef_list* facts) {
 static void recover_affixes(const ef_seq* gen, ef_est* e, ef_backend* be) {
   const char* G = gen->seq;
   const char* E = e->info->seq;
-  const size_t totg = strlen(G), tote = strlen(E);
+  const size_t totg = ef_genomic_len(G), tote = strlen(E);
   ef_iter it = efl_begin(e->factorizations);
   while (efi_has_next(&it)) {
     ef_list* f = (ef_list*)efi_next(&it);

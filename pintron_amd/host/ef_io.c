@@ -8,6 +8,25 @@
 
 #include "estfact.h"
 
+/* ---- per-thread 32-byte cells (ef_list.h) ------------------------------------------------------- */
+typedef struct cell_block { struct cell_block* next; ef_cell cells[2048]; } cell_block;
+_Thread_local ef_cell* ef_cell_free_list;
+_Thread_local long ef_cell_live;
+static _Thread_local cell_block* cell_blocks;
+
+void ef_cell_refill(void) {
+  cell_block* b = (cell_block*)malloc(sizeof(cell_block));
+  if (!b) { fprintf(stderr, "* FATAL out of memory\n"); abort(); }
+  b->next = cell_blocks; cell_blocks = b;
+  for (size_t i = 0; i < 2048; ++i) { b->cells[i].next = ef_cell_free_list; ef_cell_free_list = &b->cells[i]; }
+}
+
+void ef_cell_release_all(void) {
+  if (ef_cell_live != 0) return;            /* something of this thread is still alive: keep the blocks */
+  while (cell_blocks) { cell_block* nx = cell_blocks->next; free(cell_blocks); cell_blocks = nx; }
+  ef_cell_free_list = NULL;
+}
+
 static char* dup_range(const char* s, size_t n) {
   char* r = (char*)malloc(n + 1);
   memcpy(r, s, n);

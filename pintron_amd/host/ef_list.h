@@ -21,36 +21,65 @@ typedef struct ef_node { struct ef_node *next, *prev; void* el; } ef_node;
 typedef struct ef_list { ef_node sent; size_t size; } ef_list;
 typedef struct ef_iter { ef_node *next, *prev; ef_list* l; } ef_iter;
 
+/* ---- 32-byte cells --------------------------------------------------------------------------------
+ * An EST goes through a couple of thousand list nodes and list headers; they come from a per-thread
+ * free list of 32-byte cells (refilled in blocks, ef_io.c) instead of malloc.  A cell must be
+ * returned on the thread that took it, which holds because an EST is processed by one worker from
+ * start to end; ef_cell_release_all() gives the thread's blocks back when none of its cells is in
+ * use. */
+typedef union ef_cell { union ef_cell* next; char bytes[32]; } ef_cell;
+extern _Thread_local ef_cell* ef_cell_free_list;
+extern _Thread_local long ef_cell_live;
+void ef_cell_refill(void);
+void ef_cell_release_all(void);
+static inline void* ef_cell_get(void) {
+  if (!ef_cell_free_list) ef_cell_refill();
+  ef_cell* c = ef_cell_free_list; ef_cell_free_list = c->next; ++ef_cell_live;
+  return c;
+}
+static inline void ef_cell_put(void* p) {
+  ef_cell* c = (ef_cell*)p; c->next = ef_cell_free_list; ef_cell_free_list = c; --ef_cell_live;
+}
+typedef char ef_cell_size_check[(sizeof(ef_list) <= sizeof(ef_cell) && sizeof(ef_node) <= sizeof(ef_cell)) ? 1 : -1];
+#define EFL_NODE_NEW() ((ef_node*)ef_cell_get())
+#define EFL_NODE_DEL(n) ef_cell_put(n)
+
+static inline void efl_init(ef_list* l) { l->sent.next = l->sent.prev = &l->sent; l->sent.el = NULL; l->size = 0; }
 static inline ef_list* efl_new(void) {
-  ef_list* l = (ef_list*)malloc(sizeof(ef_list));
-  l->sent.next = l->sent.prev = &l->sent; l->sent.el = NULL; l->size = 0;
+  ef_list* l = (ef_list*)ef_cell_get();
+  efl_init(l);
   return l;
+}
+/* drops the nodes (and, with del, the elements); the header stays usable */
+static inline void efl_clear(ef_list* l, void (*del)(void*)) {
+  ef_node* n = l->sent.next;
+  while (n != &l->sent) { ef_node* nx = n->next; if (del && n->el) del(n->el); EFL_NODE_DEL(n); n = nx; }
+  efl_init(l);
 }
 static inline void efl_free(ef_list* l, void (*del)(void*)) {
   if (!l) return;
-  ef_node* n = l->sent.next;
-  while (n != &l->sent) { ef_node* nx = n->next; if (del && n->el) del(n->el); free(n); n = nx; }
-  free(l);
+  efl_clear(l, del);
+  ef_cell_put(l);
 }
 static inline size_t efl_size(const ef_list* l) { return l->size; }
 static inline bool efl_empty(const ef_list* l) { return l->size == 0; }
 static inline void efl_push_back(ef_list* l, void* el) {
-  ef_node* n = (ef_node*)malloc(sizeof(ef_node));
+  ef_node* n = EFL_NODE_NEW();
   n->el = el; n->prev = l->sent.prev; n->next = &l->sent; n->prev->next = n; l->sent.prev = n; ++l->size;
 }
 static inline void efl_push_front(ef_list* l, void* el) {
-  ef_node* n = (ef_node*)malloc(sizeof(ef_node));
+  ef_node* n = EFL_NODE_NEW();
   n->el = el; n->next = l->sent.next; n->prev = &l->sent; n->next->prev = n; l->sent.next = n; ++l->size;
 }
 static inline void* efl_head(const ef_list* l) { return l->sent.next->el; }   /* NULL when empty */
 static inline void* efl_tail(const ef_list* l) { return l->sent.prev->el; }
 static inline void* efl_pop_front(ef_list* l) {
   ef_node* n = l->sent.next; void* el = n->el;
-  l->sent.next = n->next; n->next->prev = &l->sent; free(n); --l->size; return el;
+  l->sent.next = n->next; n->next->prev = &l->sent; EFL_NODE_DEL(n); --l->size; return el;
 }
 static inline void* efl_pop_back(ef_list* l) {
   ef_node* n = l->sent.prev; void* el = n->el;
-  l->sent.prev = n->prev; n->prev->next = &l->sent; free(n); --l->size; return el;
+  l->sent.prev = n->prev; n->prev->next = &l->sent; EFL_NODE_DEL(n); --l->size; return el;
 }
 
 static inline ef_iter efl_begin(ef_list* l) { ef_iter it = { l->sent.next, &l->sent, l }; return it; }
@@ -70,18 +99,18 @@ static inline void efi_remove(ef_iter* it, void (*del)(void*)) {
   if (del) del(dead->el);
   --it->l->size;
   it->prev = dead->prev;
-  free(dead);
+  EFL_NODE_DEL(dead);
 }
 /* inserts before the element handed out by the last efi_next (include/list.h add_before_iterator) */
 static inline void efi_insert_before(ef_iter* it, void* el) {
   ef_node* cur = it->prev;
-  ef_node* n = (ef_node*)malloc(sizeof(ef_node));
+  ef_node* n = EFL_NODE_NEW();
   n->el = el; n->prev = cur->prev; n->next = cur; cur->prev->next = n; cur->prev = n; ++it->l->size;
 }
 /* removes the first node holding el; true when found */
 static inline bool efl_remove_first(ef_list* l, void* el) {
   for (ef_node* n = l->sent.next; n != &l->sent; n = n->next)
-    if (n->el == el) { n->prev->next = n->next; n->next->prev = n->prev; free(n); --l->size; return true; }
+    if (n->el == el) { n->prev->next = n->next; n->next->prev = n->prev; EFL_NODE_DEL(n); --l->size; return true; }
   return false;
 }
 /* qsort on the element pointers, written back into the existing nodes (as the reference does:

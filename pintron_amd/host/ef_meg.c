@@ -23,8 +23,10 @@ static void pairing_free(void* v) {
 ef_meg* ef_meg_from_pairings(const ef_triple* tr, size_t n_tr, size_t m) {
   ef_meg* V = (ef_meg*)malloc(sizeof(ef_meg));
   V->n = m + 2;
-  V->v = (ef_list**)malloc(V->n * sizeof(ef_list*));
-  for (size_t i = 0; i < V->n; ++i) V->v[i] = efl_new();
+  /* one list per EST position, most of them empty: the headers live in one block */
+  V->v = (ef_list**)malloc(V->n * (sizeof(ef_list*) + sizeof(ef_list)));
+  ef_list* heads = (ef_list*)(V->v + V->n);
+  for (size_t i = 0; i < V->n; ++i) { V->v[i] = &heads[i]; efl_init(V->v[i]); }
   efl_push_back(V->v[0], pairing_new(EF_SOURCE_START, EF_SOURCE_START, EF_SOURCE_LEN));
   for (size_t k = 0; k < n_tr; ++k)
     efl_push_back(V->v[1 + tr[k].p], pairing_new(tr[k].p, tr[k].t, tr[k].l));
@@ -34,7 +36,7 @@ ef_meg* ef_meg_from_pairings(const ef_triple* tr, size_t n_tr, size_t m) {
 
 void ef_meg_free(ef_meg* V) {
   if (!V) return;
-  for (size_t i = 0; i < V->n; ++i) efl_free(V->v[i], pairing_free);
+  for (size_t i = 0; i < V->n; ++i) efl_clear(V->v[i], pairing_free);
   free(V->v);
   free(V);
 }

@@ -308,7 +308,7 @@ static void try_burset_after_match(const char* est, const char* gen, int* factor
   }
   sf = *factor_left; sa = *acc_left + 1; sd = *donor_right + 1;
   stop = false;
-  const size_t el = strlen(est), gl = strlen(gen);
+  const size_t el = strlen(est), gl = ef_genomic_len(gen);
   while ((!stop && est[sf] == gen[sd]) && sf < acc_factor_right) {
     if ((unsigned)sf == el || (unsigned)sa == gl) stop = true;
     else {

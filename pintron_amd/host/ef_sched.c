@@ -49,6 +49,36 @@ typedef struct {
   char* buf[6]; size_t len[6];         /* raw, processed-ests, megs, processed-megs, megs-info, meg-edges */
 } unit;
 
+/* ---- GPU service: one thread owns the device queue ------------------------------------------------
+ * Workers do not talk to the GPU themselves.  A worker whose fibres are all blocked posts its
+ * pending DP requests and SLEEPS (condition variable); the service thread takes everything that
+ * has been posted so far, merges it into ONE plan (one upload, one set of kernel launches, one
+ * download), and wakes the posters, which decode their slice of the shared result buffers in
+ * parallel.  With more workers than cores the CPUs stay busy with host logic while other workers
+ * sleep, and the GPU sees few, large batches instead of many small ones. */
+typedef struct merged_batch {
+  pgpu_dp_result* results; char* strings;
+  int refs;                              /* posters that still have to decode their slice */
+} merged_batch;
+
+typedef struct dp_request {
+  const pgpu_dp_job* jobs; size_t n; const char* arena; size_t arena_len;
+  merged_batch* batch; size_t base;      /* filled by the service */
+  int rc; bool done;
+  struct dp_request* next;
+} dp_request;
+
+typedef struct service {
+  pthread_t thread;
+  pthread_mutex_t mu;
+  pthread_cond_t posted, finished;
+  dp_request *head, *tail;
+  bool stop;
+  pgpu_ctx* ctx;
+  struct shared* sh;
+  ef_sched_stats stats;                  /* batches, jobs, kernel timings */
+} service;
+
 typedef struct shared {
   ef_inputs* in;
   pgpu_index* idx;
@@ -62,6 +92,7 @@ typedef struct shared {
   bool kernel_timing;
   size_t gen_len;
   int n_lanes;
+  service svc;
   int failed;
   ef_sched_stats stats;
 } shared;
@@ -215,62 +246,114 @@ static int submit_pairings(worker* w, lane* ln) {
   return rc;
 }
 
-/* enqueue the pending DP requests of a lane as one batch (upload + kernels, asynchronous) */
+static void kstat_add(ef_sched_stats* st, const ef_kernel_stat* k);
+
+/* service thread: merge everything posted, run it as one plan, publish the results */
+static void* service_main(void* arg) {
+  service* sv = (service*)arg;
+  shared* sh = sv->sh;
+  pgpu_dp_job* jobs = NULL; size_t jobs_cap = 0;
+  char* arena = NULL; size_t arena_cap = 0;
+  for (;;) {
+    pthread_mutex_lock(&sv->mu);
+    while (!sv->head && !sv->stop) pthread_cond_wait(&sv->posted, &sv->mu);
+    dp_request* list = sv->head;
+    sv->head = sv->tail = NULL;
+    const bool stop = sv->stop;
+    pthread_mutex_unlock(&sv->mu);
+    if (!list) { if (stop) break; else continue; }
+    size_t nj = 0, na = 0; int nreq = 0;
+    for (dp_request* r = list; r; r = r->next) { nj += r->n; na += r->arena_len; ++nreq; }
+    if (nj > jobs_cap) { jobs_cap = nj * 2; jobs = (pgpu_dp_job*)realloc(jobs, jobs_cap * sizeof(pgpu_dp_job)); }
+    if (na + 16 > arena_cap) { arena_cap = (na + 16) * 2; arena = (char*)realloc(arena, arena_cap); }
+    size_t jpos = 0, apos = 0;
+    for (dp_request* r = list; r; r = r->next) {
+      r->base = jpos;
+      memcpy(jobs + jpos, r->jobs, r->n * sizeof(pgpu_dp_job));
+      memcpy(arena + apos, r->arena, r->arena_len);
+      for (size_t i = 0; i < r->n; ++i) {
+        pgpu_dp_job* j = &jobs[jpos + i];
+        if (!(j->flags & PGPU_JOB_A_GENOMIC)) j->a_off += apos;
+        if (!(j->flags & PGPU_JOB_B_GENOMIC)) j->b_off += apos;
+      }
+      jpos += r->n; apos += r->arena_len;
+    }
+    merged_batch* mb = (merged_batch*)calloc(1, sizeof(merged_batch));
+    mb->refs = nreq;
+    mb->results = (pgpu_dp_result*)malloc((nj + 1) * sizeof(pgpu_dp_result));
+    pgpu_dp_plan* plan = NULL;
+    int rc = pgpu_dp_plan_create(sv->ctx, sh->idx, jobs, nj, arena, apos, &plan);
+    if (rc == PGPU_OK) rc = pgpu_dp_plan_launch(sv->ctx, plan);
+    if (rc == PGPU_OK) rc = pgpu_dp_plan_sync(sv->ctx, plan);
+    if (rc == PGPU_OK) {
+      const size_t sb = pgpu_dp_plan_string_bytes(plan);
+      mb->strings = (char*)malloc(sb + 16);
+      rc = pgpu_dp_plan_fetch(sv->ctx, plan, mb->results, mb->strings, sb + 16);
+    }
+    if (rc == PGPU_OK && sh->kernel_timing) {
+      const int ng = pgpu_dp_plan_n_groups(plan);
+      for (int g = 0; g < ng; ++g) {
+        pgpu_group_info gi;
+        if (pgpu_dp_plan_group_info(plan, g, &gi) != PGPU_OK) continue;
+        ef_kernel_stat ks; memset(&ks, 0, sizeof ks);
+        snprintf(ks.name, sizeof ks.name, "%s", gi.name);
+        ks.ms = gi.ms; ks.launches = 1; ks.jobs = gi.jobs; ks.cells = gi.cells; ks.algo_bytes = gi.algo_bytes;
+        kstat_add(&sv->stats, &ks);
+      }
+    }
+    if (plan) pgpu_dp_plan_destroy(sv->ctx, plan);
+    if (rc != PGPU_OK) fprintf(stderr, "* FATAL DP batch failed: %s\n", pgpu_last_error(sv->ctx));
+    sv->stats.dp_batches++; sv->stats.dp_jobs += nj;
+    pthread_mutex_lock(&sv->mu);
+    for (dp_request* r = list; r;) { dp_request* nx = r->next; r->batch = mb; r->rc = rc; r->done = true; r = nx; }
+    pthread_cond_broadcast(&sv->finished);
+    pthread_mutex_unlock(&sv->mu);
+  }
+  free(jobs); free(arena);
+  return NULL;
+}
+
+/* post the pending DP requests of a lane, sleep until the merged batch is back, decode */
 static int launch_dp(worker* w, lane* ln) {
   shared* sh = w->sh;
+  service* sv = &sh->svc;
   const char* gen = sh->in->gen->seq;
-  const size_t gen_len = sh->gen_len;
   ef_jobbuf_reset(&ln->jb);
   ln->n_inflight = 0;
   for (size_t i = 0; i < ln->n_fibers; ++i) {
     fiber* f = ln->fibers[i];
     if (f->state != F_WAIT_DP) continue;
-    ef_jobbuf_add(&ln->jb, &f->req, gen, gen_len);
+    ef_jobbuf_add(&ln->jb, &f->req, gen, sh->gen_len);
     ln->inflight[ln->n_inflight++] = f;
   }
   if (ln->n_inflight == 0) return 0;
-  int rc = pgpu_dp_plan_create(ln->ctx, sh->idx, ln->jb.jobs, ln->n_inflight, ln->jb.arena, ln->jb.arena_len, &ln->plan);
-  if (rc == PGPU_OK) rc = pgpu_dp_plan_launch(ln->ctx, ln->plan);
-  if (rc != PGPU_OK) fprintf(stderr, "* FATAL DP batch failed: %s\n", pgpu_last_error(ln->ctx));
+  dp_request rq;
+  memset(&rq, 0, sizeof rq);
+  rq.jobs = ln->jb.jobs; rq.n = ln->n_inflight; rq.arena = ln->jb.arena; rq.arena_len = ln->jb.arena_len;
+  pthread_mutex_lock(&sv->mu);
+  if (sv->tail) sv->tail->next = &rq; else sv->head = &rq;
+  sv->tail = &rq;
+  pthread_cond_signal(&sv->posted);
+  while (!rq.done) pthread_cond_wait(&sv->finished, &sv->mu);
+  pthread_mutex_unlock(&sv->mu);
+  int rc = rq.rc;
+  if (rc == PGPU_OK) {
+    for (size_t i = 0; i < ln->n_inflight; ++i) {
+      fiber* f = ln->inflight[i];
+      f->rc = ef_decode_result(f->req.kind, &rq.batch->results[rq.base + i], rq.batch->strings, f->res);
+      if (f->rc != 0) fprintf(stderr, "* FATAL DP job of kind %d (%zu x %zu) exceeds the device limits\n", f->req.kind, f->req.la, f->req.lb);
+      f->state = F_RUNNABLE;
+    }
+  }
+  pthread_mutex_lock(&sv->mu);
+  const bool last = --rq.batch->refs == 0;
+  pthread_mutex_unlock(&sv->mu);
+  if (last) { free(rq.batch->results); free(rq.batch->strings); free(rq.batch); }
+  ln->n_inflight = 0;
   return rc;
 }
 
-/* wait for the lane's batch, hand the results to its fibres */
-static int collect_dp(worker* w, lane* ln) {
-  shared* sh = w->sh;
-  if (!ln->plan) return 0;
-  const size_t nw = ln->n_inflight;
-  if (nw > ln->results_cap) { ln->results_cap = nw * 2; ln->results = (pgpu_dp_result*)realloc(ln->results, ln->results_cap * sizeof(pgpu_dp_result)); }
-  int rc = pgpu_dp_plan_sync(ln->ctx, ln->plan);
-  if (rc == PGPU_OK) {
-    const size_t sb = pgpu_dp_plan_string_bytes(ln->plan);
-    if (sb + 16 > ln->strings_cap) { ln->strings_cap = (sb + 16) * 2; ln->strings = (char*)realloc(ln->strings, ln->strings_cap); }
-    rc = pgpu_dp_plan_fetch(ln->ctx, ln->plan, ln->results, ln->strings, ln->strings_cap);
-  }
-  if (rc == PGPU_OK && sh->kernel_timing) {
-    const int ng = pgpu_dp_plan_n_groups(ln->plan);
-    for (int g = 0; g < ng; ++g) {
-      pgpu_group_info gi;
-      if (pgpu_dp_plan_group_info(ln->plan, g, &gi) != PGPU_OK) continue;
-      ef_kernel_stat ks; memset(&ks, 0, sizeof ks);
-      snprintf(ks.name, sizeof ks.name, "%s", gi.name);
-      ks.ms = gi.ms; ks.launches = 1; ks.jobs = gi.jobs; ks.cells = gi.cells; ks.algo_bytes = gi.algo_bytes;
-      kstat_add(&w->stats, &ks);
-    }
-  }
-  pgpu_dp_plan_destroy(ln->ctx, ln->plan);
-  ln->plan = NULL;
-  if (rc != PGPU_OK) { fprintf(stderr, "* FATAL DP batch failed: %s\n", pgpu_last_error(ln->ctx)); return rc; }
-  for (size_t i = 0; i < nw; ++i) {
-    fiber* f = ln->inflight[i];
-    f->rc = ef_decode_result(f->req.kind, &ln->results[i], ln->strings, f->res);
-    if (f->rc != 0) fprintf(stderr, "* FATAL DP job of kind %d (%zu x %zu) exceeds the device limits\n", f->req.kind, f->req.la, f->req.lb);
-    f->state = F_RUNNABLE;
-  }
-  w->stats.dp_batches++; w->stats.dp_jobs += nw;
-  ln->n_inflight = 0;
-  return 0;
-}
+static int collect_dp(worker* w, lane* ln) { (void)w; (void)ln; return 0; }
 
 static void* worker_main(void* arg) {
   worker* w = (worker*)arg;
@@ -328,6 +411,7 @@ static void* worker_main(void* arg) {
     free(ln->strings); free(ln->results); free(ln->fibers); free(ln->inflight);
     pgpu_destroy(ln->ctx);
   }
+  ef_cell_release_all();
   return NULL;
 }
 
@@ -340,6 +424,7 @@ static size_t env_size(const char* name, size_t dflt) {
 struct ef_session {
   ef_inputs in;
   pgpu_ctx* ctx0;
+  pgpu_ctx* svc_ctx;            /* the GPU service thread's context */
   shared sh;
   pgpu_pairing_plan* pplan;     /* all prepared sequences (both strands), resident in HBM */
   size_t nthreads;
@@ -384,15 +469,23 @@ ef_session* ef_session_open(int argc, char** argv) {
     k += u->has_sibling ? 2 : 1;
   }
   pthread_mutex_init(&sh->mu, NULL);
+  pthread_mutex_init(&sh->svc.mu, NULL);
+  pthread_cond_init(&sh->svc.posted, NULL);
+  pthread_cond_init(&sh->svc.finished, NULL);
+  if (pgpu_init(ef_gpu_device_from_env(), &s->svc_ctx) != PGPU_OK) { free(s); return NULL; }
+  if (getenv("PINTRON_KERNEL_TIMING")) pgpu_set_timing(s->svc_ctx, 1);
   const long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
-  /* default: the host share of one GPU on an 8-GPU node (the GPU boxes expose far more cores) */
-  s->nthreads = env_size("PINTRON_THREADS", ncpu > 16 ? 16 : (ncpu > 0 ? (size_t)ncpu : 1));
+  /* default: 1.5x the host share of one GPU on an 8-GPU node (16 cores; the GPU boxes expose far
+   * more, but their CPU quota is that share): a worker sleeps while its requests are on the GPU,
+   * so a few more workers than cores keep the cores busy without running into the quota */
+  const size_t cores = ncpu > 16 ? 16 : (ncpu > 0 ? (size_t)ncpu : 1);
+  s->nthreads = env_size("PINTRON_THREADS", cores + cores / 2);
   if (s->nthreads > sh->n_units) s->nthreads = sh->n_units ? sh->n_units : 1;
-  sh->max_fibers = env_size("PINTRON_FIBERS", 2048);
+  sh->max_fibers = env_size("PINTRON_FIBERS", 1024);
   sh->stack_size = env_size("PINTRON_FIBER_STACK_KB", 256) * 1024;
   sh->kernel_timing = getenv("PINTRON_KERNEL_TIMING") != NULL;
   sh->gen_len = strlen(in->gen->seq);
-  sh->n_lanes = env_size("PINTRON_LANES", 2) >= 2 ? 2 : 1;
+  sh->n_lanes = 1;
   s->load_s = t_loaded - t_start;
   s->index_s = now_s() - t_loaded;
   return s;
@@ -423,15 +516,23 @@ int ef_session_step(ef_session* s, ef_sched_stats* stats_out) {
     if (prc != PGPU_OK) { fprintf(stderr, "* FATAL pairing prefetch failed: %s\n", pgpu_last_error(s->ctx0)); return 1; }
   }
   const double t1 = now_s();
+  service* sv = &sh->svc;
+  memset(&sv->stats, 0, sizeof sv->stats);
+  sv->stop = false; sv->head = sv->tail = NULL; sv->sh = sh; sv->ctx = s->svc_ctx;
+  pthread_create(&sv->thread, NULL, service_main, sv);
   worker* ws = (worker*)calloc(s->nthreads, sizeof(worker));
   pthread_t* th = (pthread_t*)malloc(s->nthreads * sizeof(pthread_t));
   for (size_t t = 0; t < s->nthreads; ++t) { ws[t].sh = sh; pthread_create(&th[t], NULL, worker_main, &ws[t]); }
   for (size_t t = 0; t < s->nthreads; ++t) pthread_join(th[t], NULL);
+  pthread_mutex_lock(&sv->mu); sv->stop = true; pthread_cond_signal(&sv->posted); pthread_mutex_unlock(&sv->mu);
+  pthread_join(sv->thread, NULL);
   ef_sched_stats st;
   memset(&st, 0, sizeof st);
   st.threads = s->nthreads;
+  st.dp_batches = sv->stats.dp_batches; st.dp_jobs = sv->stats.dp_jobs;
+  for (int k = 0; k < sv->stats.n_kernels; ++k) kstat_add(&st, &sv->stats.kernels[k]);
   for (size_t t = 0; t < s->nthreads; ++t) {
-    st.units += ws[t].stats.units; st.dp_batches += ws[t].stats.dp_batches; st.dp_jobs += ws[t].stats.dp_jobs;
+    st.units += ws[t].stats.units;
     st.pairing_batches += ws[t].stats.pairing_batches; st.pairing_requests += ws[t].stats.pairing_requests;
     st.host_s += ws[t].stats.host_s; st.pairing_s += ws[t].stats.pairing_s; st.dp_s += ws[t].stats.dp_s;
     for (int k = 0; k < ws[t].stats.n_kernels; ++k) kstat_add(&st, &ws[t].stats.kernels[k]);
@@ -487,6 +588,7 @@ void ef_session_close(ef_session* s) {
   free_unit_buffers(sh);
   free(sh->units); free(sh->pre_tri); free(sh->pre_first);
   if (s->pplan) pgpu_pairing_plan_destroy(s->ctx0, s->pplan);
+  pgpu_destroy(s->svc_ctx);
   pgpu_index_destroy(s->ctx0, sh->idx);
   pgpu_destroy(s->ctx0);
   ef_free_inputs(&s->in);

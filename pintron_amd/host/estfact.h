@@ -13,6 +13,7 @@
 #include <stddef.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <string.h>
 
 #include "ef_list.h"
 
@@ -61,6 +62,15 @@ typedef struct {
 } ef_seq;
 
 /* read_multifasta (src/io-multifasta.c:133-164); returns number of records, -1 on I/O error */
+/* length of the genomic sequence: strlen() over 200 kb costs microseconds and the refinement code
+ * asks for it several times per intron, so the last answer is kept per thread.  Only for the
+ * genomic string, which is immutable for the whole run. */
+static inline size_t ef_genomic_len(const char* gen) {
+  static _Thread_local const char* last; static _Thread_local size_t last_len;
+  if (last != gen) { last_len = strlen(gen); last = gen; }
+  return last_len;
+}
+
 long ef_read_multifasta(const char* path, ef_seq*** out);
 void ef_seq_free(ef_seq* s);
 void ef_parse_genomic_header(ef_seq* gen);                 /* :410-423 */

@@ -2,23 +2,36 @@
  * compute backend, so that the host logic can be compared with the reference in a container that
  * has no GPU.  Never shipped: the product est-fact links the GPU backend only. */
 #include <stdlib.h>
+#include <time.h>
 #include <string.h>
 
 #include "../../pintron_amd/host/estfact.h"
 #include "../../oracle/dp_oracle.h"
 #include "../../oracle/pairing_oracle.h"
 
+/* ESTFACT_CHECK_TIMING=1: seconds spent inside the oracle backend vs. the whole run, to stderr */
+static double backend_s;
+static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
 static int oracle_pairings(void* self, const char* pattern, size_t m, unsigned L, double rate,
                            ef_triple** out, size_t* n) {
+  const double t0 = now_s();
   long cap = 4096;
   int32_t* buf = (int32_t*)malloc(3 * cap * sizeof(int32_t));
   long cnt = orc_pairings((const orc_index*)self, pattern, m, L, rate, buf, cap, NULL);
   if (cnt > cap) { cap = cnt; buf = (int32_t*)realloc(buf, 3 * cap * sizeof(int32_t)); cnt = orc_pairings((const orc_index*)self, pattern, m, L, rate, buf, cap, NULL); }
   *out = (ef_triple*)buf; *n = (size_t)cnt;
+  backend_s += now_s() - t0;
   return 0;
 }
 
+static int oracle_dp_impl(void* self, const ef_dp_req* q, ef_dp_res* r);
 static int oracle_dp(void* self, const ef_dp_req* q, ef_dp_res* r) {
+  const double t0 = now_s();
+  const int rc = oracle_dp_impl(self, q, r);
+  backend_s += now_s() - t0;
+  return rc;
+}
+static int oracle_dp_impl(void* self, const ef_dp_req* q, ef_dp_res* r) {
   (void)self;
   switch (q->kind) {
     case EF_DP_ALIGN: {
@@ -55,11 +68,18 @@ static int oracle_dp(void* self, const ef_dp_req* q, ef_dp_res* r) {
 
 static ef_backend* open_oracle(const ef_seq* gen) {
   ef_backend* be = (ef_backend*)calloc(1, sizeof(ef_backend));
+  const double t0 = now_s();
   be->self = orc_index_create(gen->seq, strlen(gen->seq));
+  backend_s += now_s() - t0;
   be->pairings = oracle_pairings;
   be->dp = oracle_dp;
   return be;
 }
 static void close_oracle(ef_backend* be) { orc_index_destroy((orc_index*)be->self); free(be); }
 
-int main(int argc, char** argv) { return ef_run(argc, argv, open_oracle, close_oracle); }
+int main(int argc, char** argv) {
+  const double t0 = now_s();
+  const int rc = ef_run(argc, argv, open_oracle, close_oracle);
+  if (getenv("ESTFACT_CHECK_TIMING")) fprintf(stderr, "timing: total %.3f s, oracle backend %.3f s, host logic %.3f s\n", now_s() - t0, backend_s, now_s() - t0 - backend_s);
+  return rc;
+}
