@@ -50,7 +50,7 @@ class SchedStats(C.Structure):
 
 
 def load_host_lib():
-    path = os.path.join(ROOT, "pintron_amd", "lib", "libestfact.so")
+    path = os.environ.get("PINTRON_ESTFACT_LIB") or os.path.join(ROOT, "pintron_amd", "lib", "libestfact.so")
     if not os.path.exists(path):
         raise SystemExit("%s missing: run __graft_entry__.build() (there is no CPU fallback)" % path)
     L = C.CDLL(path)

@@ -32,6 +32,10 @@ extern _Thread_local ef_cell* ef_cell_free_list;
 extern _Thread_local long ef_cell_live;
 void ef_cell_refill(void);
 void ef_cell_release_all(void);
+#ifdef EF_NO_CELL_POOL                       /* measurement aid: plain malloc/free */
+static inline void* ef_cell_get(void) { return malloc(sizeof(ef_cell)); }
+static inline void ef_cell_put(void* p) { free(p); }
+#else
 static inline void* ef_cell_get(void) {
   if (!ef_cell_free_list) ef_cell_refill();
   ef_cell* c = ef_cell_free_list; ef_cell_free_list = c->next; ++ef_cell_live;
@@ -40,6 +44,7 @@ static inline void* ef_cell_get(void) {
 static inline void ef_cell_put(void* p) {
   ef_cell* c = (ef_cell*)p; c->next = ef_cell_free_list; ef_cell_free_list = c; --ef_cell_live;
 }
+#endif
 typedef char ef_cell_size_check[(sizeof(ef_list) <= sizeof(ef_cell) && sizeof(ef_node) <= sizeof(ef_cell)) ? 1 : -1];
 #define EFL_NODE_NEW() ((ef_node*)ef_cell_get())
 #define EFL_NODE_DEL(n) ef_cell_put(n)

@@ -41,6 +41,7 @@ typedef struct fiber {
   ef_dp_req req; ef_dp_res* res; int rc;
   const char* pat; size_t pat_len; unsigned pat_L; double pat_rate; ef_triple** pat_out; size_t* pat_n;
   ef_backend be;
+  struct fiber* pool_next;   /* free fibres (struct + stack) are kept for the next EST */
 } fiber;
 
 /* one input EST: entry `first` of the prepared list, plus the sibling at first+1 if any */
@@ -95,7 +96,15 @@ typedef struct shared {
   service svc;
   int failed;
   ef_sched_stats stats;
+  /* fibres (256 KB stacks) are recycled: within a worker through its own free list, across steps
+   * through this one (under mu) */
+  fiber* fiber_pool;
+  /* output text of the units lives in large chunks owned by the step (freed together) */
+  struct out_chunk* chunks;              /* under mu */
+  struct out_chunk* spare_chunks;        /* chunks of the previous step, reused (their pages stay mapped) */
 } shared;
+
+typedef struct out_chunk { struct out_chunk* next; size_t cap, used; char data[]; } out_chunk;
 
 /* A worker keeps two independent sets of fibres ("lanes"), each with its own context (stream +
  * device scratch): while the DP batch of one lane executes on the GPU, the fibres of the other
@@ -113,6 +122,8 @@ typedef struct lane {
 typedef struct worker {
   shared* sh;
   ucontext_t sched;
+  fiber* free_fibers;
+  out_chunk* chunk;                      /* current output chunk of this worker */
   lane lanes[2];
   ef_sched_stats stats;
 } worker;
@@ -152,12 +163,35 @@ static int fiber_pairings(void* self, const char* pattern, size_t m, unsigned L,
   return f->rc;
 }
 
+/* room for n bytes of output text in the worker's current chunk */
+static char* out_alloc(worker* w, size_t n) {
+  out_chunk* c = w->chunk;
+  if (!c || c->used + n > c->cap) {
+    const size_t cap = n > (1u << 20) ? n : (1u << 20);
+    shared* sh = w->sh;
+    c = NULL;
+    pthread_mutex_lock(&sh->mu);
+    if (sh->spare_chunks && sh->spare_chunks->cap >= n) { c = sh->spare_chunks; sh->spare_chunks = c->next; }
+    pthread_mutex_unlock(&sh->mu);
+    if (!c) { c = (out_chunk*)malloc(sizeof(out_chunk) + cap); c->cap = cap; }
+    c->used = 0;
+    pthread_mutex_lock(&sh->mu);
+    c->next = sh->chunks; sh->chunks = c;
+    pthread_mutex_unlock(&sh->mu);
+    w->chunk = c;
+  }
+  char* r = c->data + c->used;
+  c->used += n;
+  return r;
+}
+
 static void fiber_main(unsigned hi, unsigned lo) {
   fiber* f = (fiber*)(((uintptr_t)hi << 32) | (uintptr_t)lo);
   shared* sh = f->w->sh;
   unit* u = &sh->units[f->unit];
   FILE* fs[6];
-  for (int k = 0; k < 6; ++k) fs[k] = open_memstream(&u->buf[k], &u->len[k]);
+  char* mbuf[6]; size_t mlen[6];
+  for (int k = 0; k < 6; ++k) fs[k] = open_memstream(&mbuf[k], &mlen[k]);
   ef_side_files side = { fs[2], fs[3], fs[4], fs[5] };
   const ef_inputs* in = sh->in;
   for (size_t k = u->first; k <= u->first + (u->has_sibling ? 1 : 0); ++k) {
@@ -171,7 +205,13 @@ static void fiber_main(unsigned hi, unsigned lo) {
     ef_est_free(fe);
     if (aligned) break;
   }
-  for (int k = 0; k < 6; ++k) fclose(fs[k]);
+  for (int k = 0; k < 6; ++k) {
+    fclose(fs[k]);
+    u->len[k] = mlen[k];
+    u->buf[k] = mlen[k] ? out_alloc(f->w, mlen[k]) : NULL;
+    if (mlen[k]) memcpy(u->buf[k], mbuf[k], mlen[k]);
+    free(mbuf[k]);
+  }
   f->state = F_DONE;
   swapcontext(&f->ctx, &f->w->sched);
 }
@@ -180,12 +220,15 @@ static void fiber_main(unsigned hi, unsigned lo) {
 static bool start_fiber(worker* w, int li) {
   shared* sh = w->sh;
   lane* ln = &w->lanes[li];
+  fiber* f = w->free_fibers;
   pthread_mutex_lock(&sh->mu);
   const size_t u = sh->next_unit < sh->n_units ? sh->next_unit++ : (size_t)-1;
+  if (u != (size_t)-1 && !f && sh->fiber_pool) { f = sh->fiber_pool; sh->fiber_pool = f->pool_next; f->pool_next = NULL; }
+  else if (u != (size_t)-1 && f) w->free_fibers = f->pool_next;
   pthread_mutex_unlock(&sh->mu);
   if (u == (size_t)-1) return false;
-  fiber* f = (fiber*)calloc(1, sizeof(fiber));
-  f->stack = (char*)malloc(sh->stack_size);
+  if (f) { char* st = f->stack; memset(f, 0, sizeof(fiber)); f->stack = st; }
+  else { f = (fiber*)calloc(1, sizeof(fiber)); f->stack = (char*)malloc(sh->stack_size); }
   f->w = w; f->unit = u; f->state = F_RUNNABLE; f->lane = li;
   f->be.self = f; f->be.pairings = fiber_pairings; f->be.dp = fiber_dp;
   getcontext(&f->ctx);
@@ -389,7 +432,7 @@ static void* worker_main(void* arg) {
       size_t keep = 0;
       for (size_t i = 0; i < ln->n_fibers; ++i) {
         fiber* f = ln->fibers[i];
-        if (f->state == F_DONE) { free(f->stack); free(f); w->stats.units++; }
+        if (f->state == F_DONE) { f->pool_next = w->free_fibers; w->free_fibers = f; w->stats.units++; }
         else ln->fibers[keep++] = f;
       }
       ln->n_fibers = keep;
@@ -410,6 +453,14 @@ static void* worker_main(void* arg) {
     ef_jobbuf_free(&ln->jb);
     free(ln->strings); free(ln->results); free(ln->fibers); free(ln->inflight);
     pgpu_destroy(ln->ctx);
+  }
+  if (w->free_fibers) {
+    fiber* last = w->free_fibers;
+    while (last->pool_next) last = last->pool_next;
+    pthread_mutex_lock(&sh->mu);
+    last->pool_next = sh->fiber_pool; sh->fiber_pool = w->free_fibers;
+    pthread_mutex_unlock(&sh->mu);
+    w->free_fibers = NULL;
   }
   ef_cell_release_all();
   return NULL;
@@ -491,9 +542,12 @@ ef_session* ef_session_open(int argc, char** argv) {
   return s;
 }
 
-static void free_unit_buffers(shared* sh) {
+/* forget the previous step's output; its chunks are kept for the next step unless `release` */
+static void free_unit_buffers(shared* sh, bool release) {
   for (size_t u = 0; u < sh->n_units; ++u)
-    for (int k = 0; k < 6; ++k) { free(sh->units[u].buf[k]); sh->units[u].buf[k] = NULL; sh->units[u].len[k] = 0; }
+    for (int k = 0; k < 6; ++k) { sh->units[u].buf[k] = NULL; sh->units[u].len[k] = 0; }
+  while (sh->chunks) { out_chunk* nx = sh->chunks->next; sh->chunks->next = sh->spare_chunks; sh->spare_chunks = sh->chunks; sh->chunks = nx; }
+  if (release) while (sh->spare_chunks) { out_chunk* nx = sh->spare_chunks->next; free(sh->spare_chunks); sh->spare_chunks = nx; }
 }
 
 /* one pass of the whole hot path over the batch: pairing prefetch (resident patterns), then the
@@ -501,12 +555,17 @@ static void free_unit_buffers(shared* sh) {
 int ef_session_step(ef_session* s, ef_sched_stats* stats_out) {
   shared* sh = &s->sh;
   const double t0 = now_s();
-  free_unit_buffers(sh);
+  free_unit_buffers(sh, false);
+  const double t_f1 = now_s();
   free(sh->pre_tri); free(sh->pre_first); sh->pre_tri = NULL; sh->pre_first = NULL;
   sh->next_unit = 0; sh->failed = 0;
+  const double t_freed = now_s();
+  if (getenv("PINTRON_VERBOSE")) fprintf(stderr, "* step: free unit buffers %.3fs, free pairings %.3fs\n", t_f1 - t0, t_freed - t_f1);
+  double t_run = t_freed;
   if (s->pplan) {
     pgpu_pairing_params prm = { s->in.cfg.min_factor_len, 0, s->in.cfg.min_string_depth_rate };
     int prc = pgpu_pairing_plan_run(s->ctx0, s->pplan, &prm);
+    t_run = now_s();
     if (prc == PGPU_OK) {
       const size_t cnt = (size_t)pgpu_pairing_plan_count(s->pplan);
       sh->pre_tri = (pgpu_pairing*)malloc((cnt + 1) * sizeof(pgpu_pairing));
@@ -516,6 +575,7 @@ int ef_session_step(ef_session* s, ef_sched_stats* stats_out) {
     if (prc != PGPU_OK) { fprintf(stderr, "* FATAL pairing prefetch failed: %s\n", pgpu_last_error(s->ctx0)); return 1; }
   }
   const double t1 = now_s();
+  if (getenv("PINTRON_VERBOSE")) fprintf(stderr, "* step: free previous %.3fs, pairing kernels %.3fs, fetch %.3fs (%zu pairings)\n", t_freed - t0, t_run - t_freed, t1 - t_run, s->pplan ? (size_t)pgpu_pairing_plan_count(s->pplan) : (size_t)0);
   service* sv = &sh->svc;
   memset(&sv->stats, 0, sizeof sv->stats);
   sv->stop = false; sv->head = sv->tail = NULL; sv->sh = sh; sv->ctx = s->svc_ctx;
@@ -585,7 +645,8 @@ size_t ef_session_n_ests(const ef_session* s) { return s->sh.n_units; }
 void ef_session_close(ef_session* s) {
   if (!s) return;
   shared* sh = &s->sh;
-  free_unit_buffers(sh);
+  free_unit_buffers(sh, true);
+  while (sh->fiber_pool) { fiber* nx = sh->fiber_pool->pool_next; free(sh->fiber_pool->stack); free(sh->fiber_pool); sh->fiber_pool = nx; }
   free(sh->units); free(sh->pre_tri); free(sh->pre_first);
   if (s->pplan) pgpu_pairing_plan_destroy(s->ctx0, s->pplan);
   pgpu_destroy(s->svc_ctx);
