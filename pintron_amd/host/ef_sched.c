@@ -16,7 +16,58 @@
 #include <time.h>
 #include <stdlib.h>
 #include <string.h>
+#include <stdint.h>
 #include <ucontext.h>
+
+/* ---- fibre context switch --------------------------------------------------------------------------
+ * swapcontext() saves and restores the signal mask with a system call on every switch; an EST
+ * yields ~20 times, so on x86-64 the switch is done by hand: callee-saved registers on the own
+ * stack, exchange the stack pointers.  Elsewhere ucontext is used. */
+#if defined(__x86_64__) && !defined(EF_USE_UCONTEXT)
+typedef struct { void* sp; } ef_ctx;
+void ef_ctx_switch(void** save_sp, void* new_sp);
+void ef_ctx_entry(void);
+__asm__(
+  ".text\n"
+  ".globl ef_ctx_switch\n.type ef_ctx_switch,@function\n"
+  "ef_ctx_switch:\n"
+  "  pushq %rbp\n  pushq %rbx\n  pushq %r12\n  pushq %r13\n  pushq %r14\n  pushq %r15\n"
+  "  movq %rsp, (%rdi)\n  movq %rsi, %rsp\n"
+  "  popq %r15\n  popq %r14\n  popq %r13\n  popq %r12\n  popq %rbx\n  popq %rbp\n"
+  "  ret\n"
+  ".size ef_ctx_switch,.-ef_ctx_switch\n"
+  ".globl ef_ctx_entry\n.type ef_ctx_entry,@function\n"
+  "ef_ctx_entry:\n"                     /* first activation: r12 = argument, r13 = function */
+  "  movq %r12, %rdi\n  callq *%r13\n  ud2\n"
+  ".size ef_ctx_entry,.-ef_ctx_entry\n");
+static inline void ctx_switch(ef_ctx* from, ef_ctx* to) { ef_ctx_switch(&from->sp, to->sp); }
+/* fn(arg) starts on the given stack at the first switch to c; fn must not return */
+static void ctx_make(ef_ctx* c, char* stack, size_t size, void (*fn)(void*), void* arg) {
+  uintptr_t top = ((uintptr_t)stack + size) & ~(uintptr_t)15;
+  void** S = (void**)(top - 16);         /* 16-byte aligned: the call in ef_ctx_entry leaves rsp = 8 mod 16 */
+  S[-1] = (void*)ef_ctx_entry;           /* return address of the first switch */
+  S[-2] = NULL;                          /* rbp */
+  S[-3] = NULL;                          /* rbx */
+  S[-4] = arg;                           /* r12 */
+  S[-5] = (void*)fn;                     /* r13 */
+  S[-6] = NULL;                          /* r14 */
+  S[-7] = NULL;                          /* r15 */
+  c->sp = (void*)(S - 7);
+}
+#else
+typedef struct { ucontext_t uc; } ef_ctx;
+static inline void ctx_switch(ef_ctx* from, ef_ctx* to) { swapcontext(&from->uc, &to->uc); }
+static void ctx_tramp(unsigned fh, unsigned fl, unsigned ah, unsigned al) {
+  void (*fn)(void*) = (void (*)(void*))(((uintptr_t)fh << 32) | (uintptr_t)fl);
+  fn((void*)(((uintptr_t)ah << 32) | (uintptr_t)al));
+}
+static void ctx_make(ef_ctx* c, char* stack, size_t size, void (*fn)(void*), void* arg) {
+  getcontext(&c->uc);
+  c->uc.uc_stack.ss_sp = stack; c->uc.uc_stack.ss_size = size; c->uc.uc_link = NULL;
+  const uintptr_t f = (uintptr_t)fn, a = (uintptr_t)arg;
+  makecontext(&c->uc, (void (*)(void))ctx_tramp, 4, (unsigned)(f >> 32), (unsigned)(f & 0xffffffffu), (unsigned)(a >> 32), (unsigned)(a & 0xffffffffu));
+}
+#endif
 #include <unistd.h>
 
 #include "estfact.h"
@@ -30,7 +81,7 @@ static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &
 struct worker;
 
 typedef struct fiber {
-  ucontext_t ctx;
+  ef_ctx ctx;
   char* stack;
   struct worker* w;
   int state;
@@ -121,7 +172,7 @@ typedef struct lane {
 
 typedef struct worker {
   shared* sh;
-  ucontext_t sched;
+  ef_ctx sched;
   fiber* free_fibers;
   out_chunk* chunk;                      /* current output chunk of this worker */
   lane lanes[2];
@@ -142,7 +193,7 @@ static void kstat_add(ef_sched_stats* st, const ef_kernel_stat* k) {
 static int fiber_dp(void* self, const ef_dp_req* q, ef_dp_res* res) {
   fiber* f = (fiber*)self;
   f->req = *q; f->res = res; f->state = F_WAIT_DP;
-  swapcontext(&f->ctx, &f->w->sched);
+  ctx_switch(&f->ctx, &f->w->sched);
   return f->rc;
 }
 
@@ -159,7 +210,7 @@ static int fiber_pairings(void* self, const char* pattern, size_t m, unsigned L,
   }
   f->pat = pattern; f->pat_len = m; f->pat_L = L; f->pat_rate = rate; f->pat_out = out; f->pat_n = n;
   f->state = F_WAIT_PAIR;
-  swapcontext(&f->ctx, &f->w->sched);
+  ctx_switch(&f->ctx, &f->w->sched);
   return f->rc;
 }
 
@@ -185,8 +236,8 @@ static char* out_alloc(worker* w, size_t n) {
   return r;
 }
 
-static void fiber_main(unsigned hi, unsigned lo) {
-  fiber* f = (fiber*)(((uintptr_t)hi << 32) | (uintptr_t)lo);
+static void fiber_main(void* arg) {
+  fiber* f = (fiber*)arg;
   shared* sh = f->w->sh;
   unit* u = &sh->units[f->unit];
   FILE* fs[6];
@@ -213,7 +264,7 @@ static void fiber_main(unsigned hi, unsigned lo) {
     free(mbuf[k]);
   }
   f->state = F_DONE;
-  swapcontext(&f->ctx, &f->w->sched);
+  ctx_switch(&f->ctx, &f->w->sched);
 }
 
 /* ---- worker side --------------------------------------------------------------------------------- */
@@ -231,10 +282,7 @@ static bool start_fiber(worker* w, int li) {
   else { f = (fiber*)calloc(1, sizeof(fiber)); f->stack = (char*)malloc(sh->stack_size); }
   f->w = w; f->unit = u; f->state = F_RUNNABLE; f->lane = li;
   f->be.self = f; f->be.pairings = fiber_pairings; f->be.dp = fiber_dp;
-  getcontext(&f->ctx);
-  f->ctx.uc_stack.ss_sp = f->stack; f->ctx.uc_stack.ss_size = sh->stack_size; f->ctx.uc_link = &w->sched;
-  const uintptr_t p = (uintptr_t)f;
-  makecontext(&f->ctx, (void (*)(void))fiber_main, 2, (unsigned)(p >> 32), (unsigned)(p & 0xffffffffu));
+  ctx_make(&f->ctx, f->stack, sh->stack_size, fiber_main, f);
   ln->fibers[ln->n_fibers++] = f;
   return true;
 }
@@ -427,7 +475,7 @@ static void* worker_main(void* arg) {
       t0 = now_s();
       for (size_t i = 0; i < ln->n_fibers; ++i) {
         fiber* f = ln->fibers[i];
-        if (f->state == F_RUNNABLE) swapcontext(&w->sched, &f->ctx);
+        if (f->state == F_RUNNABLE) ctx_switch(&w->sched, &f->ctx);
       }
       size_t keep = 0;
       for (size_t i = 0; i < ln->n_fibers; ++i) {
