@@ -120,15 +120,22 @@ typedef struct dp_request {
   struct dp_request* next;
 } dp_request;
 
-typedef struct service {
+#define MAX_SERVICES 4
+typedef struct service_thread {          /* one submitter: own context (stream, device buffers) */
   pthread_t thread;
+  struct service* sv;
+  pgpu_ctx* ctx;
+  ef_sched_stats stats;                  /* batches, jobs, kernel timings */
+} service_thread;
+
+typedef struct service {
   pthread_mutex_t mu;
   pthread_cond_t posted, finished;
   dp_request *head, *tail;
   bool stop;
-  pgpu_ctx* ctx;
   struct shared* sh;
-  ef_sched_stats stats;                  /* batches, jobs, kernel timings */
+  int n_threads;                         /* PINTRON_SERVICES: batches of different submitters overlap on the GPU */
+  service_thread threads[MAX_SERVICES];
 } service;
 
 typedef struct shared {
@@ -157,16 +164,14 @@ typedef struct shared {
 
 typedef struct out_chunk { struct out_chunk* next; size_t cap, used; char data[]; } out_chunk;
 
-/* A worker keeps two independent sets of fibres ("lanes"), each with its own context (stream +
- * device scratch): while the DP batch of one lane executes on the GPU, the fibres of the other
- * lane run on the CPU, so host logic and device work of one thread overlap. */
+/* A worker keeps several independent sets of fibres ("lanes"): while the requests of one lane are
+ * with the GPU service, the fibres of the other lanes run on the CPU, so the worker only sleeps
+ * when every lane is waiting. */
+#define MAX_LANES 4
 typedef struct lane {
-  pgpu_ctx* ctx;
   fiber** fibers; size_t n_fibers;
   ef_jobbuf jb;
-  char* strings; size_t strings_cap;
-  pgpu_dp_result* results; size_t results_cap;
-  pgpu_dp_plan* plan;            /* batch in flight (launched, not yet fetched) */
+  dp_request rq; bool posted;    /* requests handed to the GPU service, not yet collected */
   fiber** inflight; size_t n_inflight;
 } lane;
 
@@ -175,7 +180,8 @@ typedef struct worker {
   ef_ctx sched;
   fiber* free_fibers;
   out_chunk* chunk;                      /* current output chunk of this worker */
-  lane lanes[2];
+  lane lanes[MAX_LANES];
+  pgpu_ctx* ctx;                         /* for pairing retries only; created on first use */
   ef_sched_stats stats;
 } worker;
 
@@ -309,13 +315,14 @@ static int submit_pairings(worker* w, lane* ln) {
     off[ng] = pos;
     pgpu_pairing_plan* plan = NULL;
     pgpu_pairing_params prm = { L, 0, rate };
-    rc = pgpu_pairing_plan_create(ln->ctx, w->sh->idx, blob, off, ng, &plan);
-    if (rc == PGPU_OK) rc = pgpu_pairing_plan_run(ln->ctx, plan, &prm);
+    if (!w->ctx && pgpu_init(ef_gpu_device_from_env(), &w->ctx) != PGPU_OK) { free(blob); free(off); free(grp); free(wait); return 1; }
+    rc = pgpu_pairing_plan_create(w->ctx, w->sh->idx, blob, off, ng, &plan);
+    if (rc == PGPU_OK) rc = pgpu_pairing_plan_run(w->ctx, plan, &prm);
     if (rc == PGPU_OK) {
       const size_t cnt = (size_t)pgpu_pairing_plan_count(plan);
       pgpu_pairing* out = (pgpu_pairing*)malloc((cnt + 1) * sizeof(pgpu_pairing));
       uint64_t* first = (uint64_t*)malloc((ng + 1) * sizeof(uint64_t));
-      rc = pgpu_pairing_plan_fetch(ln->ctx, plan, out, cnt, first);
+      rc = pgpu_pairing_plan_fetch(w->ctx, plan, out, cnt, first);
       if (rc == PGPU_OK) {
         for (size_t i = 0; i < ng; ++i) {
           const size_t n = (size_t)(first[i + 1] - first[i]);
@@ -328,8 +335,8 @@ static int submit_pairings(worker* w, lane* ln) {
       }
       free(out); free(first);
     }
-    if (plan) pgpu_pairing_plan_destroy(ln->ctx, plan);
-    if (rc != PGPU_OK) fprintf(stderr, "* FATAL pairing batch failed: %s\n", pgpu_last_error(ln->ctx));
+    if (plan) pgpu_pairing_plan_destroy(w->ctx, plan);
+    if (rc != PGPU_OK) fprintf(stderr, "* FATAL pairing batch failed: %s\n", pgpu_last_error(w->ctx));
     free(blob); free(off); free(grp);
     nw = rest;
   }
@@ -341,7 +348,8 @@ static void kstat_add(ef_sched_stats* st, const ef_kernel_stat* k);
 
 /* service thread: merge everything posted, run it as one plan, publish the results */
 static void* service_main(void* arg) {
-  service* sv = (service*)arg;
+  service_thread* me = (service_thread*)arg;
+  service* sv = me->sv;
   shared* sh = sv->sh;
   pgpu_dp_job* jobs = NULL; size_t jobs_cap = 0;
   char* arena = NULL; size_t arena_cap = 0;
@@ -373,13 +381,13 @@ static void* service_main(void* arg) {
     mb->refs = nreq;
     mb->results = (pgpu_dp_result*)malloc((nj + 1) * sizeof(pgpu_dp_result));
     pgpu_dp_plan* plan = NULL;
-    int rc = pgpu_dp_plan_create(sv->ctx, sh->idx, jobs, nj, arena, apos, &plan);
-    if (rc == PGPU_OK) rc = pgpu_dp_plan_launch(sv->ctx, plan);
-    if (rc == PGPU_OK) rc = pgpu_dp_plan_sync(sv->ctx, plan);
+    int rc = pgpu_dp_plan_create(me->ctx, sh->idx, jobs, nj, arena, apos, &plan);
+    if (rc == PGPU_OK) rc = pgpu_dp_plan_launch(me->ctx, plan);
+    if (rc == PGPU_OK) rc = pgpu_dp_plan_sync(me->ctx, plan);
     if (rc == PGPU_OK) {
       const size_t sb = pgpu_dp_plan_string_bytes(plan);
       mb->strings = (char*)malloc(sb + 16);
-      rc = pgpu_dp_plan_fetch(sv->ctx, plan, mb->results, mb->strings, sb + 16);
+      rc = pgpu_dp_plan_fetch(me->ctx, plan, mb->results, mb->strings, sb + 16);
     }
     if (rc == PGPU_OK && sh->kernel_timing) {
       const int ng = pgpu_dp_plan_n_groups(plan);
@@ -389,12 +397,12 @@ static void* service_main(void* arg) {
         ef_kernel_stat ks; memset(&ks, 0, sizeof ks);
         snprintf(ks.name, sizeof ks.name, "%s", gi.name);
         ks.ms = gi.ms; ks.launches = 1; ks.jobs = gi.jobs; ks.cells = gi.cells; ks.algo_bytes = gi.algo_bytes;
-        kstat_add(&sv->stats, &ks);
+        kstat_add(&me->stats, &ks);
       }
     }
-    if (plan) pgpu_dp_plan_destroy(sv->ctx, plan);
-    if (rc != PGPU_OK) fprintf(stderr, "* FATAL DP batch failed: %s\n", pgpu_last_error(sv->ctx));
-    sv->stats.dp_batches++; sv->stats.dp_jobs += nj;
+    if (plan) pgpu_dp_plan_destroy(me->ctx, plan);
+    if (rc != PGPU_OK) fprintf(stderr, "* FATAL DP batch failed: %s\n", pgpu_last_error(me->ctx));
+    me->stats.dp_batches++; me->stats.dp_jobs += nj;
     pthread_mutex_lock(&sv->mu);
     for (dp_request* r = list; r;) { dp_request* nx = r->next; r->batch = mb; r->rc = rc; r->done = true; r = nx; }
     pthread_cond_broadcast(&sv->finished);
@@ -404,7 +412,7 @@ static void* service_main(void* arg) {
   return NULL;
 }
 
-/* post the pending DP requests of a lane, sleep until the merged batch is back, decode */
+/* post the pending DP requests of a lane to the GPU service (does not wait) */
 static int launch_dp(worker* w, lane* ln) {
   shared* sh = w->sh;
   service* sv = &sh->svc;
@@ -418,33 +426,43 @@ static int launch_dp(worker* w, lane* ln) {
     ln->inflight[ln->n_inflight++] = f;
   }
   if (ln->n_inflight == 0) return 0;
-  dp_request rq;
-  memset(&rq, 0, sizeof rq);
-  rq.jobs = ln->jb.jobs; rq.n = ln->n_inflight; rq.arena = ln->jb.arena; rq.arena_len = ln->jb.arena_len;
+  dp_request* rq = &ln->rq;
+  memset(rq, 0, sizeof *rq);
+  rq->jobs = ln->jb.jobs; rq->n = ln->n_inflight; rq->arena = ln->jb.arena; rq->arena_len = ln->jb.arena_len;
   pthread_mutex_lock(&sv->mu);
-  if (sv->tail) sv->tail->next = &rq; else sv->head = &rq;
-  sv->tail = &rq;
+  if (sv->tail) sv->tail->next = rq; else sv->head = rq;
+  sv->tail = rq;
   pthread_cond_signal(&sv->posted);
-  while (!rq.done) pthread_cond_wait(&sv->finished, &sv->mu);
   pthread_mutex_unlock(&sv->mu);
-  int rc = rq.rc;
+  ln->posted = true;
+  return 0;
+}
+
+/* sleep until the lane's posted requests are back, then decode this lane's slice */
+static int collect_dp(worker* w, lane* ln) {
+  if (!ln->posted) return 0;
+  service* sv = &w->sh->svc;
+  dp_request* rq = &ln->rq;
+  pthread_mutex_lock(&sv->mu);
+  while (!rq->done) pthread_cond_wait(&sv->finished, &sv->mu);
+  pthread_mutex_unlock(&sv->mu);
+  ln->posted = false;
+  const int rc = rq->rc;
   if (rc == PGPU_OK) {
     for (size_t i = 0; i < ln->n_inflight; ++i) {
       fiber* f = ln->inflight[i];
-      f->rc = ef_decode_result(f->req.kind, &rq.batch->results[rq.base + i], rq.batch->strings, f->res);
+      f->rc = ef_decode_result(f->req.kind, &rq->batch->results[rq->base + i], rq->batch->strings, f->res);
       if (f->rc != 0) fprintf(stderr, "* FATAL DP job of kind %d (%zu x %zu) exceeds the device limits\n", f->req.kind, f->req.la, f->req.lb);
       f->state = F_RUNNABLE;
     }
   }
   pthread_mutex_lock(&sv->mu);
-  const bool last = --rq.batch->refs == 0;
+  const bool last = --rq->batch->refs == 0;
   pthread_mutex_unlock(&sv->mu);
-  if (last) { free(rq.batch->results); free(rq.batch->strings); free(rq.batch); }
+  if (last) { free(rq->batch->results); free(rq->batch->strings); free(rq->batch); }
   ln->n_inflight = 0;
   return rc;
 }
-
-static int collect_dp(worker* w, lane* ln) { (void)w; (void)ln; return 0; }
 
 static void* worker_main(void* arg) {
   worker* w = (worker*)arg;
@@ -453,8 +471,6 @@ static void* worker_main(void* arg) {
   const size_t per_lane = sh->max_fibers / n_lanes ? sh->max_fibers / n_lanes : 1;
   for (int li = 0; li < n_lanes; ++li) {
     lane* ln = &w->lanes[li];
-    if (pgpu_init(ef_gpu_device_from_env(), &ln->ctx) != PGPU_OK) { sh->failed = 1; return NULL; }
-    if (sh->kernel_timing) pgpu_set_timing(ln->ctx, 1);
     ln->fibers = (fiber**)malloc(per_lane * sizeof(fiber*));
     ln->inflight = (fiber**)malloc(per_lane * sizeof(fiber*));
     ef_jobbuf_init(&ln->jb);
@@ -497,11 +513,11 @@ static void* worker_main(void* arg) {
   }
   for (int li = 0; li < n_lanes; ++li) {
     lane* ln = &w->lanes[li];
-    if (ln->plan) { pgpu_dp_plan_sync(ln->ctx, ln->plan); pgpu_dp_plan_destroy(ln->ctx, ln->plan); }
+    collect_dp(w, ln);                   /* only after a failure: do not leave a posted request behind */
     ef_jobbuf_free(&ln->jb);
-    free(ln->strings); free(ln->results); free(ln->fibers); free(ln->inflight);
-    pgpu_destroy(ln->ctx);
+    free(ln->fibers); free(ln->inflight);
   }
+  if (w->ctx) pgpu_destroy(w->ctx);
   if (w->free_fibers) {
     fiber* last = w->free_fibers;
     while (last->pool_next) last = last->pool_next;
@@ -523,7 +539,6 @@ static size_t env_size(const char* name, size_t dflt) {
 struct ef_session {
   ef_inputs in;
   pgpu_ctx* ctx0;
-  pgpu_ctx* svc_ctx;            /* the GPU service thread's context */
   shared sh;
   pgpu_pairing_plan* pplan;     /* all prepared sequences (both strands), resident in HBM */
   size_t nthreads;
@@ -571,20 +586,25 @@ ef_session* ef_session_open(int argc, char** argv) {
   pthread_mutex_init(&sh->svc.mu, NULL);
   pthread_cond_init(&sh->svc.posted, NULL);
   pthread_cond_init(&sh->svc.finished, NULL);
-  if (pgpu_init(ef_gpu_device_from_env(), &s->svc_ctx) != PGPU_OK) { free(s); return NULL; }
-  if (getenv("PINTRON_KERNEL_TIMING")) pgpu_set_timing(s->svc_ctx, 1);
+  sh->svc.n_threads = (int)env_size("PINTRON_SERVICES", 1);
+  if (sh->svc.n_threads > MAX_SERVICES) sh->svc.n_threads = MAX_SERVICES;
+  for (int k = 0; k < sh->svc.n_threads; ++k) {
+    if (pgpu_init(ef_gpu_device_from_env(), &sh->svc.threads[k].ctx) != PGPU_OK) { free(s); return NULL; }
+    if (getenv("PINTRON_KERNEL_TIMING")) pgpu_set_timing(sh->svc.threads[k].ctx, 1);
+  }
   const long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
-  /* default: 1.5x the host share of one GPU on an 8-GPU node (16 cores; the GPU boxes expose far
-   * more, but their CPU quota is that share): a worker sleeps while its requests are on the GPU,
-   * so a few more workers than cores keep the cores busy without running into the quota */
+  /* default: the host share of one GPU on an 8-GPU node (16 cores; the GPU boxes expose far more,
+   * but their CPU quota is that share).  The workers hide the GPU latency with lanes, not with
+   * oversubscription. */
   const size_t cores = ncpu > 16 ? 16 : (ncpu > 0 ? (size_t)ncpu : 1);
-  s->nthreads = env_size("PINTRON_THREADS", cores + cores / 2);
+  s->nthreads = env_size("PINTRON_THREADS", cores);
   if (s->nthreads > sh->n_units) s->nthreads = sh->n_units ? sh->n_units : 1;
-  sh->max_fibers = env_size("PINTRON_FIBERS", 1024);
+  sh->max_fibers = env_size("PINTRON_FIBERS", 1536);
   sh->stack_size = env_size("PINTRON_FIBER_STACK_KB", 256) * 1024;
   sh->kernel_timing = getenv("PINTRON_KERNEL_TIMING") != NULL;
   sh->gen_len = strlen(in->gen->seq);
-  sh->n_lanes = 1;
+  sh->n_lanes = (int)env_size("PINTRON_LANES", 3);
+  if (sh->n_lanes > MAX_LANES) sh->n_lanes = MAX_LANES;
   s->load_s = t_loaded - t_start;
   s->index_s = now_s() - t_loaded;
   return s;
@@ -625,20 +645,26 @@ int ef_session_step(ef_session* s, ef_sched_stats* stats_out) {
   const double t1 = now_s();
   if (getenv("PINTRON_VERBOSE")) fprintf(stderr, "* step: free previous %.3fs, pairing kernels %.3fs, fetch %.3fs (%zu pairings)\n", t_freed - t0, t_run - t_freed, t1 - t_run, s->pplan ? (size_t)pgpu_pairing_plan_count(s->pplan) : (size_t)0);
   service* sv = &sh->svc;
-  memset(&sv->stats, 0, sizeof sv->stats);
-  sv->stop = false; sv->head = sv->tail = NULL; sv->sh = sh; sv->ctx = s->svc_ctx;
-  pthread_create(&sv->thread, NULL, service_main, sv);
+  sv->stop = false; sv->head = sv->tail = NULL; sv->sh = sh;
+  for (int k = 0; k < sv->n_threads; ++k) {
+    memset(&sv->threads[k].stats, 0, sizeof(ef_sched_stats));
+    sv->threads[k].sv = sv;
+    pthread_create(&sv->threads[k].thread, NULL, service_main, &sv->threads[k]);
+  }
   worker* ws = (worker*)calloc(s->nthreads, sizeof(worker));
   pthread_t* th = (pthread_t*)malloc(s->nthreads * sizeof(pthread_t));
   for (size_t t = 0; t < s->nthreads; ++t) { ws[t].sh = sh; pthread_create(&th[t], NULL, worker_main, &ws[t]); }
   for (size_t t = 0; t < s->nthreads; ++t) pthread_join(th[t], NULL);
-  pthread_mutex_lock(&sv->mu); sv->stop = true; pthread_cond_signal(&sv->posted); pthread_mutex_unlock(&sv->mu);
-  pthread_join(sv->thread, NULL);
+  pthread_mutex_lock(&sv->mu); sv->stop = true; pthread_cond_broadcast(&sv->posted); pthread_mutex_unlock(&sv->mu);
+  for (int k = 0; k < sv->n_threads; ++k) pthread_join(sv->threads[k].thread, NULL);
   ef_sched_stats st;
   memset(&st, 0, sizeof st);
   st.threads = s->nthreads;
-  st.dp_batches = sv->stats.dp_batches; st.dp_jobs = sv->stats.dp_jobs;
-  for (int k = 0; k < sv->stats.n_kernels; ++k) kstat_add(&st, &sv->stats.kernels[k]);
+  for (int t = 0; t < sv->n_threads; ++t) {
+    const ef_sched_stats* ss = &sv->threads[t].stats;
+    st.dp_batches += ss->dp_batches; st.dp_jobs += ss->dp_jobs;
+    for (int k = 0; k < ss->n_kernels; ++k) kstat_add(&st, &ss->kernels[k]);
+  }
   for (size_t t = 0; t < s->nthreads; ++t) {
     st.units += ws[t].stats.units;
     st.pairing_batches += ws[t].stats.pairing_batches; st.pairing_requests += ws[t].stats.pairing_requests;
@@ -697,7 +723,7 @@ void ef_session_close(ef_session* s) {
   while (sh->fiber_pool) { fiber* nx = sh->fiber_pool->pool_next; free(sh->fiber_pool->stack); free(sh->fiber_pool); sh->fiber_pool = nx; }
   free(sh->units); free(sh->pre_tri); free(sh->pre_first);
   if (s->pplan) pgpu_pairing_plan_destroy(s->ctx0, s->pplan);
-  pgpu_destroy(s->svc_ctx);
+  for (int k = 0; k < sh->svc.n_threads; ++k) pgpu_destroy(sh->svc.threads[k].ctx);
   pgpu_index_destroy(s->ctx0, sh->idx);
   pgpu_destroy(s->ctx0);
   ef_free_inputs(&s->in);
