@@ -29,8 +29,10 @@ char* ef_session_records(ef_session* s, size_t* len);
 size_t ef_session_n_ests(const ef_session* s);
 void ef_session_close(ef_session* s);
 
-/* environment: PINTRON_THREADS (default: online CPUs), PINTRON_FIBERS (fibres per thread, 2048),
- * PINTRON_FIBER_STACK_KB (256), PINTRON_GPU_DEVICE (0), PINTRON_VERBOSE */
+/* environment: PINTRON_THREADS (workers; default min(online CPUs, 16)), PINTRON_LANES (3),
+ * PINTRON_FIBERS (fibres per worker over all lanes, 1536), PINTRON_FIBER_STACK_KB (256),
+ * PINTRON_SERVICES (GPU service threads, 1), PINTRON_GPU_DEVICE (0), PINTRON_NO_PREFETCH,
+ * PINTRON_KERNEL_TIMING, PINTRON_VERBOSE */
 int ef_run_batched(int argc, char** argv);
 int ef_run_batched_stats(int argc, char** argv, ef_sched_stats* stats);
 
