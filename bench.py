@@ -19,7 +19,6 @@ two raw-multifasta-out.txt must be byte-identical.
 Contract: python bench.py --gpus N --steps K --warmup W ; one JSON line on rank 0.
 """
 import argparse
-import ctypes as C
 import hashlib
 import json
 import os
@@ -36,64 +35,7 @@ N_EST_BATCH = 100_000          # C3
 CPU_SAMPLE = 3000              # ESTs of the same workload given to the reference CPU est-fact
 
 
-class KernelStat(C.Structure):
-    _fields_ = [("name", C.c_char * 48), ("ms", C.c_double), ("launches", C.c_size_t),
-                ("jobs", C.c_size_t), ("cells", C.c_ulonglong), ("algo_bytes", C.c_ulonglong)]
-
-
-class SchedStats(C.Structure):
-    _fields_ = [(n, C.c_size_t) for n in ("threads", "units", "aligned", "dp_batches", "dp_jobs",
-                                          "pairing_batches", "pairing_requests")] + \
-               [(n, C.c_double) for n in ("load_s", "index_s", "prefetch_s", "workers_s", "host_s",
-                                          "pairing_s", "dp_s")] + \
-               [("n_kernels", C.c_int), ("kernels", KernelStat * 64)]
-
-
-def load_host_lib():
-    path = os.environ.get("PINTRON_ESTFACT_LIB") or os.path.join(ROOT, "pintron_amd", "lib", "libestfact.so")
-    if not os.path.exists(path):
-        raise SystemExit("%s missing: run __graft_entry__.build() (there is no CPU fallback)" % path)
-    L = C.CDLL(path)
-    L.ef_session_open.restype = C.c_void_p
-    L.ef_session_open.argtypes = [C.c_int, C.POINTER(C.c_char_p)]
-    L.ef_session_step.argtypes = [C.c_void_p, C.POINTER(SchedStats)]
-    L.ef_session_records.restype = C.c_void_p
-    L.ef_session_records.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
-    L.ef_session_n_ests.restype = C.c_size_t
-    L.ef_session_n_ests.argtypes = [C.c_void_p]
-    L.ef_session_write_outputs.argtypes = [C.c_void_p]
-    L.ef_session_close.argtypes = [C.c_void_p]
-    return L
-
-
-class Session:
-    def __init__(self, L, directory):
-        self.L, self.dir = L, directory
-        cwd = os.getcwd()
-        os.chdir(directory)
-        try:
-            argv = (C.c_char_p * 2)(b"est-fact", None)
-            self.h = L.ef_session_open(1, argv)
-        finally:
-            os.chdir(cwd)
-        if not self.h:
-            raise SystemExit("est-fact session could not start (no MI355X / libpintron_gpu.so?)")
-
-    def step(self):
-        st = SchedStats()
-        if self.L.ef_session_step(self.h, C.byref(st)) != 0:
-            raise SystemExit("est-fact step failed")
-        return st
-
-    def records(self) -> bytes:
-        n = C.c_size_t()
-        p = self.L.ef_session_records(self.h, C.byref(n))
-        data = C.string_at(p, n.value)
-        C.CDLL(None).free(C.c_void_p(p))
-        return data
-
-    def close(self):
-        self.L.ef_session_close(self.h)
+from pintron_amd.estfact import Session, gather_bytes, load_host_lib  # noqa: E402
 
 
 def cpu_reference(sample_dir):
@@ -136,22 +78,13 @@ def main():
     work = tempfile.mkdtemp(prefix="pintron_bench_r%d_" % rank)
     synth.write_files(wl, work)
     sess = Session(L, work)
-    n_est = int(L.ef_session_n_ests(sess.h))
+    n_est = sess.n_ests()
 
     def step():
         st = sess.step()
         if world > 1:
             # the only exchange of the sharded path: per-EST output records -> rank 0 (RCCL)
-            rec = sess.records()
-            t = torch.frombuffer(bytearray(rec), dtype=torch.uint8).cuda()
-            n = torch.tensor([t.numel()], dtype=torch.int64, device="cuda")
-            sizes = [torch.zeros_like(n) for _ in range(world)]
-            dist.all_gather(sizes, n)
-            mx = int(max(int(s.item()) for s in sizes))
-            pad = torch.zeros(mx, dtype=torch.uint8, device="cuda")
-            pad[: t.numel()] = t
-            outl = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
-            dist.gather(pad, outl, dst=0)
+            gather_bytes(sess.records(), dist, rank, world, "cuda")
         return st
 
     def fence():

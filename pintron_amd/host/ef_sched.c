@@ -701,18 +701,23 @@ int ef_session_write_outputs(ef_session* s) {
   return 0;
 }
 
-/* raw-multifasta-out records of the last step (concatenated, input order); caller frees */
-char* ef_session_records(ef_session* s, size_t* len) {
+/* text of output file `which` of the last step (0 raw-multifasta-out, 1 processed-ests, 2 megs,
+ * 3 processed-megs, 4 processed-megs-info, 5 meg-edges), concatenated in input order; caller frees */
+char* ef_session_output(ef_session* s, int which, size_t* len) {
   shared* sh = &s->sh;
+  if (which < 0 || which > 5) { *len = 0; return NULL; }
   size_t total = 0;
-  for (size_t u = 0; u < sh->n_units; ++u) total += sh->units[u].len[0];
+  for (size_t u = 0; u < sh->n_units; ++u) total += sh->units[u].len[which];
   char* r = (char*)malloc(total + 1);
   size_t pos = 0;
-  for (size_t u = 0; u < sh->n_units; ++u) { memcpy(r + pos, sh->units[u].buf[0], sh->units[u].len[0]); pos += sh->units[u].len[0]; }
+  for (size_t u = 0; u < sh->n_units; ++u) { memcpy(r + pos, sh->units[u].buf[which], sh->units[u].len[which]); pos += sh->units[u].len[which]; }
   r[pos] = '\0';
   *len = total;
   return r;
 }
+
+/* raw-multifasta-out records of the last step */
+char* ef_session_records(ef_session* s, size_t* len) { return ef_session_output(s, 0, len); }
 
 size_t ef_session_n_ests(const ef_session* s) { return s->sh.n_units; }
 

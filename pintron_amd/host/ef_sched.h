@@ -26,6 +26,7 @@ ef_session* ef_session_open(int argc, char** argv);
 int ef_session_step(ef_session* s, ef_sched_stats* stats);
 int ef_session_write_outputs(ef_session* s);
 char* ef_session_records(ef_session* s, size_t* len);
+char* ef_session_output(ef_session* s, int which, size_t* len);   /* 0..5, see ef_sched.c */
 size_t ef_session_n_ests(const ef_session* s);
 void ef_session_close(ef_session* s);
 

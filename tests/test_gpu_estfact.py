@@ -23,7 +23,9 @@ def exe():
     return EXE
 
 
-@pytest.mark.parametrize("env", [{}, {"PINTRON_ESTFACT_MODE": "direct"}, {"PINTRON_THREADS": "2", "PINTRON_FIBERS": "5"}])
+@pytest.mark.parametrize("env", [{}, {"PINTRON_ESTFACT_MODE": "direct"}, {"PINTRON_THREADS": "2", "PINTRON_FIBERS": "5"},
+                                 {"PINTRON_LANES": "1"}, {"PINTRON_LANES": "4", "PINTRON_SERVICES": "2", "PINTRON_FIBERS": "8"},
+                                 {"PINTRON_NO_PREFETCH": "1", "PINTRON_THREADS": "3"}])
 def test_ambn_golden(exe, tmp_path, env):
     for f in ("genomic.txt", "ests.txt"):
         shutil.copy(os.path.join(GOLD, f), tmp_path)
@@ -49,3 +51,44 @@ def test_c3_sample_vs_compiled_reference(exe, tmp_path):
     subprocess.run([exe], cwd=my_dir, check=True)
     for f in FILES:
         assert filecmp.cmp(my_dir / f, ref_dir / f, shallow=False), f
+
+
+@pytest.mark.parametrize("cfg,n_est", [("C2", 1000), ("C5", 3000)])
+def test_other_configs_vs_compiled_reference(exe, tmp_path, cfg, n_est):
+    """BASELINE.json's other shapes as parity cases: C2 (50 kb x 1 000 ESTs ~500 bp) in full, C5
+    (1 Mb genomic, 150 bp reads) on a 3 000-read sample."""
+    ref = os.path.join(ROOT, "oracle", "_ref", "est-fact-ref")
+    if not os.path.exists(ref):
+        pytest.skip("oracle/_ref/est-fact-ref not present")
+    from pintron_amd import synth
+    w = synth.make(cfg, n_est=n_est)
+    ref_dir, my_dir = tmp_path / "ref", tmp_path / "mine"
+    for d in (ref_dir, my_dir):
+        synth.write_files(w, str(d))
+    subprocess.run([ref], cwd=ref_dir, check=True, stderr=subprocess.DEVNULL)
+    subprocess.run([exe], cwd=my_dir, check=True)
+    for f in FILES:
+        assert filecmp.cmp(my_dir / f, ref_dir / f, shallow=False), f
+
+
+def test_session_steps_are_idempotent(exe, tmp_path):
+    """The bench's step: two passes over the resident batch give the same text, equal to the files
+    the binary writes."""
+    from pintron_amd import estfact, synth
+    w = synth.make("C3", n_est=600, seed=11)
+    synth.write_files(w, str(tmp_path))
+    L = estfact.load_host_lib()
+    s = estfact.Session(L, str(tmp_path))
+    s.step()
+    first = [s.output(k) for k in (0, 1, 2, 3, 5)]
+    st = s.step()
+    second = [s.output(k) for k in (0, 1, 2, 3, 5)]
+    s.close()
+    assert first == second and st.units == s_units(w)
+    subprocess.run([exe], cwd=tmp_path, check=True)
+    for text, f in zip(first, FILES):
+        assert text == open(tmp_path / f, "rb").read(), f
+
+
+def s_units(w):
+    return len(w.est_seqs)

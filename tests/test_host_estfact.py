@@ -35,6 +35,8 @@ def run(exe, cwd, env=None):
 @pytest.mark.parametrize("which,env", [("estfact_check", {}),
                                        ("estfact_sched_check", {"PINTRON_THREADS": "1"}),
                                        ("estfact_sched_check", {"PINTRON_THREADS": "4", "PINTRON_FIBERS": "7"}),
+                                       ("estfact_sched_check", {"PINTRON_LANES": "1", "PINTRON_THREADS": "2"}),
+                                       ("estfact_sched_check", {"PINTRON_LANES": "4", "PINTRON_SERVICES": "2", "PINTRON_FIBERS": "8"}),
                                        ("estfact_sched_check", {"PINTRON_ESTFACT_MODE": "direct"})])
 def test_ambn_outputs_match_reference(bins, tmp_path, which, env):
     for f in ("genomic.txt", "ests.txt"):
