@@ -353,6 +353,8 @@ extern "C" int pgpu_dp_plan_create(pgpu_ctx* ctx, const pgpu_index* idx, const p
     static const char* fam[] = {"lev_wave<ALIGN", "gap_wave<", "lev_wave<ED", "lev_wave<KBAND", "lcf",
                                 "lev_wave<BORDERS", "lev_wave<AFFIX"};
     if (g.family == KF_LCF) snprintf(nm, sizeof nm, "%s", fam[g.family]);
+    else if ((g.family == KF_BORDERS || g.family == KF_AFFIX) && g.R >= 2)   // one job per workgroup
+      snprintf(nm, sizeof nm, "%s<rows<=%d>", g.family == KF_BORDERS ? "borders_coop" : "affix_coop", 64 * g.R);
     else snprintf(nm, sizeof nm, "%s%sR=%d>", fam[g.family], g.family == KF_GAP ? "" : ",", g.R);
     g.name = nm;
     p->groups.push_back(g);

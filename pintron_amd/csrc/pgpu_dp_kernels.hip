@@ -346,6 +346,186 @@ void lev_wave_kernel(const DevJob* __restrict__ jobs, int njobs, DevResult* __re
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Cooperative sweeps: one job over the W waves of a workgroup
+// ---------------------------------------------------------------------------------------------
+// A single wave needs (columns + 63) * R sequential cell updates for a job with 64*R rows; a merged
+// batch holds only a few dozen jobs with hundreds of rows (small-exon searches, affix recovery),
+// so those launches are latency-bound and sit on the critical path of every batch.  Here the
+// strip of rows is spread over W*64 lanes: wave w owns lanes 64w .. 64w+63 of the same skewed
+// sweep.  Lane 0 of wave w+1 needs, at step s, what lane 63 of wave w produced at step s-1; the
+// waves are decoupled by one 64-step chunk: in interval k wave w works on chunk k-w and leaves the
+// packed (value | column char) of its last lane, per step, in an LDS array that wave w+1 reads
+// in the next interval (double-buffered; one __syncthreads per interval).  The column characters
+// travel with the wavefront, so only wave 0 reads them from memory.
+constexpr int COOP_W = 4;
+
+template <int R, bool ROWMIN, bool AFFIX>
+__device__ __forceinline__ void lev_sweep_coop(const Operand rows, const uint32_t nr,
+                                               const Operand cols, const uint32_t nc,
+                                               const uint32_t w, const uint32_t lane,
+                                               uint32_t* hand,        // [COOP_W-1][2][64] of this sweep
+                                               uint32_t (&cur)[R], uint32_t (&minv)[R],
+                                               uint32_t (&minpos)[R], AffixBest& best) {
+  uint32_t rc[R];
+  const uint32_t gl = w * 64u + lane;   // lane index within the job
+  const uint32_t row0 = gl * R;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const uint32_t i = row0 + r;
+    rc[r] = i < nr ? rows.at(i) : PAD_ROW;
+    cur[r] = i + 1;
+    if constexpr (ROWMIN) { minv[r] = i + 1; minpos[r] = 0; }
+  }
+  if (nr == 0 || nc == 0) return;       // uniform over the workgroup (one job)
+  const uint32_t last_lane = (nr - 1) / R;
+  const uint32_t steps = nc + last_lane;
+  const uint32_t nchunks = (steps + 63u) / 64u;
+  const bool wave_used = w * 64u <= last_lane;
+  uint32_t diag_in = row0, out = 0, chunk = 0, hin = 0, carry = 0;
+  uint32_t* hand_in = hand + (w > 0 ? (w - 1) * 128u : 0u);
+  uint32_t* hand_out = hand + w * 128u;
+
+  for (uint32_t k = 0; k < nchunks + COOP_W - 1; ++k) {
+    const int c = (int)k - (int)w;
+    // chunk w-1 holds no cell of this wave yet, but its hand-off carries the value for step 64w
+    if (wave_used && c >= (int)w - 1 && c >= 0 && c < (int)nchunks) {
+      if (w > 0) {
+        carry = (uint32_t)__builtin_amdgcn_readlane((int)hin, 63);
+        hin = hand_in[(c & 1) * 64 + lane];
+      }
+      const uint32_t s0 = (uint32_t)c * 64u;
+      const uint32_t tmax = min(64u, steps - s0);
+      for (uint32_t t = 0; t < tmax; ++t) {
+        const uint32_t s = s0 + t;
+        uint32_t in = wave_shr1(out);
+        if (w == 0) {
+          if (t == 0) { const uint32_t j = s + lane; chunk = j < nc ? cols.at(j) : PAD_COL; }
+          const uint32_t ch0 = (uint32_t)__builtin_amdgcn_readlane((int)chunk, (int)t);
+          if (lane == 0) in = (s + 1) | (ch0 << 24);
+        } else {
+          const uint32_t v = t == 0 ? carry : (uint32_t)__builtin_amdgcn_readlane((int)hin, (int)(t - 1));
+          if (lane == 0) in = v;
+        }
+        const uint32_t j = s - gl + 1;
+        if (j - 1u < nc) {
+          const uint32_t ch = in >> 24;
+          const uint32_t in_val = in & 0xFFFFFFu;
+          uint32_t up = in_val;
+          uint32_t diag = diag_in;
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const uint32_t left = cur[r];
+            uint32_t v = diag + (rc[r] == ch ? 0u : 1u);
+            v = min(v, min(up + 1, left + 1));
+            if constexpr (ROWMIN) {
+              if (minv[r] > v) { minv[r] = v; minpos[r] = j; }
+            }
+            if constexpr (AFFIX) {
+              const uint32_t e = row0 + r + 1, sum = e + j;
+              if (rc[r] == ch && 200u * v <= 17u * sum && best.worse_than(v, sum, e, j)) {
+                best.valid = 1; best.v = v; best.s = sum; best.e = e; best.g = j;
+              }
+            }
+            diag = left;
+            cur[r] = v;
+            up = v;
+          }
+          diag_in = in_val;
+          out = up | (ch << 24);
+        }
+        if (w + 1 < COOP_W && lane == 63) hand_out[(c & 1) * 64 + t] = out;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// general_refine_borders (src/refine.c:105-192) for patterns longer than 64: the prefix sweep on
+// waves 0-3 and the reversed-string sweep on waves 4-7 of one 512-thread workgroup.
+template <int R>
+__global__ __launch_bounds__(512)
+void borders_coop_kernel(const DevJob* __restrict__ jobs, int njobs, DevResult* __restrict__ results) {
+  extern __shared__ uint32_t lds[];      // hand-off [2][COOP_W-1][2][64], then pre, pre_pos, suf, suf_pos
+  const DevJob job = jobs[blockIdx.x];
+  DevResult* res = &results[job.out_idx];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t sweep = wave / COOP_W, w = wave % COOP_W;
+  const uint32_t len_p = job.la, len_t = job.lb, max_errs = job.p2;
+  const uint32_t t_win = min(len_p + max_errs, len_t);
+  uint32_t* hand = lds + sweep * ((COOP_W - 1) * 128);
+  uint32_t* pre = lds + 2 * (COOP_W - 1) * 128; uint32_t* pre_pos = pre + (len_p + 1);
+  uint32_t* suf = pre_pos + (len_p + 1); uint32_t* suf_pos = suf + (len_p + 1);
+  uint32_t cur[R], minv[R], minpos[R];
+  AffixBest best{0, 0, 0, 0, 0};
+  const Operand rows{job.a, len_p, sweep == 1}, cols{job.b, len_t, sweep == 1};
+  lev_sweep_coop<R, true, false>(rows, len_p, cols, t_win, w, lane, hand, cur, minv, minpos, best);
+  uint32_t* mv = sweep ? suf : pre; uint32_t* mp = sweep ? suf_pos : pre_pos;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const uint32_t i = (w * 64u + lane) * R + r + 1;
+    if (i <= len_p) { mv[i] = minv[r]; mp[i] = minpos[r]; }
+  }
+  if (threadIdx.x == 0) { pre[0] = 0; pre_pos[0] = 0; suf[0] = 0; suf_pos[0] = 0; }
+  __syncthreads();
+  if (wave != 0) return;
+  // cut scan of src/refine.c:161-178: the first i in [lo, hi] with the smallest total, ties by the
+  // larger Burset frequency; 64 lanes scan i = lo + lane, lo + lane + 64, ... and then agree
+  const uint32_t avail = len_t + min(job.tail, 2u);
+  const uint32_t lo = job.p0, hi = job.p1 > job.p0 ? job.p1 : job.p0;   // i = lo is always a candidate
+  uint32_t bi = 0xFFFFFFFFu, bc = 0xFFFFFFFFu; int bf = -1;
+  for (uint32_t i = lo + lane; i <= hi; i += 64) {
+    const int freq = burset_adaptor(job.b, avail, pre_pos[i], len_t - suf_pos[len_p - i]);
+    const uint32_t c = pre[i] + suf[len_p - i];
+    if (bc > c || (bc == c && freq > bf)) { bc = c; bf = freq; bi = i; }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const uint32_t oc = __shfl_xor(bc, off), oi = __shfl_xor(bi, off);
+    const int of = __shfl_xor(bf, off);
+    if (oc < bc || (oc == bc && (of > bf || (of == bf && oi < bi)))) { bc = oc; bf = of; bi = oi; }
+  }
+  if (lane == 0) {
+    const uint32_t off_t1 = pre_pos[bi], off_t2 = suf_pos[len_p - bi];
+    res->status = 0;
+    res->v[0] = bc <= max_errs ? 1 : 0;
+    res->v[1] = (int32_t)bi; res->v[2] = (int32_t)off_t1;
+    res->v[3] = (int32_t)(len_t - off_t2); res->v[4] = (int32_t)bc;
+  }
+}
+
+// find_longest_affix (src/factorization-refinement.c:1136-1173) for more than 64 rows
+template <int R>
+__global__ __launch_bounds__(256)
+void affix_coop_kernel(const DevJob* __restrict__ jobs, int njobs, DevResult* __restrict__ results) {
+  __shared__ uint32_t hand[(COOP_W - 1) * 128];
+  __shared__ uint32_t wbest[COOP_W][5];
+  const DevJob job = jobs[blockIdx.x];
+  DevResult* res = &results[job.out_idx];
+  const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+  uint32_t cur[R], minv[R], minpos[R];
+  AffixBest best{0, 0, 0, 0, 0};
+  const Operand rows{job.a, 0, false}, cols{job.b, 0, false};
+  lev_sweep_coop<R, false, true>(rows, job.la, cols, job.lb, w, lane, hand, cur, minv, minpos, best);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    AffixBest o;
+    o.valid = __shfl_xor(best.valid, off); o.v = __shfl_xor(best.v, off);
+    o.s = __shfl_xor(best.s, off); o.e = __shfl_xor(best.e, off); o.g = __shfl_xor(best.g, off);
+    if (o.valid && best.worse_than(o.v, o.s, o.e, o.g)) best = o;
+  }
+  if (lane == 0) { wbest[w][0] = best.valid; wbest[w][1] = best.v; wbest[w][2] = best.s; wbest[w][3] = best.e; wbest[w][4] = best.g; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < COOP_W; ++k) {
+      AffixBest o{wbest[k][0], wbest[k][1], wbest[k][2], wbest[k][3], wbest[k][4]};
+      if (o.valid && best.worse_than(o.v, o.s, o.e, o.g)) best = o;
+    }
+    res->status = 0; res->v[0] = (int32_t)best.valid;
+    res->v[1] = (int32_t)best.e; res->v[2] = (int32_t)best.g;
+  }
+}
+
 // TracebackAlignment (src/compute-alignments.c:149-207), one thread per job.  Strings are
 // written back-to-front into the job's slot so no reversal pass is needed.
 __global__ __launch_bounds__(64)
@@ -627,7 +807,16 @@ __global__ void lcf_finish_kernel(const DevJob* __restrict__ jobs, int njobs,
 
 template <int MODE, int R>
 void launch_lev_r(const DevJob* jobs, int njobs, DevResult* res, uint8_t* ws, hipStream_t st) {
-  if constexpr (MODE == MODE_BORDERS) {
+  // more than 64 rows: one job per workgroup, rows spread over COOP_W*64 lanes
+  if constexpr ((MODE == MODE_BORDERS || MODE == MODE_AFFIX) && R >= 2) {
+    constexpr int RB = R / COOP_W > 0 ? R / COOP_W : 1;
+    if constexpr (MODE == MODE_BORDERS) {
+      const size_t lds = (2 * (COOP_W - 1) * 128 + 4 * (64 * R + 1)) * sizeof(uint32_t);
+      hipLaunchKernelGGL((borders_coop_kernel<RB>), dim3(njobs), dim3(512), lds, st, jobs, njobs, res);
+    } else {
+      hipLaunchKernelGGL((affix_coop_kernel<RB>), dim3(njobs), dim3(256), 0, st, jobs, njobs, res);
+    }
+  } else if constexpr (MODE == MODE_BORDERS) {
     const size_t lds = 4 * (64 * R + 1) * sizeof(uint32_t);
     hipLaunchKernelGGL((lev_wave_kernel<R, MODE>), dim3(njobs), dim3(64), lds, st, jobs, njobs, res, ws);
   } else {

@@ -599,11 +599,11 @@ ef_session* ef_session_open(int argc, char** argv) {
   const size_t cores = ncpu > 16 ? 16 : (ncpu > 0 ? (size_t)ncpu : 1);
   s->nthreads = env_size("PINTRON_THREADS", cores);
   if (s->nthreads > sh->n_units) s->nthreads = sh->n_units ? sh->n_units : 1;
-  sh->max_fibers = env_size("PINTRON_FIBERS", 1536);
+  sh->max_fibers = env_size("PINTRON_FIBERS", 1024);
   sh->stack_size = env_size("PINTRON_FIBER_STACK_KB", 256) * 1024;
   sh->kernel_timing = getenv("PINTRON_KERNEL_TIMING") != NULL;
   sh->gen_len = strlen(in->gen->seq);
-  sh->n_lanes = (int)env_size("PINTRON_LANES", 3);
+  sh->n_lanes = (int)env_size("PINTRON_LANES", 2);
   if (sh->n_lanes > MAX_LANES) sh->n_lanes = MAX_LANES;
   s->load_s = t_loaded - t_start;
   s->index_s = now_s() - t_loaded;

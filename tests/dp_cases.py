@@ -124,7 +124,7 @@ def random_cases(rng, n_per_kind=20, max_len=600):
             s2[q:q + k] = s1[p:p + k]
         cases.append(Case(LCF, s1, bytes(s2)))
         # BORDERS: p = gap on the EST, t = genomic region with an intron in the middle
-        p = rand_seq(rng, rng.randint(1, min(110, max_len)))
+        p = rand_seq(rng, rng.randint(1, min(110, max_len) if rng.random() < 0.7 else max_len))
         cut = rng.randint(0, len(p))
         t = mutate(rng, p[:cut], 0.05) + b"GT" + rand_seq(rng, rng.randint(0, 150)) + b"AG" + \
             mutate(rng, p[cut:], 0.05)

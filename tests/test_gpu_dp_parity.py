@@ -64,6 +64,27 @@ def test_large_rows(gpu_ctx, O):
     assert out[1] == dict(status=0, score=1)
 
 
+def test_cooperative_kernels_at_class_boundaries(gpu_ctx, O):
+    """BORDERS / AFFIX with more than 64 rows run one job per workgroup (4 waves per sweep): row
+    counts around every lane/wave/row-class boundary, short and long column counts, sub-ranges."""
+    rng = random.Random(21)
+    cases = []
+    for n in (63, 64, 65, 127, 128, 129, 191, 192, 193, 255, 256, 257, 300, 511, 512, 513, 767, 1023, 1024,
+              1025, 1500, 2048, 2049, 4095, 4096):
+        a, b = D.pair(rng, n, rng.choice([0.0, 0.03, 0.1]), 0.001)
+        a = a[:n]
+        cases.append(D.Case(D.AFFIX, a, b))
+        cases.append(D.Case(D.AFFIX, a, b[: max(1, len(b) // 7)]))
+        cut = rng.randint(0, len(a))
+        t = D.mutate(rng, a[:cut], 0.04) + b"GT" + D.rand_seq(rng, rng.randint(0, 400)) + b"AG" + D.mutate(rng, a[cut:], 0.04)
+        for (lo, hi) in ((0, len(a)), (len(a) // 3, 2 * len(a) // 3), (len(a), len(a)), (5, 5)):
+            if lo <= hi <= len(a):
+                cases.append(D.Case(D.BORDERS, a, t, p0=lo, p1=hi, p2=rng.choice([0, 3, len(a) // 10 + 1, len(a)]),
+                                    b_tail=rng.choice([b"", b"A", b"GT"])))
+        cases.append(D.Case(D.BORDERS, a, t[: max(1, len(t) // 5)], p0=0, p1=len(a), p2=2))
+    run_and_check(gpu_ctx, O, cases)
+
+
 def test_lcf_genomic_scale(gpu_ctx, O):
     """LCF at the BASELINE configs' genomic lengths (200 kb and 1 Mb prefixes) with the operand
     taken from the resident genomic; checked against the oracle (seconds on CPU)."""
