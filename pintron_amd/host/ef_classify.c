@@ -148,22 +148,24 @@ static double score5(const char* gen, int splice5, int k) {           /* GetScor
 
 /* classify_genomic_intron_start_end (:95-229), class only.  The reference copies the intron
  * (real_substring); we read it in place: intron = gen[start .. start+il) */
-static int classify_uncached(const char* gen, int start, int end);
+static int classify_uncached(const ef_seq* gs, int start, int end);
 
 /* The class depends only on (genomic, start, end) and the ESTs of a gene keep proposing the same
  * few introns, so each thread remembers recent answers (direct-mapped; the genomic sequence is
  * immutable for the whole run). */
-int ef_classify_intron(const char* gen, int start, int end) {
+int ef_classify_intron(const ef_seq* gs, int start, int end) {
+  const char* gen = gs->seq;
   typedef struct { const char* gen; int start, end, type; } slot;
   static _Thread_local slot memo[1024];
   slot* m = &memo[((uint32_t)start * 2654435761u ^ (uint32_t)end * 40503u) >> 7 & 1023u];
   if (m->gen == gen && m->start == start && m->end == end) return m->type;
-  const int type = classify_uncached(gen, start, end);
+  const int type = classify_uncached(gs, start, end);
   m->gen = gen; m->start = start; m->end = end; m->type = type;
   return type;
 }
 
-static int classify_uncached(const char* gen, int start, int end) {
+static int classify_uncached(const ef_seq* gs, int start, int end) {
+  const char* gen = gs->seq;
   load_all();
   int idx = start, want = end - start + 1;
   if (idx < 0) { want += idx; idx = 0; }
@@ -171,7 +173,16 @@ static int classify_uncached(const char* gen, int start, int end) {
   const char* intron = gen + idx;
   const char* nul = (const char*)memchr(intron, 0, (size_t)want);
   const size_t il = nul ? (size_t)(nul - intron) : (size_t)want;
-  const int bps = good_bps(intron, il, 14, 30);
+  /* The branch-point scan looks at the windows 30..14 bases before the END of the intron only (and
+   * gives up on introns shorter than 30), so its verdict is a property of the end position; the
+   * small-exon search proposes thousands of introns sharing a few ends. */
+  int bps;
+  if (il < 30 || !gs->bps_memo) bps = good_bps(intron, il, 14, 30);
+  else {
+    unsigned char* m = &gs->bps_memo[(size_t)idx + il];
+    if (*m == 0) *m = good_bps(intron, il, 14, 30) != -1 ? 2 : 1;    /* same value whoever writes it */
+    bps = *m == 2 ? 0 : -1;                                             /* only "found or not" is used below */
+  }
   char p5[3] = { 0, 0, 0 }, p3[3] = { 0, 0, 0 };
   for (size_t c = 0; c < 2 && c < il; ++c) p5[c] = intron[c];
   if (il >= 2) { p3[0] = intron[il - 2]; p3[1] = intron[il - 1]; }

@@ -82,6 +82,7 @@ int ef_load_inputs(int argc, char** argv, ef_inputs* in) {
   free(gens);
   ef_parse_genomic_header(in->gen);
   if (ef_ntails_removal(in->gen) != 0) { fprintf(stderr, "* FATAL The sequence is only composed by Ns.\n"); return 1; }
+  ef_seq_index_kmers(in->gen);
   const long n_in = ef_read_multifasta("ests.txt", &ests);
   if (n_in < 0) { fprintf(stderr, "* FATAL File ests.txt not found! Terminating\n"); return 1; }
   /* preparation loop (src/main-est-fact.c:190-213) */

@@ -741,11 +741,11 @@ ef_est* ef_get_est_factorizations(const ef_seq* est_info, ef_meg* V, const ef_co
   const char* EST = est_info->seq;
   const unsigned est_len = (unsigned)V->n - 2;
   ef_list* flist = efl_new();
-  for (size_t i = 0; i < V->n; ++i) {
+  EF_MEG_FOR_POS(V, i, 0, V->n) {
     ef_iter it = efl_begin(V->v[i]);
     while (efi_has_next(&it)) { ef_pairing* p = (ef_pairing*)efi_next(&it); p->visited = false; p->emb_memo = NULL; }
   }
-  for (size_t i = 0; i < V->n; ++i) {
+  EF_MEG_FOR_POS(V, i, 0, V->n) {
     ef_iter it = efl_begin(V->v[i]);
     while (efi_has_next(&it)) {
       ef_pairing* root = (ef_pairing*)efi_next(&it);
@@ -774,7 +774,7 @@ ef_est* ef_get_est_factorizations(const ef_seq* est_info, ef_meg* V, const ef_co
     }
   }
   /* release the memoised embeddings */
-  for (size_t i = 0; i < V->n; ++i) {
+  EF_MEG_FOR_POS(V, i, 0, V->n) {
     ef_iter it = efl_begin(V->v[i]);
     while (efi_has_next(&it)) { ef_pairing* p = (ef_pairing*)efi_next(&it); if (p->emb_memo) { efl_free(p->emb_memo, embedding_free); p->emb_memo = NULL; } }
   }

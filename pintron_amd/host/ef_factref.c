@@ -195,29 +195,18 @@ static void remove_false_small_exons(const ef_seq* gen, ef_est* e, ef_backend* b
   }
 }
 
-/* positions of every ACGT 6-mer of a text, grouped by 6-mer code (12 bits), ascending */
-typedef struct { uint32_t first[4097]; uint32_t* pos; } kmer_index;
-
 static int base2(char c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : -1; }
 static int kmer_code(const char* s) {
   int code = 0;
   for (int k = 0; k < LB_SMALL_EXON; ++k) { const int b = base2(s[k]); if (b < 0) return -1; code = (code << 2) | b; }
   return code;
 }
-static void kmer_index_build(kmer_index* kx, const char* t, size_t n) {
-  memset(kx->first, 0, sizeof kx->first);
-  kx->pos = (uint32_t*)malloc((n + 1) * sizeof(uint32_t));
-  if (n < LB_SMALL_EXON) return;
-  int* codes = (int*)malloc(n * sizeof(int));
-  const size_t nk = n - LB_SMALL_EXON + 1;
-  for (size_t i = 0; i < nk; ++i) { codes[i] = kmer_code(t + i); if (codes[i] >= 0) ++kx->first[codes[i] + 1]; }
-  for (int c = 0; c < 4096; ++c) kx->first[c + 1] += kx->first[c];
-  uint32_t* fill = (uint32_t*)malloc(4096 * sizeof(uint32_t));
-  memcpy(fill, kx->first, 4096 * sizeof(uint32_t));
-  for (size_t i = 0; i < nk; ++i) if (codes[i] >= 0) kx->pos[fill[codes[i]]++] = (uint32_t)i;
-  free(fill); free(codes);
+/* first index in the ascending array a[0..n) whose value is >= v */
+static size_t lower_bound_u32(const uint32_t* a, size_t n, uint32_t v) {
+  size_t lo = 0, hi = n;
+  while (lo < hi) { const size_t mid = (lo + hi) / 2; if (a[mid] < v) lo = mid + 1; else hi = mid; }
+  return lo;
 }
-static void kmer_index_free(kmer_index* kx) { free(kx->pos); }
 
 static bool canonical_intron(const char* G, size_t s, size_t e) {           /* :481-494 */
   return (G[s] == 'G' && G[s + 1] == 'T' && G[e - 1] == 'A' && G[e] == 'G') ||
@@ -280,7 +269,7 @@ static void small_exon_between(ef_factor* p1, ef_factor* p2, ef_iter* it, const 
   const size_t sed = ef_compute_edit_distance(be, e1s, e1slen, g1s, g1slen);
   const size_t ped = ef_compute_edit_distance(be, e2p, e2plen, g2p, g2plen);
   bool go = false;
-  const int orig_class = ef_classify_intron(G, p1->GEN_end + 1, p2->GEN_start - 1);
+  const int orig_class = ef_classify_intron(gen, p1->GEN_end + 1, p2->GEN_start - 1);
   if (sed + ped > MAX_ERRORS_AS_SMALL) go = true;
   if (orig_class == INTRON_ND) go = true;
   if (go) {
@@ -309,14 +298,20 @@ static void small_exon_between(ef_factor* p1, ef_factor* p2, ef_iter* it, const 
       size_t max_len = 0, ecut1 = 0, ecut2 = 0, gcut1_1 = 0, gcut1_2 = 0, gcut2_1 = 0, gcut2_2 = 0;
       const size_t max_offstart = zmin(zmin(f1slen + 1 - MIN_PERFECT_BORDER, elen + 1 - LB_SMALL_EXON), allglen + 1 - (2 * MIL) - LB_SMALL_EXON);
       /* The reference runs strstr() over the whole intron for every (offstart, offend) pair
-       * (:781-834).  Same occurrences, same order, found through a 6-mer index of the genomic
-       * window built once (every pattern is at least LB_SMALL_EXON = 6 long); patterns whose first
-       * six characters are not all ACGT fall back to strstr(). */
-      kmer_index kx;
-      kmer_index_build(&kx, allg, allglen);
+       * (:781-834).  Same occurrences, same order, found through the 6-mer index of the genomic
+       * sequence (gen->kmer_*, built once per gene; every pattern is at least LB_SMALL_EXON = 6
+       * long): the candidates of a window are a contiguous run of the 6-mer's ascending position
+       * list.  Patterns whose first six characters are not all ACGT fall back to strstr(). */
       for (size_t os = 0; os < max_offstart; ++os) {
         const size_t max_offend = zmin(zmin(f2plen + 1 - MIN_PERFECT_BORDER, elen + 1 - os - LB_SMALL_EXON), allglen + 1 - (2 * MIL) - LB_SMALL_EXON - os);
         const int code = kmer_code(efact + os);
+        const uint32_t* cand = NULL; size_t nc = 0;
+        if (code >= 0) {                                       /* occurrences inside the window */
+          const uint32_t* all = gen->kmer_pos + gen->kmer_first[code];
+          const size_t nall = gen->kmer_first[code + 1] - gen->kmer_first[code];
+          const size_t from = lower_bound_u32(all, nall, (uint32_t)allgstart);
+          cand = all + from; nc = nall - from;
+        }
         for (size_t oe = 0; oe < max_offend; ++oe) {
           const size_t plen = elen - os - oe;                 /* pattern efact[os .. elen-oe) */
           const size_t text_lo = os + MIL, text_hi = allglen - oe - MIL;   /* text allg[text_lo .. text_hi) */
@@ -337,10 +332,10 @@ static void small_exon_between(ef_factor* p1, ef_factor* p2, ef_iter* it, const 
               ++occ;
             } else {
               bool found = false;
-              const uint32_t* cand = kx.pos + kx.first[code];
-              const size_t nc = kx.first[code + 1] - kx.first[code];
               while (cursor < nc) {
-                q = cand[cursor++];
+                const size_t qa = cand[cursor++];               /* absolute position, ascending */
+                if (qa >= allgstart + allglen) { cursor = nc; break; }
+                q = qa - allgstart;
                 if (q < text_lo || plen > text_hi || q > text_hi - plen) continue;
                 if (memcmp(allg + q + LB_SMALL_EXON, efact + os + LB_SMALL_EXON, plen - LB_SMALL_EXON) == 0) { found = true; break; }
               }
@@ -348,7 +343,7 @@ static void small_exon_between(ef_factor* p1, ef_factor* p2, ef_iter* it, const 
             }
             const size_t i1s = allgstart + os, i1e = allgstart + q - 1;
             const size_t i2s = i1e + 1 + elen - os - oe, i2e = allgstart + allglen - oe - 1;
-            const int t1 = ef_classify_intron(G, (int)i1s, (int)i1e), t2 = ef_classify_intron(G, (int)i2s, (int)i2e);
+            const int t1 = ef_classify_intron(gen, (int)i1s, (int)i1e), t2 = ef_classify_intron(gen, (int)i2s, (int)i2e);
             if (t1 != INTRON_ND && t2 != INTRON_ND) {
               const size_t sl = elen - os - oe;
               if (sl > max_len) { max_len = sl; ecut1 = estart + os; ecut2 = estart + os + sl; gcut1_1 = i1s; gcut1_2 = i1e + 1; gcut2_1 = i2s; gcut2_2 = i2e + 1; }
@@ -357,7 +352,6 @@ static void small_exon_between(ef_factor* p1, ef_factor* p2, ef_iter* it, const 
           if (code < 0) { efact[elen - oe] = sv_e; allg[text_hi] = sv_g; }
         }
       }
-      kmer_index_free(&kx);
       if (max_len >= LB_SMALL_EXON) {
         ef_factor* nw = factor_new((int)ecut1, (int)ecut2 - 1, (int)gcut1_2, (int)gcut2_1 - 1);
         p2->EST_start = (int)ecut2; p2->GEN_start = (int)gcut2_2;

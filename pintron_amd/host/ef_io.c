@@ -37,7 +37,33 @@ static char* dup_range(const char* s, size_t n) {
 void ef_seq_free(ef_seq* s) {
   if (!s) return;
   free(s->id); free(s->seq); free(s->original_seq); free(s->gb); free(s->chr);
+  free(s->kmer_first); free(s->kmer_pos); free(s->bps_memo);
   free(s);
+}
+
+/* 6-mer index of the (final) genomic working sequence: one counting sort over the sequence */
+#define EF_KMER 6
+static int kmer_base(char c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : -1; }
+void ef_seq_index_kmers(ef_seq* gen) {
+  const size_t n = strlen(gen->seq);
+  free(gen->kmer_first); free(gen->kmer_pos); free(gen->bps_memo);
+  gen->bps_memo = (unsigned char*)calloc(n + 2, 1);
+  gen->kmer_first = (uint32_t*)calloc(4097, sizeof(uint32_t));
+  gen->kmer_pos = (uint32_t*)malloc((n + 1) * sizeof(uint32_t));
+  if (n < EF_KMER) return;
+  const size_t nk = n - EF_KMER + 1;
+  int* codes = (int*)malloc(nk * sizeof(int));
+  for (size_t i = 0; i < nk; ++i) {
+    int code = 0;
+    for (int k = 0; k < EF_KMER && code >= 0; ++k) { const int b = kmer_base(gen->seq[i + k]); code = b < 0 ? -1 : ((code << 2) | b); }
+    codes[i] = code;
+    if (code >= 0) ++gen->kmer_first[code + 1];
+  }
+  for (int c = 0; c < 4096; ++c) gen->kmer_first[c + 1] += gen->kmer_first[c];
+  uint32_t* fill = (uint32_t*)malloc(4096 * sizeof(uint32_t));
+  memcpy(fill, gen->kmer_first, 4096 * sizeof(uint32_t));
+  for (size_t i = 0; i < nk; ++i) if (codes[i] >= 0) gen->kmer_pos[fill[codes[i]]++] = (uint32_t)i;
+  free(fill); free(codes);
 }
 
 static ef_seq* seq_new(void) {

@@ -31,13 +31,16 @@ ef_meg* ef_meg_from_pairings(const ef_triple* tr, size_t n_tr, size_t m) {
   for (size_t k = 0; k < n_tr; ++k)
     efl_push_back(V->v[1 + tr[k].p], pairing_new(tr[k].p, tr[k].t, tr[k].l));
   efl_push_back(V->v[V->n - 1], pairing_new(EF_SINK_START, EF_SINK_START, EF_SOURCE_LEN));
+  V->act = (size_t*)malloc((n_tr + 2) * sizeof(size_t));
+  V->n_act = 0;
+  for (size_t i = 0; i < V->n; ++i) if (!efl_empty(V->v[i])) V->act[V->n_act++] = i;
   return V;
 }
 
 void ef_meg_free(ef_meg* V) {
   if (!V) return;
-  for (size_t i = 0; i < V->n; ++i) efl_clear(V->v[i], pairing_free);
-  free(V->v);
+  EF_MEG_FOR_POS(V, i, 0, V->n) efl_clear(V->v[i], pairing_free);
+  free(V->v); free(V->act);
   free(V);
 }
 
@@ -70,7 +73,8 @@ static void add_edges_from(ef_pairing* I, ef_meg* V, int l, int fl, const ef_con
   const int n = (int)V->n;
   int ubound = I->p + I->l + fl + 1;
   if (n - l < ubound) ubound = n - l;
-  for (int j = 0; j < ubound; ++j) {
+  if (ubound <= 0) return;
+  EF_MEG_FOR_POS(V, j, 0, ubound) {
     ef_iter it = efl_begin(V->v[j]);
     while (efi_has_next(&it)) {
       ef_pairing* J = (ef_pairing*)efi_next(&it);
@@ -87,7 +91,7 @@ static bool apart(const ef_pairing* a, const ef_pairing* b) {     /* disjoint on
 void ef_build_edge_set(ef_meg* V, const ef_config* cfg) {
   const int L = (int)cfg->min_factor_len;
   const int fl = 2 * L + 1;                                       /* compute_fl */
-  for (size_t i = 1; i + 1 < V->n; ++i) {
+  EF_MEG_FOR_POS(V, i, 1, V->n - 1) {
     ef_iter it = efl_begin(V->v[i]);
     while (efi_has_next(&it)) add_edges_from((ef_pairing*)efi_next(&it), V, L, fl, cfg);
   }
@@ -96,7 +100,7 @@ void ef_build_edge_set(ef_meg* V, const ef_config* cfg) {
   {
     const int max_p = (int)(((double)p_len) * cfg->max_prefix_discarded_rate);
     ef_pairing* source = (ef_pairing*)efl_head(V->v[0]);
-    for (int i = 1; i <= max_p; ++i) {
+    EF_MEG_FOR_POS(V, i, 1, max_p >= 1 ? max_p + 1 : 1) {
       ef_iter it = efl_begin(V->v[i]);
       while (efi_has_next(&it)) {
         ef_pairing* I = (ef_pairing*)efi_next(&it);
@@ -115,7 +119,7 @@ void ef_build_edge_set(ef_meg* V, const ef_config* cfg) {
   {
     const int min_p = (int)(((double)p_len) * (1.0 - cfg->max_suffix_discarded_rate));
     ef_pairing* sink = (ef_pairing*)efl_head(V->v[p_len + 1]);
-    for (int i = 1; i <= p_len; ++i) {
+    EF_MEG_FOR_POS(V, i, 1, p_len >= 1 ? p_len + 1 : 1) {
       ef_iter it = efl_begin(V->v[i]);
       while (efi_has_next(&it)) {
         ef_pairing* I = (ef_pairing*)efi_next(&it);
@@ -135,7 +139,7 @@ void ef_build_edge_set(ef_meg* V, const ef_config* cfg) {
 
 void ef_meg_stats(ef_meg* V, size_t* pairings, size_t* edges) {
   *pairings = 0; *edges = 0;
-  for (size_t i = 0; i < V->n; ++i) {
+  EF_MEG_FOR_POS(V, i, 0, V->n) {
     ef_iter it = efl_begin(V->v[i]);
     while (efi_has_next(&it)) { const ef_pairing* p = (const ef_pairing*)efi_next(&it); ++*pairings; *edges += efl_size(p->adjs); }
   }
@@ -151,7 +155,7 @@ bool ef_is_too_complex(ef_meg* V, const ef_config* cfg) {       /* src/meg-simpl
   int min_len = 0;
   size_t freq_min_len = 0, tp = 0, te = 0;
   const size_t est_len = V->n - 2;
-  for (size_t i = 0; i < V->n; ++i) {
+  EF_MEG_FOR_POS(V, i, 0, V->n) {
     ef_iter it = efl_begin(V->v[i]);
     while (efi_has_next(&it)) {
       const ef_pairing* p = (const ef_pairing*)efi_next(&it);
@@ -176,7 +180,7 @@ static void remove_dangling(ef_meg* V) {
   bool removed;
   do {
     removed = false;
-    for (size_t i = 1; i + 1 < V->n; ++i) {
+    EF_MEG_FOR_POS(V, i, 1, V->n - 1) {
       ef_iter it = efl_begin(V->v[i]);
       while (efi_has_next(&it)) {
         ef_pairing* I = (ef_pairing*)efi_next(&it);
@@ -196,7 +200,7 @@ static void remove_dangling(ef_meg* V) {
 /* simplify_meg = remove_useless_edges (:193-232) + remove_other_sources_and_sinks */
 void ef_simplify_meg(ef_meg* V, const ef_config* cfg) {
   const int g = 2 * (int)cfg->min_factor_len + 3;                /* compute_gl */
-  for (size_t i = 1; i < V->n; ++i) {
+  EF_MEG_FOR_POS(V, i, 1, V->n) {
     ef_iter it = efl_begin(V->v[i]);
     while (efi_has_next(&it)) {
       ef_pairing* p = (ef_pairing*)efi_next(&it);
@@ -219,7 +223,7 @@ void ef_compact_short_edges(ef_meg* V, const ef_config* cfg) {
   bool removed;
   do {
     removed = false;
-    for (size_t i = 1; i < V->n; ++i) {
+    EF_MEG_FOR_POS(V, i, 1, V->n) {
       ef_iter it = efl_begin(V->v[i]);
       while (efi_has_next(&it)) {
         ef_pairing* p = (ef_pairing*)efi_next(&it);
@@ -257,7 +261,7 @@ void ef_transitive_reduction(ef_meg* V) {
   ef_meg_stats(V, &nv, &dummy);
   ef_pairing** G = (ef_pairing**)malloc((nv + 1) * sizeof(ef_pairing*));
   size_t k = 0;
-  for (size_t i = 0; i < V->n; ++i) {
+  EF_MEG_FOR_POS(V, i, 0, V->n) {
     ef_iter it = efl_begin(V->v[i]);
     while (efi_has_next(&it)) { G[k] = (ef_pairing*)efi_next(&it); G[k]->id = (int)k; ++k; }
   }
@@ -345,7 +349,7 @@ void ef_transitive_reduction(ef_meg* V) {
 
 void ef_meg_write(FILE* f, ef_meg* V) {
   int index = 0;
-  for (size_t i = 0; i < V->n; ++i) {
+  EF_MEG_FOR_POS(V, i, 0, V->n) {
     ef_iter it = efl_begin(V->v[i]);
     while (efi_has_next(&it)) {
       ef_pairing* p = (ef_pairing*)efi_next(&it);
@@ -354,7 +358,7 @@ void ef_meg_write(FILE* f, ef_meg* V) {
     }
   }
   fprintf(f, "#adj#\n");
-  for (size_t i = 0; i < V->n; ++i) {
+  EF_MEG_FOR_POS(V, i, 0, V->n) {
     ef_iter it = efl_begin(V->v[i]);
     while (efi_has_next(&it)) {
       const ef_pairing* p = (const ef_pairing*)efi_next(&it);
@@ -365,7 +369,7 @@ void ef_meg_write(FILE* f, ef_meg* V) {
 }
 
 void ef_intronic_edges_write(FILE* f, ef_meg* V) {
-  for (size_t i = 0; i < V->n; ++i) {
+  EF_MEG_FOR_POS(V, i, 0, V->n) {
     ef_iter it = efl_begin(V->v[i]);
     while (efi_has_next(&it)) {
       const ef_pairing* p = (const ef_pairing*)efi_next(&it);

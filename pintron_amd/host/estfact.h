@@ -59,6 +59,13 @@ typedef struct {
   int abs_start, abs_end; /* genomic only */
   int pref_polyA_length, suff_polyA_length, pref_polyT_length, suff_polyT_length;
   int pref_N_length, suff_N_length;
+  /* genomic only: positions of every upper-case ACGT 6-mer of seq, grouped by 6-mer code
+   * (12 bits), ascending inside a group; built once by ef_seq_index_kmers */
+  uint32_t* kmer_first;   /* 4097 offsets into kmer_pos */
+  uint32_t* kmer_pos;
+  /* genomic only: branch-point verdict of classify-intron per intron END position, filled on
+   * demand (0 = not computed yet, 1 = no branch point, 2 = branch point found) */
+  unsigned char* bps_memo;
 } ef_seq;
 
 /* read_multifasta (src/io-multifasta.c:133-164); returns number of records, -1 on I/O error */
@@ -73,6 +80,7 @@ static inline size_t ef_genomic_len(const char* gen) {
 
 long ef_read_multifasta(const char* path, ef_seq*** out);
 void ef_seq_free(ef_seq* s);
+void ef_seq_index_kmers(ef_seq* gen);                      /* used by the small-exon search */
 void ef_parse_genomic_header(ef_seq* gen);                 /* :410-423 */
 int  ef_ntails_removal(ef_seq* gen);                       /* :830-868; -1 when only N */
 void ef_set_gb_identification(ef_seq* est);                /* :279-304 */
@@ -98,7 +106,21 @@ typedef struct ef_pairing {
 typedef struct {
   size_t n;          /* |P| + 2: [0] = source, [1+i] = position i, [n-1] = sink */
   ef_list** v;
+  /* the positions that ever held a vertex, ascending (a few dozen of the ~600): vertices are only
+   * ever added at such a position, so visiting these in order = visiting all positions in order */
+  size_t* act; size_t n_act;
 } ef_meg;
+
+/* first index k with act[k] >= lo */
+static inline size_t ef_meg_act_from(const ef_meg* V, size_t lo) {
+  size_t a = 0, b = V->n_act;
+  while (a < b) { const size_t m = (a + b) / 2; if (V->act[m] < lo) a = m + 1; else b = m; }
+  return a;
+}
+/* for (i = lo; i < hi; ++i) restricted to the positions that can hold vertices */
+#define EF_MEG_FOR_POS(V, i, lo, hi) \
+  for (size_t ef_k_ = ef_meg_act_from((V), (size_t)(lo)), i; \
+       ef_k_ < (V)->n_act && (i = (V)->act[ef_k_]) < (size_t)(hi); ++ef_k_)
 
 typedef struct { int32_t p, t, l; } ef_triple;
 
@@ -166,7 +188,7 @@ void ef_remove_duplicated_factorizations(ef_list* facts);
 bool ef_refine_intron(const ef_config* cfg, const ef_seq* gen, const ef_seq* est, ef_factor* donor,
                       ef_factor* acceptor, bool first_intron, ef_backend* be);
 /* intron classification (src/classify-intron.c:95): 0 = U12, 1 = U2, 2 = not classified */
-int ef_classify_intron(const char* gen_seq, int start, int end);
+int ef_classify_intron(const ef_seq* gen, int start, int end);
 /* Burset frequencies (src/refine-intron.c:346-556) */
 int ef_burset_frequency(const char* donor, const char* acceptor);
 int ef_burset_adaptor(const char* t, size_t cut1, size_t cut2);
