@@ -138,6 +138,7 @@ typedef struct service {
   service_thread threads[MAX_SERVICES];
 } service;
 
+#define PRE_CHUNKS 8
 typedef struct shared {
   ef_inputs* in;
   pgpu_index* idx;
@@ -147,7 +148,13 @@ typedef struct shared {
   size_t max_fibers, stack_size;
   /* pairings of every list entry at the configured (min_factor_len, rate), computed in ONE
    * resident batch before the fibres start; retries with a longer factor go through batches */
-  pgpu_pairing* pre_tri; uint64_t* pre_first;
+  /* ... in PRE_CHUNKS ranges of entries, computed by a prefetch thread while the workers already
+   * run on the finished ranges: chunk c covers entries [pre_lo[c], pre_lo[c+1]) */
+  int n_pre;                                  /* 0 = no prefetch */
+  size_t pre_lo[PRE_CHUNKS + 1];
+  pgpu_pairing* pre_tri[PRE_CHUNKS]; uint64_t* pre_first[PRE_CHUNKS];
+  size_t ready_entries;                       /* entries below this have their pairings (under mu) */
+  pthread_cond_t ready_cv;
   bool kernel_timing;
   size_t gen_len;
   int n_lanes;
@@ -206,11 +213,14 @@ static int fiber_dp(void* self, const ef_dp_req* q, ef_dp_res* res) {
 static int fiber_pairings(void* self, const char* pattern, size_t m, unsigned L, double rate, ef_triple** out, size_t* n) {
   fiber* f = (fiber*)self;
   const shared* sh = f->w->sh;
-  if (sh->pre_first && L == sh->in->cfg.min_factor_len && rate == sh->in->cfg.min_string_depth_rate &&
+  if (sh->n_pre && L == sh->in->cfg.min_factor_len && rate == sh->in->cfg.min_string_depth_rate &&
       pattern == sh->in->list[f->cur_entry]->seq) {
-    const uint64_t a = sh->pre_first[f->cur_entry], b = sh->pre_first[f->cur_entry + 1];
+    int c = 0;
+    while (f->cur_entry >= sh->pre_lo[c + 1]) ++c;
+    const size_t e = f->cur_entry - sh->pre_lo[c];
+    const uint64_t a = sh->pre_first[c][e], b = sh->pre_first[c][e + 1];
     ef_triple* t = (ef_triple*)malloc((size_t)(b - a + 1) * sizeof(ef_triple));
-    memcpy(t, sh->pre_tri + a, (size_t)(b - a) * sizeof(ef_triple));
+    memcpy(t, sh->pre_tri[c] + a, (size_t)(b - a) * sizeof(ef_triple));
     *out = t; *n = (size_t)(b - a);
     return 0;
   }
@@ -280,6 +290,11 @@ static bool start_fiber(worker* w, int li) {
   fiber* f = w->free_fibers;
   pthread_mutex_lock(&sh->mu);
   const size_t u = sh->next_unit < sh->n_units ? sh->next_unit++ : (size_t)-1;
+  if (u != (size_t)-1 && sh->n_pre) {          /* the pairings of this unit may still be on their way */
+    const size_t last = sh->units[u].first + (sh->units[u].has_sibling ? 1 : 0);
+    while (last >= sh->ready_entries && !sh->failed) pthread_cond_wait(&sh->ready_cv, &sh->mu);
+  }
+  if (sh->failed) { pthread_mutex_unlock(&sh->mu); return false; }
   if (u != (size_t)-1 && !f && sh->fiber_pool) { f = sh->fiber_pool; sh->fiber_pool = f->pool_next; f->pool_next = NULL; }
   else if (u != (size_t)-1 && f) w->free_fibers = f->pool_next;
   pthread_mutex_unlock(&sh->mu);
@@ -540,7 +555,9 @@ struct ef_session {
   ef_inputs in;
   pgpu_ctx* ctx0;
   shared sh;
-  pgpu_pairing_plan* pplan;     /* all prepared sequences (both strands), resident in HBM */
+  pgpu_pairing_plan* pplan[PRE_CHUNKS];   /* all prepared sequences (both strands), resident in HBM */
+  pthread_t pre_thread;
+  double pre_kernel_ms[6], pre_t0, pre_wall;
   size_t nthreads;
   double load_s, index_s;
 };
@@ -563,18 +580,6 @@ ef_session* ef_session_open(int argc, char** argv) {
     fprintf(stderr, "* FATAL pgpu_index_build: %s\n", pgpu_last_error(s->ctx0));
     free(s); return NULL;
   }
-  if (!getenv("PINTRON_NO_PREFETCH") && in->n > 0) {
-    size_t total = 0;
-    for (size_t k = 0; k < in->n; ++k) total += strlen(in->list[k]->seq);
-    char* blob = (char*)malloc(total + 1);
-    uint64_t* off = (uint64_t*)malloc((in->n + 1) * sizeof(uint64_t));
-    size_t pos = 0;
-    for (size_t k = 0; k < in->n; ++k) { const size_t m = strlen(in->list[k]->seq); off[k] = pos; memcpy(blob + pos, in->list[k]->seq, m); pos += m; }
-    off[in->n] = pos;
-    const int prc = pgpu_pairing_plan_create(s->ctx0, sh->idx, blob, off, in->n, &s->pplan);
-    free(blob); free(off);
-    if (prc != PGPU_OK) { fprintf(stderr, "* FATAL pairing plan: %s\n", pgpu_last_error(s->ctx0)); free(s); return NULL; }
-  }
   sh->units = (unit*)calloc(in->n + 1, sizeof(unit));
   for (size_t k = 0; k < in->n;) {
     unit* u = &sh->units[sh->n_units++];
@@ -582,11 +587,33 @@ ef_session* ef_session_open(int argc, char** argv) {
     u->has_sibling = !in->list[k]->fixed_strand;
     k += u->has_sibling ? 2 : 1;
   }
+  if (!getenv("PINTRON_NO_PREFETCH") && in->n > 0) {
+    /* PRE_CHUNKS ranges of whole units with about the same number of entries */
+    sh->n_pre = sh->n_units < PRE_CHUNKS ? (int)sh->n_units : PRE_CHUNKS;
+    for (int cidx = 0; cidx <= sh->n_pre; ++cidx) {
+      const size_t u = sh->n_units * (size_t)cidx / (size_t)sh->n_pre;
+      sh->pre_lo[cidx] = u < sh->n_units ? sh->units[u].first : in->n;
+    }
+    for (int cidx = 0; cidx < sh->n_pre; ++cidx) {
+      const size_t lo = sh->pre_lo[cidx], hi = sh->pre_lo[cidx + 1];
+      size_t total = 0;
+      for (size_t k = lo; k < hi; ++k) total += strlen(in->list[k]->seq);
+      char* blob = (char*)malloc(total + 1);
+      uint64_t* off = (uint64_t*)malloc((hi - lo + 1) * sizeof(uint64_t));
+      size_t pos = 0;
+      for (size_t k = lo; k < hi; ++k) { const size_t m = strlen(in->list[k]->seq); off[k - lo] = pos; memcpy(blob + pos, in->list[k]->seq, m); pos += m; }
+      off[hi - lo] = pos;
+      const int prc = pgpu_pairing_plan_create(s->ctx0, sh->idx, blob, off, hi - lo, &s->pplan[cidx]);
+      free(blob); free(off);
+      if (prc != PGPU_OK) { fprintf(stderr, "* FATAL pairing plan: %s\n", pgpu_last_error(s->ctx0)); free(s); return NULL; }
+    }
+  }
   pthread_mutex_init(&sh->mu, NULL);
+  pthread_cond_init(&sh->ready_cv, NULL);
   pthread_mutex_init(&sh->svc.mu, NULL);
   pthread_cond_init(&sh->svc.posted, NULL);
   pthread_cond_init(&sh->svc.finished, NULL);
-  sh->svc.n_threads = (int)env_size("PINTRON_SERVICES", 1);
+  sh->svc.n_threads = (int)env_size("PINTRON_SERVICES", 2);
   if (sh->svc.n_threads > MAX_SERVICES) sh->svc.n_threads = MAX_SERVICES;
   for (int k = 0; k < sh->svc.n_threads; ++k) {
     if (pgpu_init(ef_gpu_device_from_env(), &sh->svc.threads[k].ctx) != PGPU_OK) { free(s); return NULL; }
@@ -599,11 +626,11 @@ ef_session* ef_session_open(int argc, char** argv) {
   const size_t cores = ncpu > 16 ? 16 : (ncpu > 0 ? (size_t)ncpu : 1);
   s->nthreads = env_size("PINTRON_THREADS", cores);
   if (s->nthreads > sh->n_units) s->nthreads = sh->n_units ? sh->n_units : 1;
-  sh->max_fibers = env_size("PINTRON_FIBERS", 1024);
+  sh->max_fibers = env_size("PINTRON_FIBERS", 1536);
   sh->stack_size = env_size("PINTRON_FIBER_STACK_KB", 256) * 1024;
   sh->kernel_timing = getenv("PINTRON_KERNEL_TIMING") != NULL;
   sh->gen_len = strlen(in->gen->seq);
-  sh->n_lanes = (int)env_size("PINTRON_LANES", 2);
+  sh->n_lanes = (int)env_size("PINTRON_LANES", 3);
   if (sh->n_lanes > MAX_LANES) sh->n_lanes = MAX_LANES;
   s->load_s = t_loaded - t_start;
   s->index_s = now_s() - t_loaded;
@@ -620,30 +647,42 @@ static void free_unit_buffers(shared* sh, bool release) {
 
 /* one pass of the whole hot path over the batch: pairing prefetch (resident patterns), then the
  * fibres (MEG, embeddings, DP batches, refinement) on all worker threads */
+/* prefetch thread: the pairings of chunk after chunk (one resident batch each); every finished
+ * chunk releases its units to the workers */
+static void* prefetch_main(void* arg) {
+  ef_session* s = (ef_session*)arg;
+  shared* sh = &s->sh;
+  pgpu_pairing_params prm = { s->in.cfg.min_factor_len, 0, s->in.cfg.min_string_depth_rate };
+  for (int c = 0; c < sh->n_pre; ++c) {
+    int prc = pgpu_pairing_plan_run(s->ctx0, s->pplan[c], &prm);
+    if (prc == PGPU_OK) {
+      const size_t cnt = (size_t)pgpu_pairing_plan_count(s->pplan[c]);
+      sh->pre_tri[c] = (pgpu_pairing*)malloc((cnt + 1) * sizeof(pgpu_pairing));
+      sh->pre_first[c] = (uint64_t*)malloc((sh->pre_lo[c + 1] - sh->pre_lo[c] + 1) * sizeof(uint64_t));
+      prc = pgpu_pairing_plan_fetch(s->ctx0, s->pplan[c], sh->pre_tri[c], cnt, sh->pre_first[c]);
+    }
+    for (int k = 0; k < 6; ++k) s->pre_kernel_ms[k] += pgpu_pairing_plan_kernel_ms(s->pplan[c], k);
+    pthread_mutex_lock(&sh->mu);
+    if (prc != PGPU_OK) { fprintf(stderr, "* FATAL pairing prefetch failed: %s\n", pgpu_last_error(s->ctx0)); sh->failed = 1; }
+    else sh->ready_entries = sh->pre_lo[c + 1];
+    pthread_cond_broadcast(&sh->ready_cv);
+    pthread_mutex_unlock(&sh->mu);
+    if (prc != PGPU_OK) break;
+  }
+  s->pre_wall = now_s() - s->pre_t0;
+  return NULL;
+}
+
 int ef_session_step(ef_session* s, ef_sched_stats* stats_out) {
   shared* sh = &s->sh;
   const double t0 = now_s();
   free_unit_buffers(sh, false);
-  const double t_f1 = now_s();
-  free(sh->pre_tri); free(sh->pre_first); sh->pre_tri = NULL; sh->pre_first = NULL;
-  sh->next_unit = 0; sh->failed = 0;
-  const double t_freed = now_s();
-  if (getenv("PINTRON_VERBOSE")) fprintf(stderr, "* step: free unit buffers %.3fs, free pairings %.3fs\n", t_f1 - t0, t_freed - t_f1);
-  double t_run = t_freed;
-  if (s->pplan) {
-    pgpu_pairing_params prm = { s->in.cfg.min_factor_len, 0, s->in.cfg.min_string_depth_rate };
-    int prc = pgpu_pairing_plan_run(s->ctx0, s->pplan, &prm);
-    t_run = now_s();
-    if (prc == PGPU_OK) {
-      const size_t cnt = (size_t)pgpu_pairing_plan_count(s->pplan);
-      sh->pre_tri = (pgpu_pairing*)malloc((cnt + 1) * sizeof(pgpu_pairing));
-      sh->pre_first = (uint64_t*)malloc((s->in.n + 1) * sizeof(uint64_t));
-      prc = pgpu_pairing_plan_fetch(s->ctx0, s->pplan, sh->pre_tri, cnt, sh->pre_first);
-    }
-    if (prc != PGPU_OK) { fprintf(stderr, "* FATAL pairing prefetch failed: %s\n", pgpu_last_error(s->ctx0)); return 1; }
-  }
+  for (int c = 0; c < PRE_CHUNKS; ++c) { free(sh->pre_tri[c]); free(sh->pre_first[c]); sh->pre_tri[c] = NULL; sh->pre_first[c] = NULL; }
+  sh->next_unit = 0; sh->failed = 0; sh->ready_entries = 0;
+  memset(s->pre_kernel_ms, 0, sizeof s->pre_kernel_ms);
+  s->pre_t0 = t0; s->pre_wall = 0;
+  if (sh->n_pre) pthread_create(&s->pre_thread, NULL, prefetch_main, s);
   const double t1 = now_s();
-  if (getenv("PINTRON_VERBOSE")) fprintf(stderr, "* step: free previous %.3fs, pairing kernels %.3fs, fetch %.3fs (%zu pairings)\n", t_freed - t0, t_run - t_freed, t1 - t_run, s->pplan ? (size_t)pgpu_pairing_plan_count(s->pplan) : (size_t)0);
   service* sv = &sh->svc;
   sv->stop = false; sv->head = sv->tail = NULL; sv->sh = sh;
   for (int k = 0; k < sv->n_threads; ++k) {
@@ -655,6 +694,7 @@ int ef_session_step(ef_session* s, ef_sched_stats* stats_out) {
   pthread_t* th = (pthread_t*)malloc(s->nthreads * sizeof(pthread_t));
   for (size_t t = 0; t < s->nthreads; ++t) { ws[t].sh = sh; pthread_create(&th[t], NULL, worker_main, &ws[t]); }
   for (size_t t = 0; t < s->nthreads; ++t) pthread_join(th[t], NULL);
+  if (sh->n_pre) pthread_join(s->pre_thread, NULL);
   pthread_mutex_lock(&sv->mu); sv->stop = true; pthread_cond_broadcast(&sv->posted); pthread_mutex_unlock(&sv->mu);
   for (int k = 0; k < sv->n_threads; ++k) pthread_join(sv->threads[k].thread, NULL);
   ef_sched_stats st;
@@ -671,16 +711,16 @@ int ef_session_step(ef_session* s, ef_sched_stats* stats_out) {
     st.host_s += ws[t].stats.host_s; st.pairing_s += ws[t].stats.pairing_s; st.dp_s += ws[t].stats.dp_s;
     for (int k = 0; k < ws[t].stats.n_kernels; ++k) kstat_add(&st, &ws[t].stats.kernels[k]);
   }
-  if (s->pplan) {
+  if (sh->n_pre) {
     static const char* nm[6] = { "pair_locate", "pair_chain", "pair_count+scan", "pair_fill", "pair_cross+scan", "pair_emit" };
     for (int k = 0; k < 6; ++k) {
       ef_kernel_stat ks; memset(&ks, 0, sizeof ks);
       snprintf(ks.name, sizeof ks.name, "%s", nm[k]);
-      ks.ms = pgpu_pairing_plan_kernel_ms(s->pplan, k); ks.launches = 1; ks.jobs = s->in.n;
+      ks.ms = s->pre_kernel_ms[k]; ks.launches = (size_t)sh->n_pre; ks.jobs = s->in.n;
       if (ks.ms > 0) kstat_add(&st, &ks);
     }
   }
-  st.load_s = s->load_s; st.index_s = s->index_s; st.prefetch_s = t1 - t0; st.workers_s = now_s() - t1;
+  st.load_s = s->load_s; st.index_s = s->index_s; st.prefetch_s = s->pre_wall; st.workers_s = now_s() - t1;
   for (size_t u = 0; u < sh->n_units; ++u) if (sh->units[u].len[1]) ++st.aligned;
   if (stats_out) *stats_out = st;
   free(ws); free(th);
@@ -726,8 +766,11 @@ void ef_session_close(ef_session* s) {
   shared* sh = &s->sh;
   free_unit_buffers(sh, true);
   while (sh->fiber_pool) { fiber* nx = sh->fiber_pool->pool_next; free(sh->fiber_pool->stack); free(sh->fiber_pool); sh->fiber_pool = nx; }
-  free(sh->units); free(sh->pre_tri); free(sh->pre_first);
-  if (s->pplan) pgpu_pairing_plan_destroy(s->ctx0, s->pplan);
+  free(sh->units);
+  for (int c = 0; c < PRE_CHUNKS; ++c) {
+    free(sh->pre_tri[c]); free(sh->pre_first[c]);
+    if (s->pplan[c]) pgpu_pairing_plan_destroy(s->ctx0, s->pplan[c]);
+  }
   for (int k = 0; k < sh->svc.n_threads; ++k) pgpu_destroy(sh->svc.threads[k].ctx);
   pgpu_index_destroy(s->ctx0, sh->idx);
   pgpu_destroy(s->ctx0);

@@ -13,7 +13,7 @@ typedef struct {
 
 typedef struct {
   size_t threads, units, aligned, dp_batches, dp_jobs, pairing_batches, pairing_requests;
-  double load_s, index_s, prefetch_s, workers_s;   /* wall-clock phases */
+  double load_s, index_s, prefetch_s, workers_s;   /* wall-clock phases (prefetch runs beside the workers) */
   double host_s, pairing_s, dp_s;         /* summed over threads: fibres / pairing batches / DP batches */
   int n_kernels;                          /* filled when PINTRON_KERNEL_TIMING is set */
   ef_kernel_stat kernels[EF_MAX_KERNELS];
@@ -30,9 +30,9 @@ char* ef_session_output(ef_session* s, int which, size_t* len);   /* 0..5, see e
 size_t ef_session_n_ests(const ef_session* s);
 void ef_session_close(ef_session* s);
 
-/* environment: PINTRON_THREADS (workers; default min(online CPUs, 16)), PINTRON_LANES (2),
- * PINTRON_FIBERS (fibres per worker over all lanes, 1024), PINTRON_FIBER_STACK_KB (256),
- * PINTRON_SERVICES (GPU service threads, 1), PINTRON_GPU_DEVICE (0), PINTRON_NO_PREFETCH,
+/* environment: PINTRON_THREADS (workers; default min(online CPUs, 16)), PINTRON_LANES (3),
+ * PINTRON_FIBERS (fibres per worker over all lanes, 1536), PINTRON_FIBER_STACK_KB (256),
+ * PINTRON_SERVICES (GPU service threads, 2), PINTRON_GPU_DEVICE (0), PINTRON_NO_PREFETCH,
  * PINTRON_KERNEL_TIMING, PINTRON_VERBOSE */
 int ef_run_batched(int argc, char** argv);
 int ef_run_batched_stats(int argc, char** argv, ef_sched_stats* stats);
