@@ -38,6 +38,36 @@ CPU_SAMPLE = 3000              # ESTs of the same workload given to the referenc
 from pintron_amd.estfact import Session, gather_bytes, load_host_lib  # noqa: E402
 
 
+def rocprof_symbol(group_name):
+    """Kernel symbol (as rocprofv3 prints it) of a kernel group name reported by the library."""
+    import re
+    modes = {"ED": 0, "ALIGN": 1, "BORDERS": 2, "AFFIX": 3, "KBAND": 4}
+    m = re.match(r"lev_wave<(\w+),R=(\d+)>", group_name)
+    if m:
+        return "lev_wave_kernel<%s, %d>" % (m.group(2), modes[m.group(1)])
+    m = re.match(r"gap_wave<R=(\d+)>", group_name)
+    if m:
+        return "gap_wave_kernel<%s>" % m.group(1)
+    m = re.match(r"(borders|affix)_coop<rows<=(\d+)>", group_name)
+    if m:
+        return "%s_coop_kernel<%d>" % (m.group(1), max(1, int(m.group(2)) // 256))
+    return {"lcf": "lcf_kernel", "align_traceback": "align_traceback_kernel",
+            "gap_traceback": "gap_traceback_kernel"}.get(group_name, group_name.split("+")[0] + "_kernel")
+
+
+def pmc_traffic(group_name):
+    """HBM bytes per launch of that kernel from the committed PMC passes (tools/pmc_traffic.sh:
+    (2 x FETCH_SIZE + WRITE_SIZE) x 1024, separate --pmc runs), or None."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    sym = rocprof_symbol(group_name)
+    for k, v in json.load(open(path)).items():
+        if sym in k:
+            return v["hbm_bytes_per_launch"]
+    return None
+
+
 def cpu_reference(sample_dir):
     """Reference CPU est-fact (oracle/_ref, compiled from /root/reference) on the sample, one core."""
     exe = os.path.join(ROOT, "oracle", "_ref", "est-fact-ref")
@@ -137,7 +167,7 @@ def main():
             per_launch_ms = dom["ms"] / max(dom["launches"], 1)
             ach = dom["algo_bytes"] / (dom["ms"] * 1e-3) / 1e9 if dom["ms"] and dom["algo_bytes"] else None
             out["roofline"] = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": ach / HBM_PEAK_GBS if ach else None, "traffic": None,
+                               "frac": ach / HBM_PEAK_GBS if ach else None, "traffic": pmc_traffic(name),
                                "avg_launch_ms": per_launch_ms, "launches_per_step": dom["launches"],
                                "algo_bytes_per_launch": dom["algo_bytes"] / max(dom["launches"], 1)}
             out["kernels"] = [{"name": n, "ms_per_step": round(k["ms"], 3), "launches": round(k["launches"], 1),
