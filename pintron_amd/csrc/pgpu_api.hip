@@ -41,6 +41,9 @@ struct pgpu_ctx {
   // pinned staging for the device->host result copies (pageable copies block and spin inside HIP)
   void* pin[2] = {nullptr, nullptr};
   size_t pin_cap[2] = {0, 0};
+  // timing events are recycled (a plan with the DP pool borrows them; create/destroy per group
+  // and batch is measurable at a few hundred batches per second)
+  std::vector<hipEvent_t> ev_pool;
 };
 
 static int wait_stream(pgpu_ctx* ctx, hipStream_t st) {
@@ -148,6 +151,7 @@ extern "C" int pgpu_destroy(pgpu_ctx* ctx) {
   if (ctx->ev_upload) hipEventDestroy(ctx->ev_upload);
   if (ctx->ev_done) hipEventDestroy(ctx->ev_done);
   for (auto& e : ctx->ev_aux) if (e) hipEventDestroy(e);
+  for (auto& e : ctx->ev_pool) if (e) hipEventDestroy(e);
   for (auto& q : ctx->pin) if (q) hipHostFree(q);
   hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -196,22 +200,28 @@ struct pgpu_dp_plan {
   uint64_t cells[PGPU_DP_NKINDS] = {0}, algo_bytes[PGPU_DP_NKINDS] = {0};
   double ms[PGPU_DP_NKINDS] = {0};
   uint64_t launches[PGPU_DP_NKINDS] = {0};
-  bool launched = false;
-  bool pooled = false;                      // device buffers borrowed from the context's pool
+  bool launched = false, synced = false;
+  bool pooled = false;                      // device + pinned buffers and events borrowed from the context
   pgpu_ctx* owner = nullptr;
-  std::vector<DevJob> host_jobs;            // kept alive until the uploads have been consumed
+  // One device allocation: [arena | job table | LCF keys | results | strings | traceback workspace].
+  // The first four are filled by ONE host->device copy from the pinned image `h_up`; results and
+  // strings come back in ONE device->host copy into `h_down`, enqueued by launch after the kernels.
+  uint8_t* d_base = nullptr;
+  uint8_t* h_up = nullptr; uint8_t* h_down = nullptr;
+  size_t up_bytes = 0, off_results = 0, down_bytes = 0;
 };
 
 static void plan_free(pgpu_dp_plan* p) {
   if (!p) return;
-  for (auto& g : p->groups) {
-    if (g.ev0) hipEventDestroy(g.ev0);
-    if (g.ev1) hipEventDestroy(g.ev1);
-  }
   if (p->pooled) pgpu_ctx_pool_release(p->owner, 0);
   else {
-    hipFree(p->d_jobs); hipFree(p->d_results); hipFree(p->d_arena);
-    hipFree(p->d_ws); hipFree(p->d_strs); hipFree(p->d_keys);
+    for (auto& g : p->groups) {
+      if (g.ev0) hipEventDestroy(g.ev0);
+      if (g.ev1) hipEventDestroy(g.ev1);
+    }
+    if (p->d_base) hipFree(p->d_base);
+    if (p->h_up) hipHostFree(p->h_up);
+    if (p->h_down) hipHostFree(p->h_down);
   }
   delete p;
 }
@@ -230,20 +240,11 @@ extern "C" int pgpu_dp_plan_create(pgpu_ctx* ctx, const pgpu_index* idx, const p
 
   const uint8_t* d_gen = idx ? pgpu_index_genomic(idx) : nullptr;
   const size_t gen_len = idx ? pgpu_index_length(idx) : 0;
-
-  // operands live in one HBM arena; resolve every job to device pointers once the arena exists
-  const size_t arena_alloc = arena_len + 16;
   p->owner = ctx;
   p->pooled = pgpu_ctx_pool_acquire(ctx, 0);
-  auto dev_alloc = [&](int slot, size_t bytes) -> void* {
-    if (p->pooled) return pgpu_ctx_pool_get(ctx, 0, slot, bytes);
-    void* q = nullptr;
-    return hipMalloc(&q, bytes ? bytes : 16) == hipSuccess ? q : nullptr;
-  };
-  p->d_arena = (uint8_t*)dev_alloc(0, arena_alloc);
-  if (!p->d_arena) { plan_free(p); return set_err(ctx, PGPU_ENOMEM, "hipMalloc arena (%zu B)", arena_alloc); }
 
-  struct Keyed { DevJob j; int family; int kind; uint32_t R; uint64_t size; };
+  // pass 1: validate, classify; operands are addressed by OFFSET until the arena's place is known
+  struct Keyed { DevJob j; uint64_t a_off, b_off; bool ag, bg; int family; int kind; uint32_t R; uint64_t size; };
   std::vector<Keyed> v;
   v.reserve(n_jobs);
   for (size_t i = 0; i < n_jobs; ++i) {
@@ -257,8 +258,7 @@ extern "C" int pgpu_dp_plan_create(pgpu_ctx* ctx, const pgpu_index* idx, const p
     if (in.a_off > a_space || in.a_len > a_space - in.a_off) continue;
     if (in.b_off > b_space || in.b_len > b_space - in.b_off) continue;
     Keyed k{};
-    k.j.a = (ag ? d_gen : p->d_arena) + in.a_off;
-    k.j.b = (bg ? d_gen : p->d_arena) + in.b_off;
+    k.a_off = in.a_off; k.b_off = in.b_off; k.ag = ag; k.bg = bg;
     k.j.la = in.a_len; k.j.lb = in.b_len;
     k.j.p0 = in.p0; k.j.p1 = in.p1; k.j.p2 = in.p2; k.j.tail = in.tail;
     k.j.out_idx = (uint32_t)i;
@@ -371,34 +371,71 @@ extern "C" int pgpu_dp_plan_create(pgpu_ctx* ctx, const pgpu_index* idx, const p
   for (auto& g : p->groups) {
     p->cells[g.kind] += g.cells;
     p->algo_bytes[g.kind] += g.algo_bytes;
-    if (ctx->timing && (hipEventCreate(&g.ev0) != hipSuccess || hipEventCreate(&g.ev1) != hipSuccess)) {
-      plan_free(p);
-      return set_err(ctx, PGPU_EDEVICE, "hipEventCreate failed");
+  }
+  if (ctx->timing) {
+    const size_t need = 2 * p->groups.size();
+    if (p->pooled) {
+      while (ctx->ev_pool.size() < need) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) { plan_free(p); return set_err(ctx, PGPU_EDEVICE, "hipEventCreate failed"); }
+        ctx->ev_pool.push_back(e);
+      }
+      for (size_t g = 0; g < p->groups.size(); ++g) { p->groups[g].ev0 = ctx->ev_pool[2 * g]; p->groups[g].ev1 = ctx->ev_pool[2 * g + 1]; }
+    } else {
+      for (auto& g : p->groups)
+        if (hipEventCreate(&g.ev0) != hipSuccess || hipEventCreate(&g.ev1) != hipSuccess) {
+          plan_free(p);
+          return set_err(ctx, PGPU_EDEVICE, "hipEventCreate failed");
+        }
     }
   }
 
-  // device allocations + upload
-  auto fail_mem = [&](const char* what, size_t bytes) {
+  // one device allocation, one pinned upload image, one pinned download image
+  auto up256 = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  const size_t off_arena = 0;
+  const size_t off_jobs = up256(arena_len + 16);
+  const size_t off_keys = up256(off_jobs + std::max<size_t>(v.size(), 1) * sizeof(DevJob));
+  const size_t off_results = up256(off_keys + (nkeys + 1) * sizeof(unsigned long long));
+  const size_t off_strs = off_results + std::max<size_t>(n_jobs, 1) * sizeof(DevResult);   // directly behind the results
+  const size_t off_ws = up256(off_strs + strs + 16);
+  const size_t total = off_ws + ws + 16;
+  p->up_bytes = off_strs;                      // arena .. results (prefilled)
+  p->off_results = off_results;
+  p->down_bytes = (off_strs - off_results) + strs;
+  if (p->pooled) {
+    p->d_base = (uint8_t*)pgpu_ctx_pool_get(ctx, 0, 0, total);
+    p->h_up = (uint8_t*)pinned(ctx, 0, p->up_bytes);
+    p->h_down = (uint8_t*)pinned(ctx, 1, p->down_bytes + 16);
+  } else {
+    void* q = nullptr;
+    if (hipMalloc(&q, total) == hipSuccess) p->d_base = (uint8_t*)q;
+    if (hipHostMalloc(&q, p->up_bytes, hipHostMallocDefault) == hipSuccess) p->h_up = (uint8_t*)q;
+    if (hipHostMalloc(&q, p->down_bytes + 16, hipHostMallocDefault) == hipSuccess) p->h_down = (uint8_t*)q;
+  }
+  if (!p->d_base || !p->h_up || !p->h_down) {
     plan_free(p);
-    return set_err(ctx, PGPU_ENOMEM, "hipMalloc %s (%zu B) failed", what, bytes);
-  };
-  const size_t nd = std::max<size_t>(v.size(), 1);
-  if (!(p->d_jobs = (DevJob*)dev_alloc(1, nd * sizeof(DevJob)))) return fail_mem("jobs", nd * sizeof(DevJob));
-  if (!(p->d_results = (DevResult*)dev_alloc(2, std::max<size_t>(n_jobs, 1) * sizeof(DevResult)))) return fail_mem("results", n_jobs * sizeof(DevResult));
-  if (!(p->d_ws = (uint8_t*)dev_alloc(3, ws + 16))) return fail_mem("workspace", ws);
-  if (!(p->d_strs = (uint8_t*)dev_alloc(4, strs + 16))) return fail_mem("strings", strs);
-  if (!(p->d_keys = (unsigned long long*)dev_alloc(5, (nkeys + 1) * sizeof(unsigned long long)))) return fail_mem("lcf keys", nkeys * 8);
+    return set_err(ctx, PGPU_ENOMEM, "batch buffers (%zu B device, %zu B pinned) could not be allocated", total, p->up_bytes + p->down_bytes);
+  }
+  p->d_arena = p->d_base + off_arena;
+  p->d_jobs = (DevJob*)(p->d_base + off_jobs);
+  p->d_keys = (unsigned long long*)(p->d_base + off_keys);
+  p->d_results = (DevResult*)(p->d_base + off_results);
+  p->d_strs = p->d_base + off_strs;
+  p->d_ws = p->d_base + off_ws;
 
-  std::vector<DevJob>& hj = p->host_jobs;
-  hj.resize(v.size());
-  for (size_t q = 0; q < v.size(); ++q) hj[q] = v[q].j;
-  hipError_t e = hipSuccess;
-  if (arena_len) e = hipMemcpyAsync(p->d_arena, arena, arena_len, hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess && !hj.empty())
-    e = hipMemcpyAsync(p->d_jobs, hj.data(), hj.size() * sizeof(DevJob), hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess && n_jobs)
-    e = hipMemcpyAsync(p->d_results, p->prefill.data(), n_jobs * sizeof(DevResult), hipMemcpyHostToDevice, ctx->stream);
-  // (host_jobs and prefill stay alive in the plan; the caller's arrays were staged by the copies)
+  // the upload image: operands, the sorted job table with device pointers, zeroed LCF keys,
+  // prefilled results (status of the jobs that never reach the device)
+  if (arena_len) memcpy(p->h_up + off_arena, arena, arena_len);
+  DevJob* hj = (DevJob*)(p->h_up + off_jobs);
+  for (size_t q = 0; q < v.size(); ++q) {
+    DevJob d = v[q].j;
+    d.a = (v[q].ag ? d_gen : p->d_arena) + v[q].a_off;
+    d.b = (v[q].bg ? d_gen : p->d_arena) + v[q].b_off;
+    hj[q] = d;
+  }
+  memset(p->h_up + off_keys, 0, off_results - off_keys);
+  if (n_jobs) memcpy(p->h_up + off_results, p->prefill.data(), n_jobs * sizeof(DevResult));
+  const hipError_t e = hipMemcpyAsync(p->d_base, p->h_up, p->up_bytes, hipMemcpyHostToDevice, ctx->stream);
   if (e != hipSuccess) { plan_free(p); return set_err(ctx, PGPU_EDEVICE, "upload failed: %s", hipGetErrorString(e)); }
   *out = p;
   return PGPU_OK;
@@ -407,8 +444,7 @@ extern "C" int pgpu_dp_plan_create(pgpu_ctx* ctx, const pgpu_index* idx, const p
 extern "C" int pgpu_dp_plan_launch(pgpu_ctx* ctx, pgpu_dp_plan* p) {
   if (!ctx || !p) return set_err(ctx, PGPU_EINVAL, "bad argument");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  if (p->n_keys) HIP_TRY(ctx, hipMemsetAsync(p->d_keys, 0, p->n_keys * sizeof(unsigned long long), ctx->stream));
-  // uploads (plan_create) and the key reset are on the main stream; the groups fan out
+  // the upload (plan_create) is on the main stream; the groups fan out
   if (ctx->fanout) {
     HIP_TRY(ctx, hipEventRecord(ctx->ev_upload, ctx->stream));
     for (auto& a : ctx->aux) HIP_TRY(ctx, hipStreamWaitEvent(a, ctx->ev_upload, 0));
@@ -444,6 +480,9 @@ extern "C" int pgpu_dp_plan_launch(pgpu_ctx* ctx, pgpu_dp_plan* p) {
       HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_aux[i], 0));
     }
   }
+  // results and alignment strings come back in one copy as soon as every group is done
+  if (p->down_bytes)
+    HIP_TRY(ctx, hipMemcpyAsync(p->h_down, p->d_base + p->off_results, p->down_bytes, hipMemcpyDeviceToHost, ctx->stream));
   p->launched = true;
   return PGPU_OK;
 }
@@ -451,6 +490,7 @@ extern "C" int pgpu_dp_plan_launch(pgpu_ctx* ctx, pgpu_dp_plan* p) {
 extern "C" int pgpu_dp_plan_sync(pgpu_ctx* ctx, pgpu_dp_plan* p) {
   if (!ctx || !p) return set_err(ctx, PGPU_EINVAL, "bad argument");
   if (wait_stream(ctx, ctx->stream) != 0) return set_err(ctx, PGPU_EDEVICE, "waiting for the batch failed");
+  p->synced = p->launched;
   if (p->launched) {
     for (int k = 0; k < PGPU_DP_NKINDS; ++k) { p->ms[k] = 0; p->launches[k] = 0; }
     for (auto& g : p->groups) {
@@ -469,16 +509,13 @@ extern "C" int pgpu_dp_plan_fetch(pgpu_ctx* ctx, pgpu_dp_plan* p, pgpu_dp_result
                                   char* strings, size_t cap) {
   if (!ctx || !p || (p->n_jobs && !results)) return set_err(ctx, PGPU_EINVAL, "bad argument");
   if (p->strs_bytes && strings && cap < p->strs_bytes) return set_err(ctx, PGPU_ENOSPC, "string buffer too small: need %zu", p->strs_bytes);
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
-  const size_t rb = p->n_jobs * sizeof(DevResult), sb = (p->strs_bytes && strings) ? p->strs_bytes : 0;
-  void* pr = rb ? pinned(ctx, 0, rb) : nullptr;
-  void* ps = sb ? pinned(ctx, 1, sb) : nullptr;
-  if ((rb && !pr) || (sb && !ps)) return set_err(ctx, PGPU_ENOMEM, "pinned staging buffer");
-  if (rb) HIP_TRY(ctx, hipMemcpyAsync(pr, p->d_results, rb, hipMemcpyDeviceToHost, ctx->stream));
-  if (sb) HIP_TRY(ctx, hipMemcpyAsync(ps, p->d_strs, sb, hipMemcpyDeviceToHost, ctx->stream));
-  if (wait_stream(ctx, ctx->stream) != 0) return set_err(ctx, PGPU_EDEVICE, "result download failed");
-  if (rb) memcpy(results, pr, rb);
-  if (sb) memcpy(strings, ps, sb);
+  if (!p->launched) return set_err(ctx, PGPU_EINVAL, "the plan has not been launched");
+  // launch enqueued the download behind the kernels; after this wait the pinned image is complete
+  if (!p->synced && wait_stream(ctx, ctx->stream) != 0) return set_err(ctx, PGPU_EDEVICE, "result download failed");
+  p->synced = true;
+  const size_t rb = p->n_jobs * sizeof(DevResult);
+  if (rb) memcpy(results, p->h_down, rb);
+  if (p->strs_bytes && strings) memcpy(strings, p->h_down + (p->down_bytes - p->strs_bytes), p->strs_bytes);
   return PGPU_OK;
 }
 

@@ -374,24 +374,37 @@ ef_list* ef_clean_external_exons(ef_list* fact, const char* gen, const char* est
   return fact;
 }
 
-/* dustScoreByLeftAndRight / dustScore (src/exon-complexity.c:38-79) */
-static int dinuc(char a, char b) {
-  static const char* B = "ACGT";
-  int x = -1, y = -1;
-  for (int k = 0; k < 4; ++k) { if (is_ch(a, B[k])) x = k; if (is_ch(b, B[k])) y = k; }
-  return (x < 0 || y < 0) ? 16 : 4 * x + y;
+/* dustScoreByLeftAndRight / dustScore (src/exon-complexity.c:38-79): the substring is scanned in
+ * place (real_substring stops at the terminator, so does the scan) */
+static int base_index(unsigned char c) {
+  switch (c) {
+    case 'A': case 'a': return 0;
+    case 'C': case 'c': return 1;
+    case 'G': case 'g': return 2;
+    case 'T': case 't': return 3;
+    default: return -1;
+  }
 }
 static double dust_score(const char* s, int start, int end) {
-  char* sub = ef_real_substring(start, end - start + 1, s);
-  const size_t len = strlen(sub);
+  int want = end - start + 1;
+  if (start < 0) { want += start; start = 0; }          /* real_substring clamps a negative index */
+  if (want < 0) want = 0;
+  const char* sub = s + start;
+  size_t len = 0;
+  while (len < (size_t)want && sub[len] != '\0') ++len;
   double r = 0.0;
   if ((int)len > 2) {
     int freq[17] = {0}, running = 0;
-    for (int i = 0; i < (int)len - 1; ++i) { const int k = dinuc(sub[i], sub[i + 1]); running += freq[k]; ++freq[k]; }
+    int x = base_index((unsigned char)sub[0]);
+    for (int i = 0; i < (int)len - 1; ++i) {
+      const int y = base_index((unsigned char)sub[i + 1]);
+      const int k = (x < 0 || y < 0) ? 16 : 4 * x + y;
+      running += freq[k]; ++freq[k];
+      x = y;
+    }
     const double dust = (10.0 * (double)running) / ((double)(len - 2));
     r = dust / len;
   }
-  free(sub);
   return r;
 }
 

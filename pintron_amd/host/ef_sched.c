@@ -126,6 +126,7 @@ typedef struct service_thread {          /* one submitter: own context (stream, 
   struct service* sv;
   pgpu_ctx* ctx;
   ef_sched_stats stats;                  /* batches, jobs, kernel timings */
+  double phase_s[6];                     /* idle, idle+merge, create, launch, sync, fetch+stats */
 } service_thread;
 
 typedef struct service {
@@ -370,7 +371,9 @@ static void* service_main(void* arg) {
   char* arena = NULL; size_t arena_cap = 0;
   for (;;) {
     pthread_mutex_lock(&sv->mu);
+    const double t_idle = now_s();
     while (!sv->head && !sv->stop) pthread_cond_wait(&sv->posted, &sv->mu);
+    me->phase_s[0] += now_s() - t_idle;
     dp_request* list = sv->head;
     sv->head = sv->tail = NULL;
     const bool stop = sv->stop;
@@ -396,9 +399,15 @@ static void* service_main(void* arg) {
     mb->refs = nreq;
     mb->results = (pgpu_dp_result*)malloc((nj + 1) * sizeof(pgpu_dp_result));
     pgpu_dp_plan* plan = NULL;
+    const double t_a = now_s();
+    me->phase_s[1] += t_a - t_idle - 0;        /* (includes the idle wait; corrected below) */
     int rc = pgpu_dp_plan_create(me->ctx, sh->idx, jobs, nj, arena, apos, &plan);
+    const double t_b = now_s();
     if (rc == PGPU_OK) rc = pgpu_dp_plan_launch(me->ctx, plan);
+    const double t_c = now_s();
     if (rc == PGPU_OK) rc = pgpu_dp_plan_sync(me->ctx, plan);
+    const double t_d = now_s();
+    me->phase_s[2] += t_b - t_a; me->phase_s[3] += t_c - t_b; me->phase_s[4] += t_d - t_c;
     if (rc == PGPU_OK) {
       const size_t sb = pgpu_dp_plan_string_bytes(plan);
       mb->strings = (char*)malloc(sb + 16);
@@ -416,6 +425,7 @@ static void* service_main(void* arg) {
       }
     }
     if (plan) pgpu_dp_plan_destroy(me->ctx, plan);
+    me->phase_s[5] += now_s() - t_d;
     if (rc != PGPU_OK) fprintf(stderr, "* FATAL DP batch failed: %s\n", pgpu_last_error(me->ctx));
     me->stats.dp_batches++; me->stats.dp_jobs += nj;
     pthread_mutex_lock(&sv->mu);
@@ -687,6 +697,7 @@ int ef_session_step(ef_session* s, ef_sched_stats* stats_out) {
   sv->stop = false; sv->head = sv->tail = NULL; sv->sh = sh;
   for (int k = 0; k < sv->n_threads; ++k) {
     memset(&sv->threads[k].stats, 0, sizeof(ef_sched_stats));
+    memset(sv->threads[k].phase_s, 0, sizeof sv->threads[k].phase_s);
     sv->threads[k].sv = sv;
     pthread_create(&sv->threads[k].thread, NULL, service_main, &sv->threads[k]);
   }
@@ -702,6 +713,10 @@ int ef_session_step(ef_session* s, ef_sched_stats* stats_out) {
   st.threads = s->nthreads;
   for (int t = 0; t < sv->n_threads; ++t) {
     const ef_sched_stats* ss = &sv->threads[t].stats;
+    const double* ph = sv->threads[t].phase_s;
+    if (getenv("PINTRON_VERBOSE"))
+      fprintf(stderr, "* service %d: %zu batches, %zu jobs; idle %.3fs merge %.3fs create %.3fs launch %.3fs sync %.3fs fetch %.3fs\n",
+              t, ss->dp_batches, ss->dp_jobs, ph[0], ph[1] - ph[0], ph[2], ph[3], ph[4], ph[5]);
     st.dp_batches += ss->dp_batches; st.dp_jobs += ss->dp_jobs;
     for (int k = 0; k < ss->n_kernels; ++k) kstat_add(&st, &ss->kernels[k]);
   }
