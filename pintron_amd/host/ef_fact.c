@@ -260,70 +260,94 @@ static char* padded_copy(const char* s) {
   return r;
 }
 
-/* handle_endpoints (:2127-2301) */
+/* handle_endpoints (:2127-2301): the first and the last exon are re-aligned and trimmed.  With two
+ * or more exons the two alignments do not depend on each other and are requested together; with a
+ * single exon the second alignment sees the trimmed exon, as in the reference. */
+static void endpoint_head_apply(ef_list* fact, ef_factor* head, const ef_dp_res* r) {
+  const char* ea = r->s0; const char* ga = r->s1;
+  const int dim = r->v[1];
+  int j = 0, matches = 0, cut_factor = head->EST_start, cut_exon = head->GEN_start;
+  bool stop = false;
+  while (j < dim && !stop) {
+    if (matches > 5) stop = true;
+    else {
+      if (ea[j] == ga[j]) { ++cut_factor; ++cut_exon; ++matches; }
+      else { if (ea[j] != '-') ++cut_factor; if (ga[j] != '-') ++cut_exon; matches = 0; }
+      ++j;
+    }
+  }
+  if (!stop) free(efl_pop_front(fact));
+  else { head->EST_start = cut_factor - matches; head->GEN_start = cut_exon - matches; }
+}
+
+static void endpoint_tail_apply(ef_list* fact, ef_factor* tail, const ef_dp_res* r) {
+  char* ea = padded_copy(r->s0); char* ga = padded_copy(r->s1);
+  const int dim = r->v[1];
+  int j = dim - 1, matches = 0, cut_factor = tail->EST_end, cut_exon = tail->GEN_end;
+  bool stop = false;
+  while (j >= 0 && !stop) {
+    if (matches > 10) stop = true;
+    else {
+      if (ea[j] == ga[j]) { --cut_factor; --cut_exon; ++matches; }
+      else { if (ea[j] != '-') --cut_factor; if (ga[j] != '-') --cut_exon; matches = 0; }
+      --j;
+    }
+  }
+  int est_cleavage = cut_factor + matches, gen_cleavage = cut_exon + matches;
+  int cursor = j + matches + 1;
+  stop = false;
+  while (((ea[cursor] == '-' || ga[cursor] == '-') && cursor < dim - 1) && !stop) {
+    if (ea[cursor] == '-') {
+      int tr = cursor + 1;
+      while (ea[tr] == '-') ++tr;
+      if (tr < dim && ea[tr] == ga[cursor]) { ea[cursor] = ea[tr]; ea[tr] = '-'; ++est_cleavage; ++gen_cleavage; }
+      else stop = true;
+    } else {
+      int tr = cursor + 1;
+      while (ga[tr] == '-') ++tr;
+      if (tr < dim && ga[tr] == ea[cursor]) { ga[cursor] = ga[tr]; ga[tr] = '-'; ++est_cleavage; ++gen_cleavage; }
+      else stop = true;
+    }
+    ++cursor;
+  }
+  if (gen_cleavage >= tail->GEN_start) { tail->EST_end = est_cleavage; tail->GEN_end = gen_cleavage; }
+  else free(efl_pop_back(fact));
+  free(ea); free(ga);
+}
+
+static void endpoint_request(ef_dp_req* q, const ef_factor* x, const char* gen, const char* est) {
+  char* g = ef_real_substring(x->GEN_start, x->GEN_end - x->GEN_start + 1, gen);
+  char* e = ef_real_substring(x->EST_start, x->EST_end - x->EST_start + 1, est);
+  const ef_dp_req r = { EF_DP_ALIGN, e, strlen(e), g, strlen(g), 0, 0, 0, 0 };
+  *q = r;
+}
+static void endpoint_release(ef_dp_req* q, ef_dp_res* r) {
+  free((char*)q->a); free((char*)q->b); free(r->s0); free(r->s1);
+}
+
 static ef_list* handle_endpoints(ef_list* fact, const char* gen, const char* est, ef_backend* be) {
   ef_factor* head = (ef_factor*)efl_head(fact);
-  {
-    char* g = ef_real_substring(head->GEN_start, head->GEN_end - head->GEN_start + 1, gen);
-    char* e = ef_real_substring(head->EST_start, head->EST_end - head->EST_start + 1, est);
-    ef_dp_res r;
-    run_dp(be, EF_DP_ALIGN, e, strlen(e), g, strlen(g), 0, 0, 0, 0, &r);
-    const char* ea = r.s0; const char* ga = r.s1;
-    const int dim = r.v[1];
-    int j = 0, matches = 0, cut_factor = head->EST_start, cut_exon = head->GEN_start;
-    bool stop = false;
-    while (j < dim && !stop) {
-      if (matches > 5) stop = true;
-      else {
-        if (ea[j] == ga[j]) { ++cut_factor; ++cut_exon; ++matches; }
-        else { if (ea[j] != '-') ++cut_factor; if (ga[j] != '-') ++cut_exon; matches = 0; }
-        ++j;
-      }
-    }
-    if (!stop) free(efl_pop_front(fact));
-    else { head->EST_start = cut_factor - matches; head->GEN_start = cut_exon - matches; }
-    free(r.s0); free(r.s1); free(g); free(e);
+  ef_dp_req q[2]; ef_dp_res r[2];
+  if (efl_size(fact) >= 2) {
+    ef_factor* tail = (ef_factor*)efl_tail(fact);
+    endpoint_request(&q[0], head, gen, est);
+    endpoint_request(&q[1], tail, gen, est);
+    if (ef_dp_many(be, q, r, 2) != 0) { fprintf(stderr, "* FATAL alignment backend failed\n"); abort(); }
+    endpoint_head_apply(fact, head, &r[0]);
+    endpoint_tail_apply(fact, tail, &r[1]);      /* `tail` is not the exon the head step touched */
+    endpoint_release(&q[0], &r[0]); endpoint_release(&q[1], &r[1]);
+    return fact;
   }
+  endpoint_request(&q[0], head, gen, est);
+  if (ef_dp_many(be, q, r, 1) != 0) { fprintf(stderr, "* FATAL alignment backend failed\n"); abort(); }
+  endpoint_head_apply(fact, head, &r[0]);
+  endpoint_release(&q[0], &r[0]);
   if (efl_empty(fact)) return fact;
   ef_factor* tail = (ef_factor*)efl_tail(fact);
-  {
-    char* g = ef_real_substring(tail->GEN_start, tail->GEN_end - tail->GEN_start + 1, gen);
-    char* e = ef_real_substring(tail->EST_start, tail->EST_end - tail->EST_start + 1, est);
-    ef_dp_res r;
-    run_dp(be, EF_DP_ALIGN, e, strlen(e), g, strlen(g), 0, 0, 0, 0, &r);
-    char* ea = padded_copy(r.s0); char* ga = padded_copy(r.s1);
-    const int dim = r.v[1];
-    int j = dim - 1, matches = 0, cut_factor = tail->EST_end, cut_exon = tail->GEN_end;
-    bool stop = false;
-    while (j >= 0 && !stop) {
-      if (matches > 10) stop = true;
-      else {
-        if (ea[j] == ga[j]) { --cut_factor; --cut_exon; ++matches; }
-        else { if (ea[j] != '-') --cut_factor; if (ga[j] != '-') --cut_exon; matches = 0; }
-        --j;
-      }
-    }
-    int est_cleavage = cut_factor + matches, gen_cleavage = cut_exon + matches;
-    int cursor = j + matches + 1;
-    stop = false;
-    while (((ea[cursor] == '-' || ga[cursor] == '-') && cursor < dim - 1) && !stop) {
-      if (ea[cursor] == '-') {
-        int tr = cursor + 1;
-        while (ea[tr] == '-') ++tr;
-        if (tr < dim && ea[tr] == ga[cursor]) { ea[cursor] = ea[tr]; ea[tr] = '-'; ++est_cleavage; ++gen_cleavage; }
-        else stop = true;
-      } else {
-        int tr = cursor + 1;
-        while (ga[tr] == '-') ++tr;
-        if (tr < dim && ga[tr] == ea[cursor]) { ga[cursor] = ga[tr]; ga[tr] = '-'; ++est_cleavage; ++gen_cleavage; }
-        else stop = true;
-      }
-      ++cursor;
-    }
-    if (gen_cleavage >= tail->GEN_start) { tail->EST_end = est_cleavage; tail->GEN_end = gen_cleavage; }
-    else free(efl_pop_back(fact));
-    free(ea); free(ga); free(r.s0); free(r.s1); free(g); free(e);
-  }
+  endpoint_request(&q[0], tail, gen, est);
+  if (ef_dp_many(be, q, r, 1) != 0) { fprintf(stderr, "* FATAL alignment backend failed\n"); abort(); }
+  endpoint_tail_apply(fact, tail, &r[0]);
+  endpoint_release(&q[0], &r[0]);
   return fact;
 }
 
@@ -466,32 +490,42 @@ static unsigned max_edit_for_exon(size_t exon_length) {                 /* :1828
   return (unsigned)(c > 1.0 ? c : 1.0);
 }
 
-/* clean_noisy_exons (:1842-1898) */
+/* clean_noisy_exons (:1842-1898): the banded edit distances of the exons do not depend on each
+ * other, so they are requested together */
 ef_list* ef_clean_noisy_exons(ef_list* fact, const char* gen, const char* est, bool only_internals, ef_backend* be) {
   const size_t size = efl_size(fact);
   int* idx = (int*)malloc((size + 1) * sizeof(int));
-  int n = 0;
+  ef_dp_req* rq = (ef_dp_req*)malloc((size + 1) * sizeof(ef_dp_req));
+  ef_dp_res* rs = (ef_dp_res*)malloc((size + 1) * sizeof(ef_dp_res));
+  int* slot = (int*)malloc((size + 1) * sizeof(int));        /* request of each visited exon, -1 = none */
+  size_t nrq = 0, nvis = 0;
   int index = only_internals ? 2 : 1;
+  const int first_index = index;
   const int last = only_internals ? (int)(size - 1) : (int)size;
   ef_iter it = efl_begin(fact);
   if (only_internals) efi_next(&it);
   while (efi_has_next(&it) && index <= last) {
     const ef_factor* x = (const ef_factor*)efi_next(&it);
     const unsigned max_err = max_edit_for_exon((size_t)(x->GEN_end - x->GEN_start + 1));
-    bool ok = false;
+    slot[nvis] = -1;
     if (x->GEN_start <= x->GEN_end) {
       char* g = ef_real_substring(x->GEN_start, x->GEN_end - x->GEN_start + 1, gen);
       char* e = ef_real_substring(x->EST_start, x->EST_end - x->EST_start + 1, est);
-      ef_dp_res r;
-      run_dp(be, EF_DP_KBAND, g, strlen(g), e, strlen(e), max_err, 0, 0, 0, &r);
-      ok = r.v[0] != 0;
-      free(g); free(e);
+      const ef_dp_req q = { EF_DP_KBAND, g, strlen(g), e, strlen(e), max_err, 0, 0, 0 };
+      slot[nvis] = (int)nrq;
+      rq[nrq++] = q;
     }
-    if (!ok) idx[n++] = index;
-    ++index;
+    ++nvis; ++index;
   }
+  if (ef_dp_many(be, rq, rs, nrq) != 0) { fprintf(stderr, "* FATAL dynamic-programming backend failed (K-band)\n"); abort(); }
+  int n = 0;
+  for (size_t v = 0; v < nvis; ++v) {
+    const bool ok = slot[v] >= 0 && rs[slot[v]].v[0] != 0;
+    if (!ok) idx[n++] = first_index + (int)v;
+  }
+  for (size_t k = 0; k < nrq; ++k) { free((char*)rq[k].a); free((char*)rq[k].b); }
   fact = keep_best_run(fact, idx, n);
-  free(idx);
+  free(idx); free(rq); free(rs); free(slot);
   return fact;
 }
 

@@ -28,6 +28,18 @@ static void dp(ef_backend* be, int kind, const char* a, size_t la, const char* b
   if (be->dp(be->self, &rq, r) != 0) { fprintf(stderr, "* FATAL dynamic-programming backend failed (kind %d)\n", kind); abort(); }
 }
 
+/* compute_edit_distance (src/compute-alignments.c:240-249) as a request: false when the strings are
+ * equal (distance 0 without a dynamic program) */
+static bool ed_request(ef_dp_req* q, const char* a, size_t la, const char* b, size_t lb) {
+  if (la == lb && strncmp(a, b, la) == 0) return false;
+  const ef_dp_req r = { EF_DP_ED, a, la, b, lb, 0, 0, 0, 0 };
+  *q = r;
+  return true;
+}
+static void dp_many(ef_backend* be, const ef_dp_req* q, ef_dp_res* r, size_t n) {
+  if (ef_dp_many(be, q, r, n) != 0) { fprintf(stderr, "* FATAL dynamic-programming backend failed\n"); abort(); }
+}
+
 /* valid bytes after t[len] (0..2) when t points into the NUL-terminated string s */
 static uint32_t tail_of(const char* s, const char* t, size_t len) {
   const size_t total = ef_genomic_len(s), end = (size_t)(t - s) + len;
@@ -95,22 +107,24 @@ static void recover_affixes(const ef_seq* gen, ef_est* e, ef_backend* be) {
   ef_iter it = efl_begin(e->factorizations);
   while (efi_has_next(&it)) {
     ef_list* f = (ef_list*)efi_next(&it);
+    /* the lost prefix and the lost suffix do not depend on each other: one request pair */
+    ef_dp_req q[2]; ef_dp_res r[2]; size_t nq = 0;
+    int sp = -1, ss = -1;
+    char *ef = NULL, *gf = NULL;
     ef_factor* ff = (ef_factor*)efl_head(f);
     if (ff->EST_start > 0 && ff->GEN_start > 0) {
       const size_t flen = (size_t)(ff->EST_start < ff->GEN_start ? ff->EST_start : ff->GEN_start);
       const int cap = (int)((1.0 + MAX_ERROR_RATE) * flen);
       const size_t elen = (size_t)(ff->EST_start < cap ? ff->EST_start : cap);
       const size_t glen = (size_t)(ff->GEN_start < cap ? ff->GEN_start : cap);
-      char* ef = (char*)malloc(elen + 1); char* gf = (char*)malloc(glen + 1);
+      ef = (char*)malloc(elen + 1); gf = (char*)malloc(glen + 1);
       for (size_t i = 0; i < elen; ++i) ef[i] = E[ff->EST_start - 1 - i];
       for (size_t i = 0; i < glen; ++i) gf[i] = G[ff->GEN_start - 1 - i];
       ef[elen] = gf[glen] = '\0';
       if (ef[0] != gf[0]) {
-        ef_dp_res r;
-        dp(be, EF_DP_AFFIX, ef, elen, gf, glen, 0, 0, 0, 0, &r);
-        if (r.v[0]) { ff->EST_start -= r.v[1]; ff->GEN_start -= r.v[2]; }
+        const ef_dp_req x = { EF_DP_AFFIX, ef, elen, gf, glen, 0, 0, 0, 0 };
+        sp = (int)nq; q[nq++] = x;
       }
-      free(ef); free(gf);
     }
     ef_factor* fl = (ef_factor*)efl_tail(f);
     if ((tote - (size_t)fl->EST_end) > 1 && (totg - (size_t)fl->GEN_end) > 1) {
@@ -118,14 +132,17 @@ static void recover_affixes(const ef_seq* gen, ef_est* e, ef_backend* be) {
       /* `(int)(1.0+_MAX_ERROR_RATE_)*flen` in the reference: the cast binds first => 1*flen */
       const size_t elen = zmin(tote - fl->EST_end - 1, (size_t)((int)(1.0 + MAX_ERROR_RATE)) * flen);
       const size_t glen = zmin(totg - fl->GEN_end - 1, (size_t)((int)(1.0 + MAX_ERROR_RATE)) * flen);
-      const char* ef = E + fl->EST_end;          /* starts ON the last exon character (:1239,1242) */
-      const char* gf = G + fl->GEN_end;
-      if (ef[0] != gf[0]) {
-        ef_dp_res r;
-        dp(be, EF_DP_AFFIX, ef, elen, gf, glen, 0, 0, 0, 0, &r);
-        if (r.v[0]) { fl->EST_end += r.v[1]; fl->GEN_end += r.v[2]; }
+      const char* es = E + fl->EST_end;          /* starts ON the last exon character (:1239,1242) */
+      const char* gs = G + fl->GEN_end;
+      if (es[0] != gs[0]) {
+        const ef_dp_req x = { EF_DP_AFFIX, es, elen, gs, glen, 0, 0, 0, 0 };
+        ss = (int)nq; q[nq++] = x;
       }
     }
+    dp_many(be, q, r, nq);
+    if (sp >= 0 && r[sp].v[0]) { ff->EST_start -= r[sp].v[1]; ff->GEN_start -= r[sp].v[2]; }
+    if (ss >= 0 && r[ss].v[0]) { fl->EST_end += r[ss].v[1]; fl->GEN_end += r[ss].v[2]; }
+    free(ef); free(gf);
   }
 }
 
@@ -138,7 +155,6 @@ static bool analyze_small_exon(ef_factor** pprev, ef_factor** pcurr, ef_factor* 
   const size_t elen = (size_t)(curr->EST_end + 1 - curr->EST_start);
   const size_t glen = (size_t)(curr->GEN_end + 1 - curr->GEN_start);
   if (elen > UB_MED_EXON) return false;
-  const size_t orig_ed = ef_compute_edit_distance(be, E + curr->EST_start, elen, G + curr->GEN_start, glen);
   const int estart_i = prev->EST_start + 1 > prev->EST_end + 1 - AFFIXES_LENGTH ? prev->EST_start + 1 : prev->EST_end + 1 - AFFIXES_LENGTH;
   const size_t estart = (size_t)estart_i;
   const size_t eend = zmin((size_t)next->EST_end, (size_t)(next->EST_start + AFFIXES_LENGTH));
@@ -149,10 +165,18 @@ static bool analyze_small_exon(ef_factor** pprev, ef_factor** pcurr, ef_factor* 
   const size_t gend = zmin((size_t)next->GEN_end, (size_t)(next->GEN_start + AFFIXES_LENGTH));
   const size_t gpreflen = prev->GEN_end + 1 - gstart, gsufflen = gend - next->GEN_start, allglen = gend - gstart;
   const char* allgfact = G + gstart;
-  const size_t ed_pref = ef_compute_edit_distance(be, allefact, epreflen, allgfact, gpreflen);
+  /* three independent edit distances (:990,1012,1017), requested together */
+  ef_dp_req q3[3]; ef_dp_res r3[3]; size_t n3 = 0;
+  int s_orig = -1, s_pref = -1, s_suff = -1;
+  if (ed_request(&q3[n3], E + curr->EST_start, elen, G + curr->GEN_start, glen)) s_orig = (int)n3++;
+  if (ed_request(&q3[n3], allefact, epreflen, allgfact, gpreflen)) s_pref = (int)n3++;
   /* the reference takes the "suffix" BEFORE the window start (allefact - esufflen, :1017-1018) */
-  const size_t ed_suff = (estart >= esufflen && gstart >= gsufflen)
-      ? ef_compute_edit_distance(be, allefact - esufflen, esufflen, allgfact - gsufflen, gsufflen) : 0;
+  if (estart >= esufflen && gstart >= gsufflen &&
+      ed_request(&q3[n3], allefact - esufflen, esufflen, allgfact - gsufflen, gsufflen)) s_suff = (int)n3++;
+  dp_many(be, q3, r3, n3);
+  const size_t orig_ed = s_orig >= 0 ? (size_t)(uint32_t)r3[s_orig].v[0] : 0;
+  const size_t ed_pref = s_pref >= 0 ? (size_t)(uint32_t)r3[s_pref].v[0] : 0;
+  const size_t ed_suff = s_suff >= 0 ? (size_t)(uint32_t)r3[s_suff].v[0] : 0;
   ef_dp_res r;
   const uint32_t max_errs = (uint32_t)(orig_ed + ed_pref + ed_suff);
   dp(be, EF_DP_BORDERS, allefact, allelen, allgfact, allglen, 0, (uint32_t)allelen, max_errs, tail_of(G, allgfact, allglen), &r);
@@ -228,11 +252,17 @@ static void small_exon_at_prefix(ef_factor* p1, ef_iter* it, const ef_seq* gen, 
   const size_t eplen = zmin(zmin((size_t)p1->EST_start, (size_t)p1->GEN_start), 2 * UB_SMALL_EXON);
   const char* epfact = E + p1->EST_start - eplen;
   const size_t e1plen = zmin(zmin(e1len, g1len), UB_SMALL_EXON);
-  ef_dp_res r;
-  dp(be, EF_DP_LCF, G, (size_t)p1->GEN_start, epfact, eplen, 0, 0, 0, 0, &r);
+  /* the common factor and the edit distance of the exon prefix (needed only when the factor is long
+   * enough, :546) do not depend on each other: requested together */
+  ef_dp_req q2[2]; ef_dp_res r2[2]; size_t n2 = 1;
+  { const ef_dp_req x = { EF_DP_LCF, G, (size_t)p1->GEN_start, epfact, eplen, 0, 0, 0, 0 }; q2[0] = x; }
+  const bool need_ed = ed_request(&q2[1], E + p1->EST_start, e1plen, G + p1->GEN_start, e1plen);
+  if (need_ed) n2 = 2;
+  dp_many(be, q2, r2, n2);
+  ef_dp_res r = r2[0];
   const size_t cflen = (size_t)r.v[0], pg = (size_t)r.v[1], pe = (size_t)r.v[2];
   if (cflen < LB_SMALL_EXON) return;
-  const unsigned edp = ef_compute_edit_distance(be, E + p1->EST_start, e1plen, G + p1->GEN_start, e1plen);
+  const unsigned edp = need_ed ? (unsigned)r2[1].v[0] : 0u;
   /* `pe` is an offset inside the discarded prefix but the reference uses it as an absolute EST
    * coordinate from here on (:551-603); reproduced as is */
   const size_t allelen = zmin((size_t)(p1->EST_end + 1), (size_t)(p1->EST_start + UB_SMALL_EXON)) - pe;
@@ -266,18 +296,26 @@ static void small_exon_between(ef_factor* p1, ef_factor* p2, ef_iter* it, const 
   const size_t e2pstart = (size_t)p2->EST_start, g2pstart = (size_t)p2->GEN_start;
   char* e2p = ef_real_substring((int)e2pstart, (int)e2plen, E);
   char* g2p = ef_real_substring((int)g2pstart, (int)g2plen, G);
-  const size_t sed = ef_compute_edit_distance(be, e1s, e1slen, g1s, g1slen);
-  const size_t ped = ef_compute_edit_distance(be, e2p, e2plen, g2p, g2plen);
+  /* both edit distances and, for the side(s) that are not identical, the common factors the
+   * reference asks for afterwards (:690-718): independent of each other, requested together */
+  ef_dp_req q4[4]; ef_dp_res r4[4]; size_t n4 = 0;
+  int s_sed = -1, s_ped = -1, s_l1 = -1, s_l2 = -1;
+  if (ed_request(&q4[n4], e1s, e1slen, g1s, g1slen)) s_sed = (int)n4++;
+  if (ed_request(&q4[n4], e2p, e2plen, g2p, g2plen)) s_ped = (int)n4++;
+  if (s_sed >= 0) { const ef_dp_req x = { EF_DP_LCF, e1s, e1slen, g1s, g1slen, 0, 0, 0, 0 }; s_l1 = (int)n4; q4[n4++] = x; }
+  if (s_ped >= 0) { const ef_dp_req x = { EF_DP_LCF, e2p, e2plen, g2p, g2plen, 0, 0, 0, 0 }; s_l2 = (int)n4; q4[n4++] = x; }
+  dp_many(be, q4, r4, n4);
+  const size_t sed = s_sed >= 0 ? (size_t)(uint32_t)r4[s_sed].v[0] : 0;
+  const size_t ped = s_ped >= 0 ? (size_t)(uint32_t)r4[s_ped].v[0] : 0;
   bool go = false;
   const int orig_class = ef_classify_intron(gen, p1->GEN_end + 1, p2->GEN_start - 1);
   if (sed + ped > MAX_ERRORS_AS_SMALL) go = true;
   if (orig_class == INTRON_ND) go = true;
   if (go) {
     size_t e1socc = 0, g1socc = 0, f1slen = e1slen;
-    ef_dp_res r;
-    if (sed > 0) { dp(be, EF_DP_LCF, e1s, e1slen, g1s, g1slen, 0, 0, 0, 0, &r); f1slen = (size_t)r.v[0]; e1socc = (size_t)r.v[1]; g1socc = (size_t)r.v[2]; }
+    if (sed > 0) { const ef_dp_res r = r4[s_l1]; f1slen = (size_t)r.v[0]; e1socc = (size_t)r.v[1]; g1socc = (size_t)r.v[2]; }
     size_t e2pocc = 0, g2pocc = 0, f2plen = e2plen;
-    if (ped > 0) { dp(be, EF_DP_LCF, e2p, e2plen, g2p, g2plen, 0, 0, 0, 0, &r); f2plen = (size_t)r.v[0]; e2pocc = (size_t)r.v[1]; g2pocc = (size_t)r.v[2]; }
+    if (ped > 0) { const ef_dp_res r = r4[s_l2]; f2plen = (size_t)r.v[0]; e2pocc = (size_t)r.v[1]; g2pocc = (size_t)r.v[2]; }
     if (f1slen == e1slen && e2pocc > 0) {
       size_t nf = f1slen + 1;
       while ((nf - f1slen) < e2pocc && E[e1sstart + e1socc + f1slen] == G[g2pstart + nf - f1slen]) ++nf;

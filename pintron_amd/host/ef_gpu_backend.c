@@ -102,6 +102,25 @@ static int direct_dp(void* self, const ef_dp_req* q, ef_dp_res* res) {
   return ef_decode_result(q->kind, &r, d->strings, res);
 }
 
+static int direct_dp_many(void* self, const ef_dp_req* reqs, ef_dp_res* res, size_t n) {
+  direct_be* d = (direct_be*)self;
+  if (n == 0) return 0;
+  ef_jobbuf_reset(&d->jb);
+  size_t need = 16;
+  for (size_t k = 0; k < n; ++k) { ef_jobbuf_add(&d->jb, &reqs[k], d->gen, d->gen_len); need += 2 * (reqs[k].la + reqs[k].lb + 1); }
+  if (need > d->strings_cap) { d->strings_cap = need * 2; d->strings = (char*)realloc(d->strings, d->strings_cap); }
+  pgpu_dp_result* r = (pgpu_dp_result*)malloc(n * sizeof(pgpu_dp_result));
+  size_t used = 0;
+  int rc = pgpu_dp_batch(d->ctx, d->idx, d->jb.jobs, n, d->jb.arena, d->jb.arena_len, r, d->strings, d->strings_cap, &used);
+  if (rc != PGPU_OK) fprintf(stderr, "* FATAL pgpu_dp_batch: %s\n", pgpu_last_error(d->ctx));
+  for (size_t k = 0; k < n && rc == PGPU_OK; ++k) {
+    if (r[k].status != PGPU_OK) { fprintf(stderr, "* FATAL DP job of kind %d and size %zu x %zu exceeds the device limits\n", reqs[k].kind, reqs[k].la, reqs[k].lb); rc = -1; }
+    else rc = ef_decode_result(reqs[k].kind, &r[k], d->strings, &res[k]);
+  }
+  free(r);
+  return rc == PGPU_OK ? 0 : -1;
+}
+
 ef_backend* ef_gpu_open(const ef_seq* gen) {
   direct_be* d = (direct_be*)calloc(1, sizeof(direct_be));
   if (pgpu_init(ef_gpu_device_from_env(), &d->ctx) != PGPU_OK) { free(d); return NULL; }
@@ -113,7 +132,7 @@ ef_backend* ef_gpu_open(const ef_seq* gen) {
   }
   ef_jobbuf_init(&d->jb);
   ef_backend* be = (ef_backend*)calloc(1, sizeof(ef_backend));
-  be->self = d; be->pairings = direct_pairings; be->dp = direct_dp;
+  be->self = d; be->pairings = direct_pairings; be->dp = direct_dp; be->dp_many = direct_dp_many;
   return be;
 }
 

@@ -13,9 +13,6 @@ typedef struct {
   int new_acceptor_factor_left, new_donor_right_on_gen, new_acceptor_left_on_gen;
 } gap_aln;
 
-static uint32_t edist(ef_backend* be, const char* a, const char* b) {
-  return ef_edit_distance(be, a, strlen(a), b, strlen(b));
-}
 
 /* ---- Burset frequencies ----------------------------------------------------------------------- */
 /* getBursetFrequency (src/refine-intron.c:376-556) as data: index = donor[0],donor[1],acceptor[0],
@@ -236,18 +233,45 @@ static bool shift_generic(const char* est, const char* gen, const gap_aln* al, b
   }
   free(ext_est); free(ext_gen);
 
+  /* Every edit distance the decision loops below can ask for is a function of strings that are
+   * fixed by now (<= 2 + 4 pairs of at most a few dozen characters): they are requested together
+   * and the loops read the answers, instead of suspending the EST up to six times. */
+  uint32_t ed_prev[CYCLES], ed_pair[CYCLES][CYCLES];
+  {
+    ef_dp_req q[CYCLES + CYCLES * CYCLES]; ef_dp_res rs[CYCLES + CYCLES * CYCLES]; size_t nq = 0;
+    int sp[CYCLES], sx[CYCLES][CYCLES];
+    for (int i = 0; i < CYCLES; ++i) {
+      sp[i] = -1;
+      if (variant1 && cut_factor[i] != NULL) {
+        const ef_dp_req x = { EF_DP_ED, cut_factor[i], strlen(cut_factor[i]), prev_match[i], strlen(prev_match[i]), 0, 0, 0, 0 };
+        sp[i] = (int)nq; q[nq++] = x;
+      }
+      for (int j = 0; j < CYCLES; ++j) {
+        sx[i][j] = -1;
+        const char *a = NULL, *b = NULL;
+        if (ext_cut[i] != NULL && ext_match[j] != NULL) { a = ext_cut[i]; b = ext_match[j]; }
+        else if (cut_factor[i] != NULL && match_str[j] != NULL) { a = cut_factor[i]; b = match_str[j]; }
+        if (a) { const ef_dp_req x = { EF_DP_ED, a, strlen(a), b, strlen(b), 0, 0, 0, 0 }; sx[i][j] = (int)nq; q[nq++] = x; }
+      }
+    }
+    if (ef_dp_many(be, q, rs, nq) != 0) { fprintf(stderr, "* FATAL edit-distance backend failed\n"); abort(); }
+    for (int i = 0; i < CYCLES; ++i) {
+      ed_prev[i] = sp[i] >= 0 ? (uint32_t)rs[sp[i]].v[0] : 0;
+      for (int j = 0; j < CYCLES; ++j) ed_pair[i][j] = sx[i][j] >= 0 ? (uint32_t)rs[sx[i][j]].v[0] : 0;
+    }
+  }
   bool stop = false;
   if (variant1) {
     unsigned error = 1000, edit_prev = 1000;
     for (int i = 0; i < CYCLES && !stop; ++i) {
       for (int j = 0; j < CYCLES && !stop; ++j) {
         if (cut_factor[i] != NULL && match_str[j] != NULL) {
-          edit_prev = edist(be, cut_factor[i], prev_match[i]);
+          edit_prev = ed_prev[i];
           if (edit_prev <= 5) {
             if (ext_cut[i] != NULL && ext_match[j] != NULL)
-              error = edist(be, ext_cut[i], ext_match[j]) - edit_prev - (unsigned)ext_error;
+              error = ed_pair[i][j] - edit_prev - (unsigned)ext_error;
             else
-              error = edist(be, cut_factor[i], match_str[j]) - edit_prev;
+              error = ed_pair[i][j] - edit_prev;
           }
         }
         if (error <= 1) {
@@ -268,8 +292,8 @@ static bool shift_generic(const char* est, const char* gen, const gap_aln* al, b
     int error = 1000, edit = 1000;
     for (int i = 0; i < CYCLES && !stop; ++i) {
       for (int j = 0; j < CYCLES && !stop; ++j) {
-        if (ext_cut[i] != NULL && ext_match[j] != NULL) edit = (int)edist(be, ext_cut[i], ext_match[j]) - ext_error;
-        else if (cut_factor[i] != NULL && match_str[j] != NULL) edit = (int)edist(be, cut_factor[i], match_str[j]);
+        if (ext_cut[i] != NULL && ext_match[j] != NULL) edit = (int)ed_pair[i][j] - ext_error;
+        else if (cut_factor[i] != NULL && match_str[j] != NULL) edit = (int)ed_pair[i][j];
         else edit = 1000;
         if (edit < error) {
           error = edit;

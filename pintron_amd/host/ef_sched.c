@@ -89,7 +89,8 @@ typedef struct fiber {
   size_t cur_entry;          /* entry of the prepared list being factorized */
   int lane;
   /* pending request */
-  ef_dp_req req; ef_dp_res* res; int rc;
+  const ef_dp_req* reqs; ef_dp_res* ress; size_t nreq;   /* nreq independent DP requests */
+  ef_dp_req req1; int rc;
   const char* pat; size_t pat_len; unsigned pat_L; double pat_rate; ef_triple** pat_out; size_t* pat_n;
   ef_backend be;
   struct fiber* pool_next;   /* free fibres (struct + stack) are kept for the next EST */
@@ -204,11 +205,18 @@ static void kstat_add(ef_sched_stats* st, const ef_kernel_stat* k) {
 }
 
 /* ---- fibre side ---------------------------------------------------------------------------------- */
-static int fiber_dp(void* self, const ef_dp_req* q, ef_dp_res* res) {
+static int fiber_dp_many(void* self, const ef_dp_req* reqs, ef_dp_res* res, size_t n) {
   fiber* f = (fiber*)self;
-  f->req = *q; f->res = res; f->state = F_WAIT_DP;
+  if (n == 0) return 0;
+  f->reqs = reqs; f->ress = res; f->nreq = n; f->state = F_WAIT_DP;
   ctx_switch(&f->ctx, &f->w->sched);
   return f->rc;
+}
+
+static int fiber_dp(void* self, const ef_dp_req* q, ef_dp_res* res) {
+  fiber* f = (fiber*)self;
+  f->req1 = *q;
+  return fiber_dp_many(self, &f->req1, res, 1);
 }
 
 static int fiber_pairings(void* self, const char* pattern, size_t m, unsigned L, double rate, ef_triple** out, size_t* n) {
@@ -303,7 +311,7 @@ static bool start_fiber(worker* w, int li) {
   if (f) { char* st = f->stack; memset(f, 0, sizeof(fiber)); f->stack = st; }
   else { f = (fiber*)calloc(1, sizeof(fiber)); f->stack = (char*)malloc(sh->stack_size); }
   f->w = w; f->unit = u; f->state = F_RUNNABLE; f->lane = li;
-  f->be.self = f; f->be.pairings = fiber_pairings; f->be.dp = fiber_dp;
+  f->be.self = f; f->be.pairings = fiber_pairings; f->be.dp = fiber_dp; f->be.dp_many = fiber_dp_many;
   ctx_make(&f->ctx, f->stack, sh->stack_size, fiber_main, f);
   ln->fibers[ln->n_fibers++] = f;
   return true;
@@ -447,13 +455,13 @@ static int launch_dp(worker* w, lane* ln) {
   for (size_t i = 0; i < ln->n_fibers; ++i) {
     fiber* f = ln->fibers[i];
     if (f->state != F_WAIT_DP) continue;
-    ef_jobbuf_add(&ln->jb, &f->req, gen, sh->gen_len);
+    for (size_t k = 0; k < f->nreq; ++k) ef_jobbuf_add(&ln->jb, &f->reqs[k], gen, sh->gen_len);
     ln->inflight[ln->n_inflight++] = f;
   }
   if (ln->n_inflight == 0) return 0;
   dp_request* rq = &ln->rq;
   memset(rq, 0, sizeof *rq);
-  rq->jobs = ln->jb.jobs; rq->n = ln->n_inflight; rq->arena = ln->jb.arena; rq->arena_len = ln->jb.arena_len;
+  rq->jobs = ln->jb.jobs; rq->n = ln->jb.n; rq->arena = ln->jb.arena; rq->arena_len = ln->jb.arena_len;
   pthread_mutex_lock(&sv->mu);
   if (sv->tail) sv->tail->next = rq; else sv->head = rq;
   sv->tail = rq;
@@ -474,10 +482,17 @@ static int collect_dp(worker* w, lane* ln) {
   ln->posted = false;
   const int rc = rq->rc;
   if (rc == PGPU_OK) {
+    size_t j = rq->base;
     for (size_t i = 0; i < ln->n_inflight; ++i) {
       fiber* f = ln->inflight[i];
-      f->rc = ef_decode_result(f->req.kind, &rq->batch->results[rq->base + i], rq->batch->strings, f->res);
-      if (f->rc != 0) fprintf(stderr, "* FATAL DP job of kind %d (%zu x %zu) exceeds the device limits\n", f->req.kind, f->req.la, f->req.lb);
+      f->rc = 0;
+      for (size_t k = 0; k < f->nreq; ++k, ++j) {
+        const int drc = ef_decode_result(f->reqs[k].kind, &rq->batch->results[j], rq->batch->strings, &f->ress[k]);
+        if (drc != 0) {
+          fprintf(stderr, "* FATAL DP job of kind %d (%zu x %zu) exceeds the device limits\n", f->reqs[k].kind, f->reqs[k].la, f->reqs[k].lb);
+          f->rc = drc;
+        }
+      }
       f->state = F_RUNNABLE;
     }
   }

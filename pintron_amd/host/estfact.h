@@ -161,7 +161,18 @@ typedef struct ef_backend {
                   ef_triple** out, size_t* n);
   /* one dynamic program; returns 0 or aborts the EST (never a CPU fallback in the product) */
   int (*dp)(void* self, const ef_dp_req* req, ef_dp_res* res);
+  /* n dynamic programs that do not depend on each other, answered together (one suspension of the
+   * EST instead of n); may be NULL, then ef_dp_many() asks one by one */
+  int (*dp_many)(void* self, const ef_dp_req* reqs, ef_dp_res* res, size_t n);
 } ef_backend;
+
+static inline int ef_dp_many(ef_backend* be, const ef_dp_req* reqs, ef_dp_res* res, size_t n) {
+  if (n == 0) return 0;
+  memset(res, 0, n * sizeof(ef_dp_res));
+  if (be->dp_many) return be->dp_many(be->self, reqs, res, n);
+  for (size_t k = 0; k < n; ++k) { const int rc = be->dp(be->self, &reqs[k], &res[k]); if (rc != 0) return rc; }
+  return 0;
+}
 
 /* ---- factorizations (include/types.h:160-180) ------------------------------------------------ */
 typedef struct { int EST_start, EST_end, GEN_start, GEN_end; } ef_factor;   /* 0-based inclusive */
