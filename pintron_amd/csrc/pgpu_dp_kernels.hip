@@ -568,6 +568,117 @@ void align_traceback_kernel(const DevJob* __restrict__ jobs, int njobs,
   res->str[1] = job.str_off + cap + pos;
 }
 
+// TracebackAlignment (src/compute-alignments.c:149-207), one WAVE per job.
+// The walk from (n,m) back to the border is a chain of dependent direction look-ups; done by one
+// thread against HBM/L2 every step costs a memory round trip (~250 ns).  Here the wave copies a
+// window of direction entries (a run of consecutive sweep steps, coalesced 16 B per lane) into
+// LDS and walks it there; the walk state is wave-uniform, so it lives in scalar registers and a
+// step is one LDS read plus a few scalar instructions.  The walk only records the 2-bit
+// direction per step; the gapped strings are then written by all 64 lanes at once: the character
+// a step consumes is found from a prefix count (ballot + popcount) of the steps before it.
+constexpr int TB_WIN_BYTES = 8192;    // direction window per wave
+constexpr int TB_PATH = 1024;         // path steps buffered before the lanes write them out
+
+__device__ __forceinline__ void tb_flush(const uint8_t* path, uint32_t np, const uint8_t* a, const uint8_t* b,
+                                         uint32_t i0, uint32_t j0, uint32_t pos0, uint8_t* ea, uint8_t* ga,
+                                         uint32_t lane) {
+  uint32_t ca = 0, cb = 0;             // characters of a / b consumed by the steps before this group
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  for (uint32_t base = 0; base < np; base += 64) {
+    const uint32_t idx = base + lane;
+    const bool valid = idx < np;
+    const uint32_t d = valid ? path[idx] : 3u;
+    const bool ua = valid && d != 2u, ub = valid && d != 1u;       // step consumes a[..] / b[..]
+    const unsigned long long ma = __ballot(ua), mb = __ballot(ub);
+    if (valid) {
+      const uint32_t ia = i0 - 1u - (ca + (uint32_t)__popcll(ma & lt));
+      const uint32_t ib = j0 - 1u - (cb + (uint32_t)__popcll(mb & lt));
+      ea[pos0 - 1u - idx] = ua ? a[ia] : (uint8_t)'-';
+      ga[pos0 - 1u - idx] = ub ? b[ib] : (uint8_t)'-';
+    }
+    ca += (uint32_t)__popcll(ma); cb += (uint32_t)__popcll(mb);
+  }
+}
+
+__global__ __launch_bounds__(256)
+void align_traceback_wave_kernel(const DevJob* __restrict__ jobs, int njobs,
+                                 DevResult* __restrict__ results, const uint8_t* __restrict__ ws,
+                                 uint8_t* __restrict__ strs) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_win[4][TB_WIN_BYTES];
+  __shared__ uint8_t s_path[4][TB_PATH];
+  const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+  const int t = blockIdx.x * 4 + (int)wv;
+  if (t >= njobs) return;                                  // the whole wave leaves
+  const DevJob job = jobs[t];
+  DevResult* res = &results[job.out_idx];
+  const uint32_t n = job.la, m = job.lb, cap = n + m + 1;
+  uint8_t* ea = strs + job.str_off;
+  uint8_t* ga = ea + cap;
+  if (res->v[5] == 1) {                  // identity alignment
+    for (uint32_t i = lane; i < n; i += 64) { ea[i] = job.a[i]; ga[i] = job.b[i]; }
+    if (lane == 0) {
+      ea[n] = 0; ga[n] = 0;
+      res->v[1] = (int32_t)n;
+      res->str[0] = job.str_off; res->str[1] = job.str_off + cap;
+      res->v[5] = 0;
+    }
+    return;
+  }
+  uint8_t* win = s_win[wv];
+  uint8_t* path = s_path[wv];
+  const uint32_t R = job.r_class, EB = R <= 4 ? 1u : R / 4;
+  const uint32_t lgR = 31u - (uint32_t)__builtin_clz(R);   // R is a power of two
+  const uint32_t WS = TB_WIN_BYTES / (64u * EB);           // sweep steps per window
+  const uint8_t* dirs = ws + job.ws_off;
+  uint32_t i = n, j = m, k = 0, np = 0;
+  uint32_t i0 = n, j0 = m, pos = cap - 1;
+  if (lane == 0) { ea[pos] = 0; ga[pos] = 0; }
+  uint32_t s_lo = 1u, s_hi = 0u;                           // empty window
+  while (i > 0 && j > 0) {
+    const uint32_t l = (i - 1) >> lgR, r = (i - 1) & (R - 1), s = (j - 1) + l;
+    if (s < s_lo || s > s_hi) {                            // bring in the steps (s - WS, s]
+      s_hi = s; s_lo = s + 1 >= WS ? s + 1 - WS : 0;
+      const uint32_t bytes = (s_hi - s_lo + 1) * 64u * EB;
+      const uint8_t* src = dirs + (size_t)s_lo * 64u * EB;
+      for (uint32_t off = lane * 16u; off < bytes; off += 64u * 16u)
+        *reinterpret_cast<uint4*>(win + off) = *reinterpret_cast<const uint4*>(src + off);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    uint32_t d = (win[((s - s_lo) * 64u + l) * EB + (r >> 2)] >> (2u * (r & 3u))) & 3u;
+    d = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);  // the walk is wave-uniform: keep it scalar
+    if (lane == 0) path[np] = (uint8_t)d;
+    ++np;
+    if (d == 0)      { --i; --j; }
+    else if (d == 1) { --i; }
+    else             { --j; }
+    if (np == TB_PATH) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      tb_flush(path, np, job.a, job.b, i0, j0, pos, ea, ga, lane);
+      pos -= np; k += np; np = 0; i0 = i; j0 = j;
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  tb_flush(path, np, job.a, job.b, i0, j0, pos, ea, ga, lane);
+  pos -= np; k += np;
+  // what is left of one string is aligned to gaps (:193-206): a[..i) over '-', then '-' over b[..j)
+  for (uint32_t q = lane; q < i; q += 64) { ea[pos - 1 - q] = job.a[i - 1 - q]; ga[pos - 1 - q] = '-'; }
+  pos -= i; k += i;
+  for (uint32_t q = lane; q < j; q += 64) { ea[pos - 1 - q] = '-'; ga[pos - 1 - q] = job.b[j - 1 - q]; }
+  pos -= j; k += j;
+  if (lane == 0) {
+    res->v[1] = (int32_t)k;
+    res->str[0] = job.str_off + pos;
+    res->str[1] = job.str_off + cap + pos;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // 3-state gap alignment: ComputeGapAlignMatrix with only_one_align (src/refine-intron.c:623-824)
 // ---------------------------------------------------------------------------------------------
@@ -855,7 +966,7 @@ void launch_lev(int family, int R, const DevJob* jobs, int njobs, DevResult* res
 void launch_align_traceback(const DevJob* jobs, int njobs, DevResult* res, const uint8_t* ws,
                             uint8_t* strs, hipStream_t st) {
   if (njobs <= 0) return;
-  hipLaunchKernelGGL(align_traceback_kernel, dim3((njobs + 63) / 64), dim3(64), 0, st, jobs, njobs, res, ws, strs);
+  hipLaunchKernelGGL(align_traceback_wave_kernel, dim3((njobs + 3) / 4), dim3(256), 0, st, jobs, njobs, res, ws, strs);
 }
 
 void launch_gap(int R, const DevJob* jobs, int njobs, DevResult* res, uint8_t* ws, hipStream_t st) {

@@ -651,7 +651,7 @@ ef_session* ef_session_open(int argc, char** argv) {
   const size_t cores = ncpu > 16 ? 16 : (ncpu > 0 ? (size_t)ncpu : 1);
   s->nthreads = env_size("PINTRON_THREADS", cores);
   if (s->nthreads > sh->n_units) s->nthreads = sh->n_units ? sh->n_units : 1;
-  sh->max_fibers = env_size("PINTRON_FIBERS", 1536);
+  sh->max_fibers = env_size("PINTRON_FIBERS", 768);
   sh->stack_size = env_size("PINTRON_FIBER_STACK_KB", 256) * 1024;
   sh->kernel_timing = getenv("PINTRON_KERNEL_TIMING") != NULL;
   sh->gen_len = strlen(in->gen->seq);

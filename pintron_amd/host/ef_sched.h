@@ -31,7 +31,7 @@ size_t ef_session_n_ests(const ef_session* s);
 void ef_session_close(ef_session* s);
 
 /* environment: PINTRON_THREADS (workers; default min(online CPUs, 16)), PINTRON_LANES (3),
- * PINTRON_FIBERS (fibres per worker over all lanes, 1536), PINTRON_FIBER_STACK_KB (256),
+ * PINTRON_FIBERS (fibres per worker over all lanes, 768), PINTRON_FIBER_STACK_KB (256),
  * PINTRON_SERVICES (GPU service threads, 2), PINTRON_GPU_DEVICE (0), PINTRON_NO_PREFETCH,
  * PINTRON_KERNEL_TIMING, PINTRON_VERBOSE */
 int ef_run_batched(int argc, char** argv);
