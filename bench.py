@@ -51,8 +51,8 @@ def rocprof_symbol(group_name):
     m = re.match(r"(borders|affix)_coop<rows<=(\d+)>", group_name)
     if m:
         return "%s_coop_kernel<%d>" % (m.group(1), max(1, int(m.group(2)) // 256))
-    return {"lcf": "lcf_kernel", "align_traceback": "align_traceback_kernel",
-            "gap_traceback": "gap_traceback_kernel"}.get(group_name, group_name.split("+")[0] + "_kernel")
+    return {"lcf": "lcf_kernel", "align_traceback": "align_traceback_wave_kernel",
+            "gap_traceback": "gap_traceback_wave_kernel"}.get(group_name, group_name.split("+")[0] + "_kernel")
 
 
 def pmc_traffic(group_name):

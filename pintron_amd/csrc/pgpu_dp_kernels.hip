@@ -12,8 +12,9 @@
 //   * traceback directions are packed (2 bits/cell, or 5 bits/cell for the 3-plane gap DP) and
 //     stored step-major, [step][lane], so that every store instruction of the wave writes one
 //     contiguous 64*entry-byte segment of HBM;
-//   * tracebacks run in a second kernel, one THREAD per job: each is a latency-bound pointer
-//     chase, and a batch holds 10^4..10^6 of them, so they are overlapped with each other.
+//   * tracebacks run in a second kernel, one wave per job: the chain of dependent direction
+//     look-ups is walked in LDS (windows of the direction stream are staged there) with the walk
+//     state in scalar registers, and the gapped strings are written by all lanes at once.
 //
 // Integer/character work only: no MFMA.  Reference routines are cited per kernel; paths are
 // relative to the AlgoLab/PIntron tree.
@@ -526,48 +527,6 @@ void affix_coop_kernel(const DevJob* __restrict__ jobs, int njobs, DevResult* __
   }
 }
 
-// TracebackAlignment (src/compute-alignments.c:149-207), one thread per job.  Strings are
-// written back-to-front into the job's slot so no reversal pass is needed.
-__global__ __launch_bounds__(64)
-void align_traceback_kernel(const DevJob* __restrict__ jobs, int njobs,
-                            DevResult* __restrict__ results, const uint8_t* __restrict__ ws,
-                            uint8_t* __restrict__ strs) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= njobs) return;
-  const DevJob job = jobs[t];
-  DevResult* res = &results[job.out_idx];
-  const uint32_t n = job.la, m = job.lb, cap = n + m + 1;
-  uint8_t* ea = strs + job.str_off;
-  uint8_t* ga = ea + cap;
-  if (res->v[5] == 1) {                  // identity alignment
-    for (uint32_t i = 0; i < n; ++i) { ea[i] = job.a[i]; ga[i] = job.b[i]; }
-    ea[n] = 0; ga[n] = 0;
-    res->v[1] = (int32_t)n;
-    res->str[0] = job.str_off; res->str[1] = job.str_off + cap;
-    res->v[5] = 0;
-    return;
-  }
-  const uint32_t R = job.r_class, EB = R <= 4 ? 1u : R / 4;
-  const uint8_t* dirs = ws + job.ws_off;
-  uint32_t i = n, j = m, k = 0;
-  uint32_t pos = cap - 1;
-  ea[pos] = 0; ga[pos] = 0;
-  while (i > 0 && j > 0) {
-    const uint32_t l = (i - 1) / R, r = (i - 1) % R, s = (j - 1) + l;
-    const uint32_t d = (dirs[((size_t)s * 64 + l) * EB + (r >> 2)] >> (2 * (r & 3))) & 3u;
-    --pos;
-    if (d == 0)      { ea[pos] = job.a[--i]; ga[pos] = job.b[--j]; }
-    else if (d == 1) { ea[pos] = job.a[--i]; ga[pos] = '-'; }
-    else             { ea[pos] = '-';        ga[pos] = job.b[--j]; }
-    ++k;
-  }
-  while (i > 0) { --pos; ea[pos] = job.a[--i]; ga[pos] = '-'; ++k; }
-  while (j > 0) { --pos; ea[pos] = '-'; ga[pos] = job.b[--j]; ++k; }
-  res->v[1] = (int32_t)k;
-  res->str[0] = job.str_off + pos;
-  res->str[1] = job.str_off + cap + pos;
-}
-
 // TracebackAlignment (src/compute-alignments.c:149-207), one WAVE per job.
 // The walk from (n,m) back to the border is a chain of dependent direction look-ups; done by one
 // thread against HBM/L2 every step costs a memory round trip (~250 ns).  Here the wave copies a
@@ -587,8 +546,8 @@ __device__ __forceinline__ void tb_flush(const uint8_t* path, uint32_t np, const
   for (uint32_t base = 0; base < np; base += 64) {
     const uint32_t idx = base + lane;
     const bool valid = idx < np;
-    const uint32_t d = valid ? path[idx] : 3u;
-    const bool ua = valid && d != 2u, ub = valid && d != 1u;       // step consumes a[..] / b[..]
+    const uint32_t d = valid ? path[idx] : 1u;
+    const bool ua = valid && d <= 1u, ub = valid && d != 1u;       // step consumes a[..] / b[..] (2, 3: b only)
     const unsigned long long ma = __ballot(ua), mb = __ballot(ub);
     if (valid) {
       const uint32_t ia = i0 - 1u - (ca + (uint32_t)__popcll(ma & lt));
@@ -777,54 +736,94 @@ void gap_wave_kernel(const DevJob* __restrict__ jobs, int njobs, DevResult* __re
   }
 }
 
-// TracebackGapAlignment (src/refine-intron.c:828-890), one thread per job.
-__global__ __launch_bounds__(64)
-void gap_traceback_kernel(const DevJob* __restrict__ jobs, int njobs,
-                          DevResult* __restrict__ results, const uint8_t* __restrict__ ws,
-                          uint8_t* __restrict__ strs) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+// TracebackGapAlignment (src/refine-intron.c:828-890), one wave per job: same scheme as
+// align_traceback_wave_kernel (direction window in LDS, scalar walk, parallel write-out); the walk
+// additionally carries the plane (R exon -> G intron -> L exon) and notes where it jumps.
+__global__ __launch_bounds__(256)
+void gap_traceback_wave_kernel(const DevJob* __restrict__ jobs, int njobs,
+                               DevResult* __restrict__ results, const uint8_t* __restrict__ ws,
+                               uint8_t* __restrict__ strs) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_win[4][TB_WIN_BYTES];
+  __shared__ uint8_t s_path[4][TB_PATH];
+  const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+  const int t = blockIdx.x * 4 + (int)wv;
   if (t >= njobs) return;
   const DevJob job = jobs[t];
   DevResult* res = &results[job.out_idx];
   const uint32_t n = job.la, m = job.lb, cap = n + m + 1, R = job.r_class;
+  const uint32_t lgR = 31u - (uint32_t)__builtin_clz(R);
+  const uint32_t WS = TB_WIN_BYTES / (64u * R);            // 1 B per cell: an entry is R bytes
   uint8_t* ea = strs + job.str_off;
   uint8_t* ga = ea + cap;
+  uint8_t* win = s_win[wv];
+  uint8_t* path = s_path[wv];
   const uint8_t* dirs = ws + job.ws_off;
-  int plane = res->pad;
+  int plane = __builtin_amdgcn_readfirstlane(res->pad);
   int32_t factor_cut = 0, intron_start = 0, intron_end = 0;
   int32_t rev_end = -1, rev_start = -1;
-  uint32_t i = n, j = m, k = 0, pos = cap - 1;
-  ea[pos] = 0; ga[pos] = 0;
+  uint32_t i = n, j = m, k = 0, np = 0;
+  uint32_t i0 = n, j0 = m, pos = cap - 1;
+  if (lane == 0) { ea[pos] = 0; ga[pos] = 0; }
+  uint32_t s_lo = 1u, s_hi = 0u;
   while (i > 0 && j > 0) {
-    const uint32_t l = (i - 1) / R, r = (i - 1) % R, s = (j - 1) + l;
-    const uint32_t b = dirs[((size_t)s * 64 + l) * R + r];
+    const uint32_t l = (i - 1) >> lgR, r = (i - 1) & (R - 1), s = (j - 1) + l;
+    if (s < s_lo || s > s_hi) {
+      s_hi = s; s_lo = s + 1 >= WS ? s + 1 - WS : 0;
+      const uint32_t bytes = (s_hi - s_lo + 1) * 64u * R;
+      const uint8_t* src = dirs + (size_t)s_lo * 64u * R;
+      for (uint32_t off = lane * 16u; off < bytes; off += 64u * 16u)
+        *reinterpret_cast<uint4*>(win + off) = *reinterpret_cast<const uint4*>(src + off);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    uint32_t b = win[((s - s_lo) * 64u + l) * R + r];
+    b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
     // decode to the reference's direction values: 0, 1, 2, or -2 (here 3)
     uint32_t d;
     if (plane == 2) d = (b >> 3) & 3u;
     else if (plane == 1) d = ((b >> 2) & 1u) ? 3u : 2u;
     else d = b & 3u;
-    --pos;
-    if (d == 0)      { ea[pos] = job.a[--i]; ga[pos] = job.b[--j]; }
-    else if (d == 1) { ea[pos] = job.a[--i]; ga[pos] = '-'; }
+    if (lane == 0) path[np] = (uint8_t)d;
+    const uint32_t kk = k + np;                            // steps taken before this one
+    ++np;
+    if (d == 0)      { --i; --j; }
+    else if (d == 1) { --i; }
     else {
       if (d == 3) {
-        if (plane == 2) { intron_end = (int32_t)j - 1; factor_cut = (int32_t)i; rev_end = (int32_t)k; }
-        else            { intron_start = (int32_t)j - 1; rev_start = (int32_t)k; }
+        if (plane == 2) { intron_end = (int32_t)j - 1; factor_cut = (int32_t)i; rev_end = (int32_t)kk; }
+        else            { intron_start = (int32_t)j - 1; rev_start = (int32_t)kk; }
         --plane;
       }
-      ea[pos] = '-'; ga[pos] = job.b[--j];
+      --j;
     }
-    ++k;
+    if (np == TB_PATH) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      tb_flush(path, np, job.a, job.b, i0, j0, pos, ea, ga, lane);
+      pos -= np; k += np; np = 0; i0 = i; j0 = j;
+      __builtin_amdgcn_wave_barrier();
+    }
   }
-  while (i > 0) { --pos; ea[pos] = job.a[--i]; ga[pos] = '-'; ++k; }
-  while (j > 0) { --pos; ea[pos] = '-'; ga[pos] = job.b[--j]; ++k; }
-  res->v[0] = (int32_t)k;
-  res->v[1] = factor_cut; res->v[2] = intron_start; res->v[3] = intron_end;
-  res->v[4] = rev_start >= 0 ? (int32_t)k - 1 - rev_start : 0;
-  res->v[5] = rev_end >= 0 ? (int32_t)k - 1 - rev_end : 0;
-  res->pad = 0;
-  res->str[0] = job.str_off + pos;
-  res->str[1] = job.str_off + cap + pos;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  tb_flush(path, np, job.a, job.b, i0, j0, pos, ea, ga, lane);
+  pos -= np; k += np;
+  for (uint32_t q = lane; q < i; q += 64) { ea[pos - 1 - q] = job.a[i - 1 - q]; ga[pos - 1 - q] = '-'; }
+  pos -= i; k += i;
+  for (uint32_t q = lane; q < j; q += 64) { ea[pos - 1 - q] = '-'; ga[pos - 1 - q] = job.b[j - 1 - q]; }
+  pos -= j; k += j;
+  if (lane == 0) {
+    res->v[0] = (int32_t)k;
+    res->v[1] = factor_cut; res->v[2] = intron_start; res->v[3] = intron_end;
+    res->v[4] = rev_start >= 0 ? (int32_t)k - 1 - rev_start : 0;
+    res->v[5] = rev_end >= 0 ? (int32_t)k - 1 - rev_end : 0;
+    res->pad = 0;
+    res->str[0] = job.str_off + pos;
+    res->str[1] = job.str_off + cap + pos;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -985,7 +984,7 @@ void launch_gap(int R, const DevJob* jobs, int njobs, DevResult* res, uint8_t* w
 void launch_gap_traceback(const DevJob* jobs, int njobs, DevResult* res, const uint8_t* ws,
                           uint8_t* strs, hipStream_t st) {
   if (njobs <= 0) return;
-  hipLaunchKernelGGL(gap_traceback_kernel, dim3((njobs + 63) / 64), dim3(64), 0, st, jobs, njobs, res, ws, strs);
+  hipLaunchKernelGGL(gap_traceback_wave_kernel, dim3((njobs + 3) / 4), dim3(256), 0, st, jobs, njobs, res, ws, strs);
 }
 
 void launch_lcf(const DevJob* jobs, int njobs, uint32_t max_chunks, uint32_t max_l2,
