@@ -20,20 +20,32 @@ static void pairing_free(void* v) {
   free(x);
 }
 
+/* positions without a vertex share this list: it is never written (vertices are only added at
+ * positions that already hold one) */
+static ef_list empty_position = { { &empty_position.sent, &empty_position.sent, NULL }, 0 };
+
 ef_meg* ef_meg_from_pairings(const ef_triple* tr, size_t n_tr, size_t m) {
   ef_meg* V = (ef_meg*)malloc(sizeof(ef_meg));
   V->n = m + 2;
-  /* one list per EST position, most of them empty: the headers live in one block */
-  V->v = (ef_list**)malloc(V->n * (sizeof(ef_list*) + sizeof(ef_list)));
+  /* one list per EST position, most of them empty: headers exist only for the positions that
+   * hold a vertex (source, sink and the distinct p of the pairings) */
+  V->v = (ef_list**)malloc(V->n * sizeof(ef_list*) + (n_tr + 2) * sizeof(ef_list));
   ef_list* heads = (ef_list*)(V->v + V->n);
-  for (size_t i = 0; i < V->n; ++i) { V->v[i] = &heads[i]; efl_init(V->v[i]); }
-  efl_push_back(V->v[0], pairing_new(EF_SOURCE_START, EF_SOURCE_START, EF_SOURCE_LEN));
-  for (size_t k = 0; k < n_tr; ++k)
-    efl_push_back(V->v[1 + tr[k].p], pairing_new(tr[k].p, tr[k].t, tr[k].l));
-  efl_push_back(V->v[V->n - 1], pairing_new(EF_SINK_START, EF_SINK_START, EF_SOURCE_LEN));
+  for (size_t i = 0; i < V->n; ++i) V->v[i] = &empty_position;
   V->act = (size_t*)malloc((n_tr + 2) * sizeof(size_t));
   V->n_act = 0;
-  for (size_t i = 0; i < V->n; ++i) if (!efl_empty(V->v[i])) V->act[V->n_act++] = i;
+  size_t h = 0;
+#define MEG_POS(i_) do { if (V->v[(i_)] == &empty_position) { V->v[(i_)] = &heads[h++]; efl_init(V->v[(i_)]); } } while (0)
+  MEG_POS(0);
+  efl_push_back(V->v[0], pairing_new(EF_SOURCE_START, EF_SOURCE_START, EF_SOURCE_LEN));
+  for (size_t k = 0; k < n_tr; ++k) {
+    MEG_POS(1 + (size_t)tr[k].p);
+    efl_push_back(V->v[1 + tr[k].p], pairing_new(tr[k].p, tr[k].t, tr[k].l));
+  }
+  MEG_POS(V->n - 1);
+  efl_push_back(V->v[V->n - 1], pairing_new(EF_SINK_START, EF_SINK_START, EF_SOURCE_LEN));
+#undef MEG_POS
+  for (size_t i = 0; i < V->n; ++i) if (V->v[i] != &empty_position) V->act[V->n_act++] = i;
   return V;
 }
 

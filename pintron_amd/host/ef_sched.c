@@ -12,6 +12,7 @@
  * files are byte-identical to a sequential run.
  */
 #define _GNU_SOURCE
+#include <malloc.h>
 #include <pthread.h>
 #include <time.h>
 #include <stdlib.h>
@@ -589,6 +590,10 @@ struct ef_session {
 
 ef_session* ef_session_open(int argc, char** argv) {
   const double t_start = now_s();
+  /* the per-EST code allocates and frees a few hundred small blocks per EST on every worker; keep
+   * the arenas from returning memory to the system and asking for it again between ESTs */
+  mallopt(M_TRIM_THRESHOLD, 512 << 20);
+  mallopt(M_TOP_PAD, 16 << 20);
   ef_session* s = (ef_session*)calloc(1, sizeof(ef_session));
   if (ef_load_inputs(argc, argv, &s->in) != 0) { free(s); return NULL; }
   ef_classify_init();
