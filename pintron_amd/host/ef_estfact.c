@@ -18,22 +18,27 @@ void ef_write_multifasta_output(const ef_seq* gen, const ef_est* e, FILE* f, cha
     int polya = efi_next(&pa) == (void*)1, polyad = efi_next(&pd) == (void*)1;
     const size_t n = efl_size(fact);
     if (!(retain_externals || (n > 2 || (n == 2 && e->info->suff_polyA_length != -1)))) continue;
-    fprintf(f, ">%s\n", e->info->id);
+    ef_wbuf w; efw_open(&w, f);
+    efw_ch(&w, '>'); efw_str(&w, e->info->id); efw_ch(&w, '\n');
     if (!retain_externals) { polya = 0; polyad = 0; }
-    fprintf(f, "#polya=%d\n#polyad=%d\n", polya, polyad);
+    efw_str(&w, "#polya="); efw_int(&w, polya); efw_str(&w, "\n#polyad="); efw_int(&w, polyad); efw_ch(&w, '\n');
     unsigned counter = 1;
     const unsigned l_index = retain_externals == 0 ? 1 : 0;
     const unsigned r_index = retain_externals == 0 ? (e->info->suff_polyA_length == -1 ? (unsigned)n : (unsigned)n + 1) : (unsigned)n + 1;
     ef_iter xi = efl_begin(fact);
     while (efi_has_next(&xi)) {
       const ef_factor* x = (const ef_factor*)efi_next(&xi);
-      if (counter > l_index && counter < r_index)
-        fprintf(f, "%d %d %d %d %.*s %.*s\n", x->EST_start + 1, x->EST_end + 1,
-                gen->pref_N_length + x->GEN_start + 1, gen->pref_N_length + x->GEN_end + 1,
-                x->EST_end + 1 - x->EST_start, e->info->original_seq + x->EST_start,
-                x->GEN_end + 1 - x->GEN_start, gen->original_seq + gen->pref_N_length + x->GEN_start);
+      if (counter > l_index && counter < r_index) {        /* "%d %d %d %d %.*s %.*s\n" */
+        efw_int(&w, x->EST_start + 1); efw_ch(&w, ' '); efw_int(&w, x->EST_end + 1); efw_ch(&w, ' ');
+        efw_int(&w, gen->pref_N_length + x->GEN_start + 1); efw_ch(&w, ' ');
+        efw_int(&w, gen->pref_N_length + x->GEN_end + 1); efw_ch(&w, ' ');
+        efw_strn(&w, e->info->original_seq + x->EST_start, x->EST_end + 1 - x->EST_start); efw_ch(&w, ' ');
+        efw_strn(&w, gen->original_seq + gen->pref_N_length + x->GEN_start, x->GEN_end + 1 - x->GEN_start);
+        efw_ch(&w, '\n');
+      }
       ++counter;
     }
+    efw_flush(&w);
   }
 }
 

@@ -64,8 +64,10 @@ uint32_t ef_compute_edit_distance(ef_backend* be, const char* a, size_t la, cons
 /* ---------------------------------------------------------------------------------------------- */
 /* embeddings (src/est-factorizations.c:597-917, 1362-1460)                                       */
 /* ---------------------------------------------------------------------------------------------- */
-static ptl* ptl_new(int p, int t, int l) { ptl* x = (ptl*)malloc(sizeof(ptl)); x->p = p; x->t = t; x->l = l; return x; }
-static void embedding_free(void* e) { efl_free((ef_list*)e, free); }
+/* embedding elements come from the per-thread cell pool like the list nodes that carry them */
+static ptl* ptl_new(int p, int t, int l) { ptl* x = (ptl*)ef_cell_get(); x->p = p; x->t = t; x->l = l; return x; }
+static void ptl_free(void* x) { ef_cell_put(x); }
+static void embedding_free(void* e) { efl_free((ef_list*)e, ptl_free); }
 
 static ef_list* embedding_copy(ef_list* e) {
   ef_list* c = efl_new();

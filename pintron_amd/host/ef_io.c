@@ -21,10 +21,22 @@ void ef_cell_refill(void) {
   for (size_t i = 0; i < 2048; ++i) { b->cells[i].next = ef_cell_free_list; ef_cell_free_list = &b->cells[i]; }
 }
 
+typedef struct cell64_block { struct cell64_block* next; ef_cell64 cells[1024]; } cell64_block;
+_Thread_local ef_cell64* ef_cell64_free_list;
+static _Thread_local cell64_block* cell64_blocks;
+
+void ef_cell64_refill(void) {
+  cell64_block* b = (cell64_block*)malloc(sizeof(cell64_block));
+  if (!b) { fprintf(stderr, "* FATAL out of memory\n"); abort(); }
+  b->next = cell64_blocks; cell64_blocks = b;
+  for (size_t i = 0; i < 1024; ++i) { b->cells[i].next = ef_cell64_free_list; ef_cell64_free_list = &b->cells[i]; }
+}
+
 void ef_cell_release_all(void) {
   if (ef_cell_live != 0) return;            /* something of this thread is still alive: keep the blocks */
   while (cell_blocks) { cell_block* nx = cell_blocks->next; free(cell_blocks); cell_blocks = nx; }
-  ef_cell_free_list = NULL;
+  while (cell64_blocks) { cell64_block* nx = cell64_blocks->next; free(cell64_blocks); cell64_blocks = nx; }
+  ef_cell_free_list = NULL; ef_cell64_free_list = NULL;
 }
 
 static char* dup_range(const char* s, size_t n) {
@@ -308,5 +320,7 @@ ef_seq* ef_copy_and_reverse(const ef_seq* est) {
 }
 
 void ef_write_single_est_info(FILE* f, const ef_seq* s) {
-  fprintf(f, ">%s\n%s\n", s->id, s->original_seq);
+  ef_wbuf w; efw_open(&w, f);
+  efw_ch(&w, '>'); efw_str(&w, s->id); efw_ch(&w, '\n'); efw_str(&w, s->original_seq); efw_ch(&w, '\n');
+  efw_flush(&w);
 }

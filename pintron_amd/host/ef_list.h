@@ -46,6 +46,23 @@ static inline void ef_cell_put(void* p) {
 }
 #endif
 typedef char ef_cell_size_check[(sizeof(ef_list) <= sizeof(ef_cell) && sizeof(ef_node) <= sizeof(ef_cell)) ? 1 : -1];
+/* the same scheme for 64-byte blocks (MEG vertices) */
+typedef union ef_cell64 { union ef_cell64* next; char bytes[64]; } ef_cell64;
+extern _Thread_local ef_cell64* ef_cell64_free_list;
+void ef_cell64_refill(void);
+#ifdef EF_NO_CELL_POOL
+static inline void* ef_cell64_get(void) { return malloc(sizeof(ef_cell64)); }
+static inline void ef_cell64_put(void* p) { free(p); }
+#else
+static inline void* ef_cell64_get(void) {
+  if (!ef_cell64_free_list) ef_cell64_refill();
+  ef_cell64* c = ef_cell64_free_list; ef_cell64_free_list = c->next; ++ef_cell_live;
+  return c;
+}
+static inline void ef_cell64_put(void* p) {
+  ef_cell64* c = (ef_cell64*)p; c->next = ef_cell64_free_list; ef_cell64_free_list = c; --ef_cell_live;
+}
+#endif
 #define EFL_NODE_NEW() ((ef_node*)ef_cell_get())
 #define EFL_NODE_DEL(n) ef_cell_put(n)
 

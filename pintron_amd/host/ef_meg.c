@@ -7,8 +7,10 @@
 
 #include "estfact.h"
 
+typedef char ef_pairing_fits_cell64[sizeof(ef_pairing) <= sizeof(ef_cell64) ? 1 : -1];
 static ef_pairing* pairing_new(int p, int t, int l) {
-  ef_pairing* x = (ef_pairing*)calloc(1, sizeof(ef_pairing));
+  ef_pairing* x = (ef_pairing*)ef_cell64_get();
+  memset(x, 0, sizeof(ef_pairing));
   x->p = p; x->t = t; x->l = l;
   x->adjs = efl_new(); x->incs = efl_new();
   return x;
@@ -17,7 +19,7 @@ static ef_pairing* pairing_new(int p, int t, int l) {
 static void pairing_free(void* v) {
   ef_pairing* x = (ef_pairing*)v;
   efl_free(x->adjs, NULL); efl_free(x->incs, NULL);
-  free(x);
+  ef_cell64_put(x);
 }
 
 /* positions without a vertex share this list: it is never written (vertices are only added at
@@ -360,27 +362,33 @@ void ef_transitive_reduction(ef_meg* V) {
 }
 
 void ef_meg_write(FILE* f, ef_meg* V) {
+  ef_wbuf w; efw_open(&w, f);
   int index = 0;
   EF_MEG_FOR_POS(V, i, 0, V->n) {
     ef_iter it = efl_begin(V->v[i]);
     while (efi_has_next(&it)) {
       ef_pairing* p = (ef_pairing*)efi_next(&it);
-      fprintf(f, "(%d,%d,%d)\n", p->p, p->t, p->l);
+      efw_ch(&w, '('); efw_int(&w, p->p); efw_ch(&w, ','); efw_int(&w, p->t); efw_ch(&w, ','); efw_int(&w, p->l);
+      efw_mem(&w, ")\n", 2);                                   /* "(%d,%d,%d)\n" */
       p->id = index++;
     }
   }
-  fprintf(f, "#adj#\n");
+  efw_mem(&w, "#adj#\n", 6);
   EF_MEG_FOR_POS(V, i, 0, V->n) {
     ef_iter it = efl_begin(V->v[i]);
     while (efi_has_next(&it)) {
       const ef_pairing* p = (const ef_pairing*)efi_next(&it);
       ef_iter a = efl_begin(p->adjs);
-      while (efi_has_next(&a)) fprintf(f, "%d-%d\n", p->id, ((const ef_pairing*)efi_next(&a))->id);
+      while (efi_has_next(&a)) {                               /* "%d-%d\n" */
+        efw_int(&w, p->id); efw_ch(&w, '-'); efw_int(&w, ((const ef_pairing*)efi_next(&a))->id); efw_ch(&w, '\n');
+      }
     }
   }
+  efw_flush(&w);
 }
 
 void ef_intronic_edges_write(FILE* f, ef_meg* V) {
+  ef_wbuf w; efw_open(&w, f);
   EF_MEG_FOR_POS(V, i, 0, V->n) {
     ef_iter it = efl_begin(V->v[i]);
     while (efi_has_next(&it)) {
@@ -390,13 +398,15 @@ void ef_intronic_edges_write(FILE* f, ef_meg* V) {
       while (efi_has_next(&a)) {
         const ef_pairing* x = (const ef_pairing*)efi_next(&a);
         if (x->p == EF_SINK_START) continue;
-        fprintf(f, "%d %d %d %d %d %d %d %d %d", p->t + p->l, x->t, p->p + p->l, x->p,
-                (x->t - p->t - p->l), (x->p - p->p - p->l), (x->t - p->t) - (x->p - p->p), p->l, x->l);
-        if ((x->t - p->t) - (x->p - p->p) >= 50) fprintf(f, " intronic");
-        fprintf(f, "\n");
+        const int v9[9] = { p->t + p->l, x->t, p->p + p->l, x->p, (x->t - p->t - p->l), (x->p - p->p - p->l),
+                            (x->t - p->t) - (x->p - p->p), p->l, x->l };
+        for (int k = 0; k < 9; ++k) { if (k) efw_ch(&w, ' '); efw_int(&w, v9[k]); }
+        if ((x->t - p->t) - (x->p - p->p) >= 50) efw_mem(&w, " intronic", 9);
+        efw_ch(&w, '\n');
       }
     }
   }
+  efw_flush(&w);
 }
 
 /* build_meg (src/compute-est-fact.c:90-152) */

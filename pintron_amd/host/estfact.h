@@ -138,6 +138,35 @@ void ef_meg_stats(ef_meg* V, size_t* pairings, size_t* edges);         /* :52 */
 void ef_meg_write(FILE* f, ef_meg* V);                                 /* src/io-meg.c:146 */
 void ef_intronic_edges_write(FILE* f, ef_meg* V);                      /* src/max-emb-graph.c:677 */
 
+/* ---- output text ------------------------------------------------------------------------------
+ * The record writers produce a few hundred short numeric fields per EST; they are assembled in a
+ * small buffer with a hand-written integer formatter and handed to stdio in large pieces (printf
+ * parsing was >10 % of the host time). */
+typedef struct { FILE* f; size_t n; char b[4096]; } ef_wbuf;
+static inline void efw_open(ef_wbuf* w, FILE* f) { w->f = f; w->n = 0; }
+static inline void efw_flush(ef_wbuf* w) { if (w->n) { fwrite(w->b, 1, w->n, w->f); w->n = 0; } }
+static inline void efw_ch(ef_wbuf* w, char c) { if (w->n == sizeof w->b) efw_flush(w); w->b[w->n++] = c; }
+static inline void efw_mem(ef_wbuf* w, const char* s, size_t n) {
+  if (n > sizeof w->b / 2) { efw_flush(w); fwrite(s, 1, n, w->f); return; }
+  if (w->n + n > sizeof w->b) efw_flush(w);
+  memcpy(w->b + w->n, s, n); w->n += n;
+}
+static inline void efw_str(ef_wbuf* w, const char* s) { efw_mem(w, s, strlen(s)); }
+/* printf("%.*s"): at most `prec` characters, fewer when the string ends first */
+static inline void efw_strn(ef_wbuf* w, const char* s, int prec) {
+  size_t n = 0;
+  while ((int)n < prec && s[n] != '\0') ++n;
+  efw_mem(w, s, n);
+}
+static inline void efw_int(ef_wbuf* w, long long v) {                     /* printf("%d") */
+  char t[24]; int k = 0;
+  unsigned long long u = v < 0 ? 0ull - (unsigned long long)v : (unsigned long long)v;
+  do { t[k++] = (char)('0' + u % 10); u /= 10; } while (u);
+  if (w->n + 24 > sizeof w->b) efw_flush(w);
+  if (v < 0) w->b[w->n++] = '-';
+  while (k) w->b[w->n++] = t[--k];
+}
+
 /* ---- backend: where pairings and dynamic programs are computed ------------------------------ */
 /* DP request/response in the vocabulary of include/pintron_gpu.h (same kinds, same result slots) */
 enum { EF_DP_ALIGN = 0, EF_DP_GAP = 1, EF_DP_ED = 2, EF_DP_KBAND = 3, EF_DP_LCF = 4,

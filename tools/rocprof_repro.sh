@@ -1,7 +1,10 @@
 export TMPDIR=/tmp
-for cfg in "X=1" "PINTRON_SERVICES=1" "X=2"; do
+fails=0
+for it in 1 2 3 4 5 6 7 8; do
   rm -rf gpurun_out/rp_test
-  echo "== $cfg"
-  env $cfg rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/rp_test -o t -- python3 bench.py --steps 3 --warmup 1 --no-cpu > gpurun_out/rp_test.json 2> gpurun_out/rp_test.err; echo "rc=$?"; grep -A22 "SIGSEGV" gpurun_out/rp_test.err | head -30
+  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/rp_test -o t -- python3 bench.py --steps 3 --warmup 1 --no-cpu > gpurun_out/rp_test.json 2> gpurun_out/rp_test.err; rc=$?
+  echo "run $it rc=$rc"
+  if [ $rc -ne 0 ]; then fails=$((fails+1)); cp gpurun_out/rp_test.err gpurun_out/rp_fail_$it.err; fi
 done
-find gpurun_out/rp_test -name '*kernel_trace.csv' -delete
+echo "failures: $fails"
+rm -rf gpurun_out/rp_test
