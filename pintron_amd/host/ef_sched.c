@@ -571,6 +571,11 @@ static void* worker_main(void* arg) {
   return NULL;
 }
 
+static bool env_flag(const char* name) {          /* set and not "0" */
+  const char* v = getenv(name);
+  return v && !(v[0] == '0' && v[1] == '\0');
+}
+
 static size_t env_size(const char* name, size_t dflt) {
   const char* v = getenv(name);
   return (v && atol(v) > 0) ? (size_t)atol(v) : dflt;
@@ -605,7 +610,7 @@ ef_session* ef_session_open(int argc, char** argv) {
   ef_inputs* in = &s->in;
   shared* sh = &s->sh;
   sh->in = in;
-  if (getenv("PINTRON_KERNEL_TIMING")) pgpu_set_timing(s->ctx0, 1);
+  if (env_flag("PINTRON_KERNEL_TIMING")) pgpu_set_timing(s->ctx0, 1);
   if (pgpu_index_build(s->ctx0, in->gen->seq, strlen(in->gen->seq), &sh->idx) != PGPU_OK) {
     fprintf(stderr, "* FATAL pgpu_index_build: %s\n", pgpu_last_error(s->ctx0));
     free(s); return NULL;
@@ -647,7 +652,7 @@ ef_session* ef_session_open(int argc, char** argv) {
   if (sh->svc.n_threads > MAX_SERVICES) sh->svc.n_threads = MAX_SERVICES;
   for (int k = 0; k < sh->svc.n_threads; ++k) {
     if (pgpu_init(ef_gpu_device_from_env(), &sh->svc.threads[k].ctx) != PGPU_OK) { free(s); return NULL; }
-    if (getenv("PINTRON_KERNEL_TIMING")) pgpu_set_timing(sh->svc.threads[k].ctx, 1);
+    if (env_flag("PINTRON_KERNEL_TIMING")) pgpu_set_timing(sh->svc.threads[k].ctx, 1);
   }
   const long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
   /* default: the host share of one GPU on an 8-GPU node (16 cores; the GPU boxes expose far more,
@@ -658,7 +663,7 @@ ef_session* ef_session_open(int argc, char** argv) {
   if (s->nthreads > sh->n_units) s->nthreads = sh->n_units ? sh->n_units : 1;
   sh->max_fibers = env_size("PINTRON_FIBERS", 768);
   sh->stack_size = env_size("PINTRON_FIBER_STACK_KB", 256) * 1024;
-  sh->kernel_timing = getenv("PINTRON_KERNEL_TIMING") != NULL;
+  sh->kernel_timing = env_flag("PINTRON_KERNEL_TIMING");
   sh->gen_len = strlen(in->gen->seq);
   sh->n_lanes = (int)env_size("PINTRON_LANES", 3);
   if (sh->n_lanes > MAX_LANES) sh->n_lanes = MAX_LANES;
