@@ -757,6 +757,15 @@ int ef_session_step(ef_session* s, ef_sched_stats* stats_out) {
       ef_kernel_stat ks; memset(&ks, 0, sizeof ks);
       snprintf(ks.name, sizeof ks.name, "%s", nm[k]);
       ks.ms = s->pre_kernel_ms[k]; ks.launches = (size_t)sh->n_pre; ks.jobs = s->in.n;
+      /* algorithmic bytes: two 4-byte suffix-array probes per bisection
+       * step and position for the descent; 12 bytes per pairing written */
+      if (k == 0 || k == 5) {
+        unsigned long long positions = 0, pairs = 0;
+        for (int c = 0; c < sh->n_pre; ++c) { positions += pgpu_pairing_plan_positions(s->pplan[c]); pairs += pgpu_pairing_plan_count(s->pplan[c]); }
+        unsigned lg = 0;
+        while ((1ull << lg) < sh->gen_len) ++lg;
+        ks.algo_bytes = k == 0 ? positions * lg * 8ull : pairs * 12ull;
+      }
       if (ks.ms > 0) kstat_add(&st, &ks);
     }
   }

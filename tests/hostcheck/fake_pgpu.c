@@ -63,6 +63,7 @@ int pgpu_pairing_plan_run(pgpu_ctx* ctx, pgpu_pairing_plan* p, const pgpu_pairin
   return PGPU_OK;
 }
 uint64_t pgpu_pairing_plan_count(const pgpu_pairing_plan* p) { return p->cnt; }
+uint64_t pgpu_pairing_plan_positions(const pgpu_pairing_plan* p) { return p->off[p->n]; }
 int pgpu_pairing_plan_fetch(pgpu_ctx* ctx, pgpu_pairing_plan* p, pgpu_pairing* out, size_t cap, uint64_t* first) {
   (void)ctx;
   if (cap < p->cnt) return PGPU_ENOSPC;
