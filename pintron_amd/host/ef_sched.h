@@ -34,6 +34,8 @@ void ef_session_close(ef_session* s);
  * PINTRON_FIBERS (fibres per worker over all lanes, 768), PINTRON_FIBER_STACK_KB (256),
  * PINTRON_SERVICES (GPU service threads, 2), PINTRON_GPU_DEVICE (0), PINTRON_NO_PREFETCH,
  * PINTRON_KERNEL_TIMING, PINTRON_VERBOSE */
+/* set by a program that ends right after ef_run_batched: the session is not taken apart */
+extern int ef_leave_without_cleanup;
 int ef_run_batched(int argc, char** argv);
 int ef_run_batched_stats(int argc, char** argv, ef_sched_stats* stats);
 

@@ -3,7 +3,9 @@
  * raw-multifasta-out.txt, processed-ests.txt and the MEG side files.  All pairings and dynamic
  * programs run on the GPU through libpintron_gpu.so; without a gfx950 device the program fails. */
 #include <stdlib.h>
+#include <stdio.h>
 #include <string.h>
+#include <unistd.h>
 
 #include "estfact.h"
 #include "ef_gpu.h"
@@ -12,5 +14,10 @@
 int main(int argc, char** argv) {
   const char* mode = getenv("PINTRON_ESTFACT_MODE");
   if (mode && !strcmp(mode, "direct")) return ef_run(argc, argv, ef_gpu_open, ef_gpu_close);
-  return ef_run_batched(argc, argv);
+  /* PINTRON_CLEAN_EXIT keeps the orderly teardown (profilers that flush at exit need it) */
+  if (getenv("PINTRON_CLEAN_EXIT")) return ef_run_batched(argc, argv);
+  ef_leave_without_cleanup = 1;
+  const int rc = ef_run_batched(argc, argv);
+  fflush(NULL);
+  _exit(rc);
 }
