@@ -3,6 +3,7 @@
  * (same files in cwd, same record formats, same order of ESTs and of the reverse-complement
  * siblings).  The wall-clock timeout of the reference (src/my_time.c:177-198) is not reproduced:
  * nothing here depends on time. */
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 #include <unistd.h>
@@ -75,6 +76,23 @@ ef_est* ef_compute_est_fact(const ef_seq* gen, const ef_seq* est, ef_backend* be
   return fe;
 }
 
+typedef struct { ef_seq** ests; ef_seq** revs; long lo, hi; } prep_job;
+static void* prep_main(void* arg) {
+  prep_job* j = (prep_job*)arg;
+  for (long i = j->lo; i < j->hi; ++i) {
+    ef_seq* est = j->ests[i];
+    ef_set_gb_identification(est);
+    ef_set_strand_and_rc(est);
+    ef_polyAT_substitution(est);
+    if (!est->fixed_strand) {
+      ef_seq* rev = ef_copy_and_reverse(est);
+      ef_polyAT_substitution(rev);
+      j->revs[i] = rev;
+    }
+  }
+  return NULL;
+}
+
 /* inputs of one est-fact run: configuration, genomic, prepared EST list (siblings interleaved) */
 int ef_load_inputs(int argc, char** argv, ef_inputs* in) {
   memset(in, 0, sizeof(*in));
@@ -90,21 +108,24 @@ int ef_load_inputs(int argc, char** argv, ef_inputs* in) {
   ef_seq_index_kmers(in->gen);
   const long n_in = ef_read_multifasta("ests.txt", &ests);
   if (n_in < 0) { fprintf(stderr, "* FATAL File ests.txt not found! Terminating\n"); return 1; }
-  /* preparation loop (src/main-est-fact.c:190-213) */
+  /* preparation loop (src/main-est-fact.c:190-213): every EST is prepared on its own, so the
+   * loop is split over a few threads; the list is then filled in input order */
+  ef_seq** revs = (ef_seq**)calloc((size_t)n_in + 1, sizeof(ef_seq*));
+  enum { PREP_THREADS = 8 };
+  prep_job jobs[PREP_THREADS]; pthread_t th[PREP_THREADS]; bool started[PREP_THREADS];
+  for (int t = 0; t < PREP_THREADS; ++t) {
+    jobs[t].ests = ests; jobs[t].revs = revs;
+    jobs[t].lo = n_in * t / PREP_THREADS; jobs[t].hi = n_in * (t + 1) / PREP_THREADS;
+    started[t] = n_in >= 1024 && pthread_create(&th[t], NULL, prep_main, &jobs[t]) == 0;
+    if (!started[t]) prep_main(&jobs[t]);
+  }
+  for (int t = 0; t < PREP_THREADS; ++t) if (started[t]) pthread_join(th[t], NULL);
   in->list = (ef_seq**)malloc((size_t)(2 * n_in + 1) * sizeof(ef_seq*));
   for (long i = 0; i < n_in; ++i) {
-    ef_seq* est = ests[i];
-    ef_set_gb_identification(est);
-    ef_set_strand_and_rc(est);
-    in->list[in->n++] = est;
-    ef_polyAT_substitution(est);
-    if (!est->fixed_strand) {
-      ef_seq* rev = ef_copy_and_reverse(est);
-      in->list[in->n++] = rev;
-      ef_polyAT_substitution(rev);
-    }
+    in->list[in->n++] = ests[i];
+    if (revs[i]) in->list[in->n++] = revs[i];
   }
-  free(ests);
+  free(ests); free(revs);
   return 0;
 }
 
