@@ -147,8 +147,10 @@ typedef struct {
 } pgpu_dp_result;           /* 48 bytes */
 
 /* limits (per job); larger jobs get status PGPU_ERANGE */
-#define PGPU_MAX_ROWS_LEV  4096u   /* ALIGN: a_len; ED: min(a_len,b_len); BORDERS/AFFIX: a_len */
-#define PGPU_MAX_ROWS_GAP  2048u   /* GAP: a_len */
+#define PGPU_MAX_ROWS_LEV     65536u  /* ALIGN, AFFIX: a_len; ED, KBAND: min(a_len,b_len) (beyond 4096 rows
+                                        one wave sweeps the matrix in strips of 4096 rows) */
+#define PGPU_MAX_ROWS_BORDERS 4096u  /* BORDERS: a_len */
+#define PGPU_MAX_ROWS_GAP     2048u  /* GAP: a_len */
 #define PGPU_MAX_COLS      1048576u
 
 /* A plan holds a batch of jobs resident in HBM: operands, sorted job table, workspaces, results.

@@ -179,6 +179,7 @@ struct Group {
 };
 
 uint32_t row_class(uint32_t rows) {         // smallest R in {1,2,4,...,64} with 64*R >= rows
+  if (rows > 4096u) return ROW_CLASS_STRIPS;  // beyond that: strips of 4096 rows on the R = 64 kernels
   uint32_t R = 1;
   while (64u * R < rows) R <<= 1;
   return R;
@@ -286,7 +287,7 @@ extern "C" int pgpu_dp_plan_create(pgpu_ctx* ctx, const pgpu_index* idx, const p
         if (lb > 65535u || la >= (1u << 28)) continue;
         k.family = KF_LCF; k.R = 0; k.size = (uint64_t)la * lb; break;
       case PGPU_DP_BORDERS:
-        if (la > PGPU_MAX_ROWS_LEV || lb > PGPU_MAX_COLS) continue;
+        if (la > PGPU_MAX_ROWS_BORDERS || lb > PGPU_MAX_COLS) continue;
         if (in.p0 > in.p1 || in.p1 > la) { pre.status = PGPU_EINVAL; continue; }
         k.family = KF_BORDERS; k.R = row_class(la); k.size = (uint64_t)la * lb; break;
       case PGPU_DP_AFFIX:
@@ -310,7 +311,14 @@ extern "C" int pgpu_dp_plan_create(pgpu_ctx* ctx, const pgpu_index* idx, const p
   size_t ws = 0, strs = 0, nkeys = 0;
   for (auto& k : v) {
     const uint32_t la = k.j.la, lb = k.j.lb;
-    if (k.family == KF_ALIGN) {
+    if (k.R == ROW_CLASS_STRIPS) {            // two boundary rows, then (ALIGN) the directions of every strip
+      const uint32_t nc = (k.family == KF_ED || k.family == KF_KBAND) ? std::max(la, lb) : lb;
+      k.j.ws_off = ws; ws += 2 * strip_bnd_bytes(nc);
+      if (k.family == KF_ALIGN) {
+        ws += (size_t)((la + 4095u) / 4096u) * ((size_t)lb + 64) * 64 * align_entry_bytes(k.R);
+        k.j.str_off = strs; strs += 2 * ((size_t)la + lb + 1);
+      }
+    } else if (k.family == KF_ALIGN) {
       k.j.ws_off = ws; ws += ((size_t)lb + 64) * 64 * align_entry_bytes(k.R);
       k.j.str_off = strs; strs += 2 * ((size_t)la + lb + 1);
     } else if (k.family == KF_GAP) {
@@ -353,6 +361,7 @@ extern "C" int pgpu_dp_plan_create(pgpu_ctx* ctx, const pgpu_index* idx, const p
     static const char* fam[] = {"lev_wave<ALIGN", "gap_wave<", "lev_wave<ED", "lev_wave<KBAND", "lcf",
                                 "lev_wave<BORDERS", "lev_wave<AFFIX"};
     if (g.family == KF_LCF) snprintf(nm, sizeof nm, "%s", fam[g.family]);
+    else if (g.R == (int)ROW_CLASS_STRIPS) snprintf(nm, sizeof nm, "%s,R=64 strips>", fam[g.family]);
     else if ((g.family == KF_BORDERS || g.family == KF_AFFIX) && g.R >= 2)   // one job per workgroup
       snprintf(nm, sizeof nm, "%s<rows<=%d>", g.family == KF_BORDERS ? "borders_coop" : "affix_coop", 64 * g.R);
     else snprintf(nm, sizeof nm, "%s%sR=%d>", fam[g.family], g.family == KF_GAP ? "" : ",", g.R);

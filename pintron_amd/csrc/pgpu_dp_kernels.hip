@@ -118,41 +118,57 @@ struct AffixBest {          // running best cut of find_longest_affix
 // One column sweep.  On return cur[r] = M[row(l,r)][nc].
 constexpr uint32_t BAND_INF = 0x3FFFFFu;   // "outside the band"; stays below the 24-bit value field
 
+// Rows beyond 64*R are processed in horizontal STRIPS of 64*R rows by the same wave: the strip's
+// last row is written, per column, to a boundary array in the job's workspace (`bottom`) and is
+// the row above the first row (`top`) of the next strip; `row_base` = rows before this strip.
+// The boundary values go through memory written and read by one wave: agent-scope atomics keep
+// the per-CU L1 out of the way.
 template <int R, bool WILD, bool DIRS, bool ROWMIN, bool AFFIX, bool BAND = false>
 __device__ __forceinline__ void lev_sweep(const Operand rows, const uint32_t nr,
                                           const Operand cols, const uint32_t nc,
                                           const uint32_t lane, uint32_t (&cur)[R],
                                           uint32_t (&minv)[R], uint32_t (&minpos)[R],
-                                          AffixBest& best, uint8_t* dir_ws, const uint32_t band_k = 0) {
+                                          AffixBest& best, uint8_t* dir_ws, const uint32_t band_k = 0,
+                                          const uint32_t row_base = 0, const uint32_t* top_row = nullptr,
+                                          uint32_t* bottom_row = nullptr) {
   uint32_t rc[R];                       // row characters of this lane's strip
-  const uint32_t row0 = lane * R;       // rows row0+1 .. row0+R
+  const uint32_t row0 = lane * R;       // rows row0+1 .. row0+R (of the strip)
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const uint32_t i = row0 + r;
     rc[r] = i < nr ? rows.at(i) : PAD_ROW;
-    cur[r] = i + 1;                     // M[i+1][0]
-    if constexpr (BAND) { if (i + 1 > band_k) cur[r] = BAND_INF; }
+    cur[r] = row_base + i + 1;          // M[i+1][0]
+    if constexpr (BAND) { if (row_base + i + 1 > band_k) cur[r] = BAND_INF; }
     if constexpr (ROWMIN) { minv[r] = i + 1; minpos[r] = 0; }
   }
   if (nr == 0 || nc == 0) return;
   const uint32_t last_lane = (nr - 1) / R;
+  const uint32_t last_r = (nr - 1) % R;
   const uint32_t steps = nc + last_lane;
-  uint32_t diag_in = row0;              // M[row0][j-1] for j = 1
+  uint32_t diag_in = row_base + row0;   // M[row0][j-1] for j = 1
   uint32_t out = 0;                     // (value of the strip's last row) | (column char << 24)
-  uint32_t chunk = 0;
+  uint32_t chunk = 0, tchunk = 0;
   constexpr uint32_t EB = R <= 4 ? 1u : R / 4;
+  if (bottom_row && lane == 0) {
+    uint32_t b0 = row_base + nr;
+    if constexpr (BAND) { if (b0 > band_k) b0 = BAND_INF; }
+    __hip_atomic_store(&bottom_row[0], b0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (top_row && lane == 0) diag_in = __hip_atomic_load(&top_row[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
   for (uint32_t s = 0; s < steps; ++s) {
     const uint32_t t = s & 63u;
     if (t == 0) {                       // refill the column-character window (coalesced 64 B)
       const uint32_t j = s + lane;
       chunk = j < nc ? cols.at(j) : PAD_COL;
+      if (top_row) tchunk = j < nc ? __hip_atomic_load(&top_row[j + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
     }
     uint32_t in = wave_shr1(out);
     const uint32_t ch0 = (uint32_t)__builtin_amdgcn_readlane((int)chunk, (int)t);
+    const uint32_t top_in = (uint32_t)__builtin_amdgcn_readlane((int)tchunk, (int)t);
     if (lane == 0) {
-      uint32_t top = s + 1;                                // M[0][j] = j, j = s+1
-      if constexpr (BAND) { if (top > band_k) top = BAND_INF; }
+      uint32_t top = top_row ? top_in : s + 1;             // M[row_base][j], j = s+1
+      if constexpr (BAND) { if (!top_row && top > band_k) top = BAND_INF; }
       in = top | (ch0 << 24);
     }
     const uint32_t j = s - lane + 1;                     // column of this lane (wraps when idle)
@@ -182,14 +198,14 @@ __device__ __forceinline__ void lev_sweep(const Operand rows, const uint32_t nr,
         if constexpr (BAND) {
           // K_band_edit_distance keeps cells with |column - row| <= k only; neighbours outside
           // the band do not take part in the minimum (src/compute-alignments.c:375-443)
-          const uint32_t row = row0 + r + 1;
+          const uint32_t row = row_base + row0 + r + 1;
           v = (j + band_k >= row && row + band_k >= j) ? min(v, BAND_INF) : BAND_INF;
         }
         if constexpr (ROWMIN) {
           if (minv[r] > v) { minv[r] = v; minpos[r] = j; }   // strict: first arg-min
         }
         if constexpr (AFFIX) {
-          const uint32_t e = row0 + r + 1, sum = e + j;
+          const uint32_t e = row_base + row0 + r + 1, sum = e + j;
           // cut_weight = 2*v/(e+g) <= 0.17  <=>  200*v <= 17*(e+g)   (exact)
           if (rc[r] == ch && 200u * v <= 17u * sum && best.worse_than(v, sum, e, j)) {
             best.valid = 1; best.v = v; best.s = sum; best.e = e; best.g = j;
@@ -202,6 +218,12 @@ __device__ __forceinline__ void lev_sweep(const Operand rows, const uint32_t nr,
       diag_in = in_val;
       out = up | (ch << 24);
       if constexpr (DIRS) dp.store(dir_ws + ((size_t)s * 64 + lane) * EB);
+      if (bottom_row && lane == last_lane) {
+        uint32_t bv = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) if ((uint32_t)r == last_r) bv = cur[r];
+        __hip_atomic_store(&bottom_row[j], bv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
   }
 }
@@ -224,7 +246,11 @@ enum { MODE_ED = 0, MODE_ALIGN = 1, MODE_BORDERS = 2, MODE_AFFIX = 3, MODE_KBAND
 //              shortcut of compute_alignment (:48-58); directions go to the workspace
 // MODE_BORDERS general_refine_borders (src/refine.c:105-192)
 // MODE_AFFIX   find_longest_affix (src/factorization-refinement.c:1136-1173)
-template <int R, int MODE>
+// STRIPS (R = 64 only): jobs with more than 4096 rows, swept in strips of 4096 rows; the job's
+// workspace starts with the two boundary rows (strip_bnd_bytes each), ALIGN directions follow,
+// one block of (columns + 64) * 64 * 16 bytes per strip.
+
+template <int R, int MODE, bool STRIPS = false>
 __global__ __launch_bounds__(MODE == MODE_BORDERS ? 64 : 256)
 void lev_wave_kernel(const DevJob* __restrict__ jobs, int njobs, DevResult* __restrict__ results,
                      uint8_t* __restrict__ ws) {
@@ -242,6 +268,24 @@ void lev_wave_kernel(const DevJob* __restrict__ jobs, int njobs, DevResult* __re
     const bool swap = job.la > job.lb;
     const Operand rows{swap ? job.b : job.a, 0, false}, cols{swap ? job.a : job.b, 0, false};
     const uint32_t nr = swap ? job.lb : job.la, nc = swap ? job.la : job.lb;
+    if constexpr (STRIPS) {
+      constexpr uint32_t SR = 64u * R;
+      uint32_t* bnd = reinterpret_cast<uint32_t*>(ws + job.ws_off);
+      const size_t bw = strip_bnd_bytes(nc) / 4;
+      uint32_t done = 0;
+      for (uint32_t k = 0; done < nr; ++k, done += SR) {
+        const uint32_t part = min(SR, nr - done);
+        const Operand rs{rows.base + done, 0, false};
+        lev_sweep<R, false, false, false, false>(rs, part, cols, nc, lane, cur, minv, minpos, best, nullptr, 0, done,
+                                                 k ? bnd + ((k - 1) & 1) * bw : nullptr, done + part < nr ? bnd + (k & 1) * bw : nullptr);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // the next strip reads this strip's last row
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+      store_row_value<R>(cur, lane, nr - (done - SR), &res->v[0]);
+      if (lane == 0) res->status = 0;
+      return;
+    }
     lev_sweep<R, false, false, false, false>(rows, nr, cols, nc, lane, cur, minv, minpos, best, nullptr);
     if (nr == 0) { if (lane == 0) { res->status = 0; res->v[0] = (int32_t)nc; } return; }
     store_row_value<R>(cur, lane, nr, &res->v[0]);
@@ -255,6 +299,26 @@ void lev_wave_kernel(const DevJob* __restrict__ jobs, int njobs, DevResult* __re
       return;
     }
     const Operand rows{job.a, 0, false}, cols{job.b, 0, false};
+    if constexpr (STRIPS) {
+      constexpr uint32_t SR = 64u * R;
+      uint32_t* bnd = reinterpret_cast<uint32_t*>(ws + job.ws_off);
+      const size_t bw = strip_bnd_bytes(m) / 4;
+      uint8_t* dirs = ws + job.ws_off + 2 * strip_bnd_bytes(m);
+      const size_t strip_dirs = ((size_t)m + 64) * 64 * (R / 4);
+      uint32_t done = 0;
+      for (uint32_t k = 0; done < n; ++k, done += SR) {
+        const uint32_t part = min(SR, n - done);
+        const Operand rs{job.a + done, 0, false};
+        lev_sweep<R, true, true, false, false>(rs, part, cols, m, lane, cur, minv, minpos, best, dirs + k * strip_dirs, 0, done,
+                                               k ? bnd + ((k - 1) & 1) * bw : nullptr, done + part < n ? bnd + (k & 1) * bw : nullptr);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // the next strip reads this strip's last row
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+      store_row_value<R>(cur, lane, n - (done - SR), &res->v[0]);
+      if (lane == 0) { res->status = 0; res->v[5] = 0; }
+      return;
+    }
     lev_sweep<R, true, true, false, false>(rows, n, cols, m, lane, cur, minv, minpos, best, ws + job.ws_off);
     if (n == 0 || m == 0) { if (lane == 0) { res->status = 0; res->v[0] = (int32_t)(n + m); res->v[5] = 0; } return; }
     store_row_value<R>(cur, lane, n, &res->v[0]);
@@ -324,6 +388,28 @@ void lev_wave_kernel(const DevJob* __restrict__ jobs, int njobs, DevResult* __re
     }
     const bool banded = !(2ull * ub + 1 >= n);
     const Operand rows{sht, 0, false}, cols{lng, 0, false};
+    if constexpr (STRIPS) {
+      constexpr uint32_t SR = 64u * R;
+      uint32_t* bnd = reinterpret_cast<uint32_t*>(ws + job.ws_off);
+      const size_t bw = strip_bnd_bytes(n) / 4;
+      uint32_t done = 0;
+      for (uint32_t k = 0; done < m; ++k, done += SR) {
+        const uint32_t part = min(SR, m - done);
+        const Operand rs{sht + done, 0, false};
+        const uint32_t* tp = k ? bnd + ((k - 1) & 1) * bw : nullptr;
+        uint32_t* bt = done + part < m ? bnd + (k & 1) * bw : nullptr;
+        if (banded) lev_sweep<R, false, false, false, false, true>(rs, part, cols, n, lane, cur, minv, minpos, best, nullptr, ub, done, tp, bt);
+        else        lev_sweep<R, false, false, false, false, false>(rs, part, cols, n, lane, cur, minv, minpos, best, nullptr, 0, done, tp, bt);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // the next strip reads this strip's last row
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+      const uint32_t lrow = m - (done - SR);
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        if (lane * R + r + 1 == lrow) { res->status = 0; res->v[1] = (int32_t)cur[r]; res->v[0] = cur[r] <= ub ? 1 : 0; }
+      return;
+    }
     if (banded) lev_sweep<R, false, false, false, false, true>(rows, m, cols, n, lane, cur, minv, minpos, best, nullptr, ub);
     else        lev_sweep<R, false, false, false, false, false>(rows, m, cols, n, lane, cur, minv, minpos, best, nullptr);
     if (m == 0) { if (lane == 0) { res->status = 0; res->v[1] = (int32_t)n; res->v[0] = n <= ub ? 1 : 0; } return; }
@@ -332,7 +418,23 @@ void lev_wave_kernel(const DevJob* __restrict__ jobs, int njobs, DevResult* __re
       if (lane * R + r + 1 == m) { res->status = 0; res->v[1] = (int32_t)cur[r]; res->v[0] = cur[r] <= ub ? 1 : 0; }
   } else {  // MODE_AFFIX
     const Operand rows{job.a, 0, false}, cols{job.b, 0, false};
-    lev_sweep<R, false, false, false, true>(rows, job.la, cols, job.lb, lane, cur, minv, minpos, best, nullptr);
+    if constexpr (STRIPS) {
+      constexpr uint32_t SR = 64u * R;
+      uint32_t* bnd = reinterpret_cast<uint32_t*>(ws + job.ws_off);
+      const size_t bw = strip_bnd_bytes(job.lb) / 4;
+      uint32_t done = 0;
+      for (uint32_t k = 0; done < job.la; ++k, done += SR) {
+        const uint32_t part = min(SR, job.la - done);
+        const Operand rs{job.a + done, 0, false};
+        lev_sweep<R, false, false, false, true>(rs, part, cols, job.lb, lane, cur, minv, minpos, best, nullptr, 0, done,
+                                                k ? bnd + ((k - 1) & 1) * bw : nullptr, done + part < job.la ? bnd + (k & 1) * bw : nullptr);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // the next strip reads this strip's last row
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+    } else {
+      lev_sweep<R, false, false, false, true>(rows, job.la, cols, job.lb, lane, cur, minv, minpos, best, nullptr);
+    }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {       // wave-wide arg-best
       AffixBest o;
@@ -585,20 +687,23 @@ void align_traceback_wave_kernel(const DevJob* __restrict__ jobs, int njobs,
   }
   uint8_t* win = s_win[wv];
   uint8_t* path = s_path[wv];
-  const uint32_t R = job.r_class, EB = R <= 4 ? 1u : R / 4;
+  const bool strips = job.r_class == ROW_CLASS_STRIPS;     // more than 4096 rows: strips of 64*64 rows
+  const uint32_t R = strips ? 64u : job.r_class, EB = R <= 4 ? 1u : R / 4;
   const uint32_t lgR = 31u - (uint32_t)__builtin_clz(R);   // R is a power of two
   const uint32_t WS = TB_WIN_BYTES / (64u * EB);           // sweep steps per window
-  const uint8_t* dirs = ws + job.ws_off;
+  const uint8_t* dirs = ws + job.ws_off + (strips ? 2 * strip_bnd_bytes(m) : 0);
+  const size_t strip_dirs = ((size_t)m + 64) * 64 * EB;
   uint32_t i = n, j = m, k = 0, np = 0;
   uint32_t i0 = n, j0 = m, pos = cap - 1;
   if (lane == 0) { ea[pos] = 0; ga[pos] = 0; }
-  uint32_t s_lo = 1u, s_hi = 0u;                           // empty window
+  uint32_t s_lo = 1u, s_hi = 0u, win_strip = 0;            // empty window
   while (i > 0 && j > 0) {
-    const uint32_t l = (i - 1) >> lgR, r = (i - 1) & (R - 1), s = (j - 1) + l;
-    if (s < s_lo || s > s_hi) {                            // bring in the steps (s - WS, s]
-      s_hi = s; s_lo = s + 1 >= WS ? s + 1 - WS : 0;
+    const uint32_t strip = strips ? (i - 1) >> 12 : 0u, li = strips ? (i - 1) & 4095u : i - 1;
+    const uint32_t l = li >> lgR, r = li & (R - 1), s = (j - 1) + l;
+    if (s < s_lo || s > s_hi || strip != win_strip) {      // bring in the steps (s - WS, s] of the strip
+      s_hi = s; s_lo = s + 1 >= WS ? s + 1 - WS : 0; win_strip = strip;
       const uint32_t bytes = (s_hi - s_lo + 1) * 64u * EB;
-      const uint8_t* src = dirs + (size_t)s_lo * 64u * EB;
+      const uint8_t* src = dirs + strip * strip_dirs + (size_t)s_lo * 64u * EB;
       for (uint32_t off = lane * 16u; off < bytes; off += 64u * 16u)
         *reinterpret_cast<uint4*>(win + off) = *reinterpret_cast<const uint4*>(src + off);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -936,6 +1041,11 @@ void launch_lev_r(const DevJob* jobs, int njobs, DevResult* res, uint8_t* ws, hi
 
 template <int MODE>
 void launch_lev_mode(int R, const DevJob* jobs, int njobs, DevResult* res, uint8_t* ws, hipStream_t st) {
+  if (R == (int)ROW_CLASS_STRIPS) {                 // > 4096 rows: one wave per job, strips of 4096 rows
+    if constexpr (MODE != MODE_BORDERS)
+      hipLaunchKernelGGL((lev_wave_kernel<64, MODE, true>), dim3((njobs + 3) / 4), dim3(256), 0, st, jobs, njobs, res, ws);
+    return;
+  }
   switch (R) {
     case 1:  launch_lev_r<MODE, 1>(jobs, njobs, res, ws, st); break;
     case 2:  launch_lev_r<MODE, 2>(jobs, njobs, res, ws, st); break;

@@ -40,5 +40,9 @@ void launch_lcf_finish(const DevJob* jobs, int njobs, DevResult* res,
                        const unsigned long long* keys, hipStream_t st);
 
 // bytes of one traceback entry (all rows of one lane in one column)
-static inline uint32_t align_entry_bytes(uint32_t R) { return R <= 4 ? 1u : R / 4; }
+// row class of jobs with more than 4096 rows: run by the R = 64 kernels in strips of 4096 rows
+constexpr uint32_t ROW_CLASS_STRIPS = 128;
+// one boundary row (the last row of a strip, per column) in the job's workspace; there are two
+__host__ __device__ inline size_t strip_bnd_bytes(uint32_t nc) { return (((size_t)nc + 1) * 4 + 15) & ~(size_t)15; }
+static inline uint32_t align_entry_bytes(uint32_t R) { return R == ROW_CLASS_STRIPS ? 16u : (R <= 4 ? 1u : R / 4); }
 static inline uint32_t gap_entry_bytes(uint32_t R) { return R; }

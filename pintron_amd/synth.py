@@ -143,3 +143,40 @@ def write_files(w: Workload, directory: str) -> None:
         f.write(w.genomic_fasta())
     with open(os.path.join(directory, "ests.txt"), "w") as f:
         f.write(w.ests_fasta())
+
+
+def make_long_transcripts(seed=77):
+    """A gene with a 5.6 kb last exon and full-length transcripts of it (RefSeq-like input): DP
+    matrices with more than 4096 rows.  Returns (genomic_fasta_text, ests_fasta_text)."""
+    import random
+    rng = random.Random(seed)
+
+    def rs(n):
+        return "".join(rng.choice("ACGT") for _ in range(n))
+
+    def mut(s, rate):
+        out = []
+        for c in s:
+            x = rng.random()
+            if x < rate * 0.6:
+                out.append(rng.choice("ACGT"))
+            elif x < rate * 0.8:
+                pass
+            elif x < rate:
+                out.append(c)
+                out.append(rng.choice("ACGT"))
+            else:
+                out.append(c)
+        return "".join(out)
+
+    exons = [rs(350), rs(420), rs(5600)]
+    introns = ["GT" + rs(1500) + "AG", "GT" + rs(2500) + "AG"]
+    gen = rs(3000) + exons[0] + introns[0] + exons[1] + introns[1] + exons[2] + rs(3000)
+    tr = "".join(exons)
+    ests = [mut(tr, 0.01), mut(tr[200:], 0.02), mut(tr[:3000], 0.01), mut(tr[500:6300], 0.03) + "A" * 30]
+    for _ in range(20):
+        a = rng.randint(0, len(tr) - 700)
+        ests.append(mut(tr[a:a + rng.randint(400, 700)], 0.02))
+    g = ">chrL:1:%d:+1\n%s\n" % (len(gen), gen)
+    e = "".join(">/gb=LNG%04d /clone_end=3'\n%s\n" % (i, x) for i, x in enumerate(ests))
+    return g, e

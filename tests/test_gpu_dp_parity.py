@@ -57,11 +57,33 @@ def test_large_rows(gpu_ctx, O):
     # over the limit: per-job ERANGE, the rest of the batch still runs
     jl = capi.JobList()
     big = D.rand_seq(rng, 4097)
-    jl.add(capi.ALIGN, big, big[:-1] + b"A")
+    jl.add(capi.BORDERS, big, big[:-1] + b"A", p0=0, p1=4097, p2=3)
     jl.add(capi.ED, b"ACGT", b"ACGA")
+    jl.add(capi.GAP, big[:2049], big)
     out = capi.run_jobs(gpu_ctx, jl)
     assert out[0]["status"] == capi.PGPU_ERANGE
     assert out[1] == dict(status=0, score=1)
+    assert out[2]["status"] == capi.PGPU_ERANGE
+
+
+def test_strips_beyond_4096_rows(gpu_ctx, O):
+    """More than 4096 rows: the R = 64 kernels sweep the matrix in strips of 4096 rows (long 3' UTR
+    exons of full-length mRNAs).  Sizes around the strip boundaries, square and ragged."""
+    rng = random.Random(31)
+    cases = []
+    for n, m in ((4097, 4097), (5000, 700), (8192, 8300), (8193, 40), (9000, 9100), (12289, 6000)):
+        a, b = D.pair(rng, max(n, m), 0.03, 0.001)
+        a, b = a[:n], b[:m]
+        cases.append(D.Case(D.ALIGN, a, b))
+        cases.append(D.Case(D.ED, a, b))
+        cases.append(D.Case(D.ED, b, a))
+        cases.append(D.Case(D.KBAND, a, b, p0=max(n, m) // 25))
+        cases.append(D.Case(D.KBAND, a, b, p0=max(n, m)))
+        cases.append(D.Case(D.AFFIX, a, b))
+    big = D.rand_seq(rng, 6000)
+    cases.append(D.Case(D.ALIGN, big, big))                  # identity shortcut at that size
+    cases.append(D.Case(D.ALIGN, big, b""))
+    run_and_check(gpu_ctx, O, cases)
 
 
 def test_cooperative_kernels_at_class_boundaries(gpu_ctx, O):

@@ -71,6 +71,26 @@ def test_other_configs_vs_compiled_reference(exe, tmp_path, cfg, n_est):
         assert filecmp.cmp(my_dir / f, ref_dir / f, shallow=False), f
 
 
+def test_long_transcripts_vs_compiled_reference(exe, tmp_path):
+    """Full-length transcripts with a 5.6 kb exon: alignments, K-band distances and affix searches
+    with more than 4096 rows (strips) inside the whole program."""
+    ref = os.path.join(ROOT, "oracle", "_ref", "est-fact-ref")
+    if not os.path.exists(ref):
+        pytest.skip("oracle/_ref/est-fact-ref not present")
+    from pintron_amd import synth
+    g, e = synth.make_long_transcripts()
+    ref_dir, my_dir = tmp_path / "ref", tmp_path / "mine"
+    for d in (ref_dir, my_dir):
+        d.mkdir()
+        (d / "genomic.txt").write_text(g)
+        (d / "ests.txt").write_text(e)
+    subprocess.run([ref], cwd=ref_dir, check=True, stderr=subprocess.DEVNULL)
+    subprocess.run([exe], cwd=my_dir, check=True)
+    for f in FILES:
+        assert filecmp.cmp(my_dir / f, ref_dir / f, shallow=False), f
+    assert os.path.getsize(my_dir / "raw-multifasta-out.txt") > 50000
+
+
 def test_session_steps_are_idempotent(exe, tmp_path):
     """The bench's step: two passes over the resident batch give the same text, equal to the files
     the binary writes."""

@@ -60,6 +60,22 @@ def test_synthetic_sample_matches_compiled_reference(bins, tmp_path):
     assert os.path.getsize(my_dir / "raw-multifasta-out.txt") > 10000
 
 
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
+def test_long_transcripts_match_compiled_reference(bins, tmp_path):
+    """Exons of several kb (full-length mRNAs): the host logic has no size limits of its own."""
+    from pintron_amd import synth
+    g, e = synth.make_long_transcripts()
+    ref_dir, my_dir = tmp_path / "ref", tmp_path / "mine"
+    for d in (ref_dir, my_dir):
+        d.mkdir()
+        (d / "genomic.txt").write_text(g)
+        (d / "ests.txt").write_text(e)
+    subprocess.run([os.path.join(O.REF_DIR, "est-fact-ref")], cwd=ref_dir, check=True, stderr=subprocess.DEVNULL)
+    run(bins["estfact_sched_check"], my_dir, {"PINTRON_THREADS": "2"})
+    for f in FILES:
+        assert filecmp.cmp(my_dir / f, ref_dir / f, shallow=False), f
+
+
 def test_cli_options_and_config_dump(bins, tmp_path):
     for f in ("genomic.txt", "ests.txt"):
         shutil.copy(os.path.join(GOLD, f), tmp_path)
