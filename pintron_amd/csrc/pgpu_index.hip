@@ -25,10 +25,19 @@
 
 #include "pgpu_index.h"
 
+// The first KTAB characters of a pattern position select the suffix-array interval of that
+// KTAB-mer from a table (2 x 4^KTAB x 4 B = 512 KB, L2-resident) instead of ~2 x 17 bisection
+// steps over the whole array; the bisection continues inside that interval (a handful of
+// suffixes) from character KTAB on.  Only upper-case ACGT k-mers are tabulated.
+constexpr uint32_t KTAB = 8;
+constexpr uint32_t KTAB_ENTRIES = 1u << (2 * KTAB);
+
 struct pgpu_index {
   uint8_t* d_gen = nullptr;
   uint32_t* d_sa = nullptr;
   uint32_t* d_lcp = nullptr;      // n+1 entries; lcp[0] = lcp[n] = 0
+  uint32_t* d_klo = nullptr;      // [code] -> first suffix-array index of the k-mer (klo == khi: absent)
+  uint32_t* d_khi = nullptr;
   size_t len = 0;
 };
 
@@ -75,6 +84,34 @@ __global__ void lcp_kernel(const uint8_t* __restrict__ T, const uint32_t* __rest
   const uint32_t lim = n - (a > b ? a : b);
   while (h < lim && T[a + h] == T[b + h]) ++h;
   lcp[k] = h;
+}
+
+__device__ __forceinline__ int kmer_base(uint32_t c) {
+  return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : -1;
+}
+// 2-bit code of s[0..KTAB), or -1 when a character is not A/C/G/T (`avail` readable characters)
+__device__ __forceinline__ int kmer_code(const uint8_t* __restrict__ s, uint32_t avail) {
+  if (avail < KTAB) return -1;
+  int code = 0;
+#pragma unroll
+  for (uint32_t x = 0; x < KTAB; ++x) {
+    const int b = kmer_base(s[x]);
+    if (b < 0) return -1;
+    code = (code << 2) | b;
+  }
+  return code;
+}
+// suffixes sharing a KTAB-mer are contiguous in the suffix array: mark where each run starts/ends
+__global__ void kmer_table_kernel(const uint8_t* __restrict__ T, uint32_t n, const uint32_t* __restrict__ sa,
+                                  uint32_t* __restrict__ klo, uint32_t* __restrict__ khi) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const int c = kmer_code(T + sa[k], n - sa[k]);
+  if (c < 0) return;
+  const int prev = k > 0 ? kmer_code(T + sa[k - 1], n - sa[k - 1]) : -1;
+  const int next = k + 1 < n ? kmer_code(T + sa[k + 1], n - sa[k + 1]) : -1;
+  if (prev != c) klo[c] = k;
+  if (next != c) khi[c] = k + 1;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -133,6 +170,7 @@ __device__ __forceinline__ uint32_t extend(const uint8_t* __restrict__ T, uint32
 // one wave per pattern, lanes stride over its positions
 __global__ __launch_bounds__(64)
 void pair_locate_kernel(const uint8_t* __restrict__ T, uint32_t n, const uint32_t* __restrict__ sa,
+                        const uint32_t* __restrict__ klo, const uint32_t* __restrict__ khi,
                         const uint8_t* __restrict__ pats, const unsigned long long* __restrict__ pat_off,
                         PairParams prm, uint32_t* __restrict__ lo_out, uint32_t* __restrict__ hi_out,
                         uint32_t* __restrict__ a_out) {
@@ -142,7 +180,13 @@ void pair_locate_kernel(const uint8_t* __restrict__ T, uint32_t n, const uint32_
   for (uint32_t i = threadIdx.x; i < m; i += 64) {
     uint32_t lo = 0, hi = 0, A = 0;
     if (m - i >= prm.L) {
-      sa_interval(T, n, sa, P + i, prm.L, 0, 0, n, &lo, &hi);
+      const int code = prm.L >= KTAB ? kmer_code(P + i, m - i) : -1;
+      if (code >= 0) {                              // the k-mer's run, then bisect on characters KTAB..L
+        const uint32_t from = klo[code], to = khi[code];
+        if (from < to) sa_interval(T, n, sa, P + i, prm.L, KTAB, from, to, &lo, &hi);
+      } else {
+        sa_interval(T, n, sa, P + i, prm.L, 0, 0, n, &lo, &hi);
+      }
       for (uint32_t k = lo; k < hi; ++k) {
         const uint32_t t = sa[k];
         if (prev_excluded(T, t, P, i)) continue;
@@ -381,11 +425,16 @@ extern "C" int pgpu_index_build(pgpu_ctx* ctx, const char* genomic, size_t len, 
     }
   }
   hipLaunchKernelGGL(lcp_kernel, grd, blk, 0, st, idx->d_gen, idx->d_sa, n, idx->d_lcp);
+  TRY_HIP(dmalloc(&idx->d_klo, KTAB_ENTRIES));
+  TRY_HIP(dmalloc(&idx->d_khi, KTAB_ENTRIES));
+  TRY_HIP(hipMemsetAsync(idx->d_klo, 0, KTAB_ENTRIES * sizeof(uint32_t), st));
+  TRY_HIP(hipMemsetAsync(idx->d_khi, 0, KTAB_ENTRIES * sizeof(uint32_t), st));
+  if (n > 0) hipLaunchKernelGGL(kmer_table_kernel, grd, blk, 0, st, idx->d_gen, n, idx->d_sa, idx->d_klo, idx->d_khi);
   TRY_HIP(hipStreamSynchronize(st));
   TRY_HIP(hipGetLastError());
 done:
   hipFree(rank); hipFree(sa2); hipFree(flags); hipFree(newrank); hipFree(keys); hipFree(keys2); hipFree(tmp);
-  if (rc != PGPU_OK) { hipFree(idx->d_gen); hipFree(idx->d_sa); hipFree(idx->d_lcp); delete idx; return rc; }
+  if (rc != PGPU_OK) { hipFree(idx->d_gen); hipFree(idx->d_sa); hipFree(idx->d_lcp); hipFree(idx->d_klo); hipFree(idx->d_khi); delete idx; return rc; }
   *out = idx;
   return PGPU_OK;
 }
@@ -393,7 +442,7 @@ done:
 extern "C" int pgpu_index_destroy(pgpu_ctx* ctx, pgpu_index* idx) {
   if (!ctx || !idx) return PGPU_EINVAL;
   hipStreamSynchronize(pgpu_ctx_stream(ctx));
-  hipFree(idx->d_gen); hipFree(idx->d_sa); hipFree(idx->d_lcp);
+  hipFree(idx->d_gen); hipFree(idx->d_sa); hipFree(idx->d_lcp); hipFree(idx->d_klo); hipFree(idx->d_khi);
   delete idx;
   return PGPU_OK;
 }
@@ -509,7 +558,7 @@ extern "C" int pgpu_pairing_plan_run(pgpu_ctx* ctx, pgpu_pairing_plan* p, const 
   if (p->n_pat == 0) return PGPU_OK;
   size_t b;
   if (p->ev[0]) TRY_HIP(hipEventRecord(p->ev[0], st));
-  hipLaunchKernelGGL(pair_locate_kernel, pgrid, pblk, 0, st, ix->d_gen, n, ix->d_sa, p->d_pats, p->d_pat_off, prm, p->d_lo, p->d_hi, p->d_a);
+  hipLaunchKernelGGL(pair_locate_kernel, pgrid, pblk, 0, st, ix->d_gen, n, ix->d_sa, ix->d_klo, ix->d_khi, p->d_pats, p->d_pat_off, prm, p->d_lo, p->d_hi, p->d_a);
   if (p->ev[1]) TRY_HIP(hipEventRecord(p->ev[1], st));
   hipLaunchKernelGGL(pair_chain_kernel, dim3((unsigned)((p->n_pat + 63) / 64)), pblk, 0, st, ix->d_gen, n, ix->d_sa, ix->d_lcp,
                      p->d_pats, p->d_pat_off, (uint32_t)p->n_pat, prm, p->d_lo, p->d_hi, p->d_a, p->d_thr);
