@@ -105,6 +105,27 @@ template <int R> struct DirPack {          // 2 bits per row, R rows
 
 struct AffixBest {          // running best cut of find_longest_affix
   uint32_t valid, v, s, e, g;
+  // One cell of the scan, branch-free (a lone wave pays for every taken branch): the cell is a
+  // candidate when the characters match and 200*v <= 17*(e+g); it replaces the running best when
+  // its weight v/(e+g) is smaller, or equal with a later (e,g).  `small`: e+g < 2^15, so every
+  // product fits 24x24 -> 32 bits (full-rate v_mul_u32_u24); otherwise 64-bit products.
+  template <bool SMALL>
+  __device__ __forceinline__ void consider(bool match, uint32_t cv, uint32_t ce, uint32_t cg) {
+    const uint32_t cs = ce + cg;
+    bool cand, less, equal;
+    if constexpr (SMALL) {
+      cand = match & (__umul24(200u, cv) <= __umul24(17u, cs));
+      const uint32_t lhs = __umul24(cv, s), rhs = __umul24(v, cs);
+      less = lhs < rhs; equal = lhs == rhs;
+    } else {
+      cand = match & (200ull * cv <= 17ull * cs);
+      const uint64_t lhs = (uint64_t)cv * s, rhs = (uint64_t)v * cs;
+      less = lhs < rhs; equal = lhs == rhs;
+    }
+    const bool later = (ce > e) | ((ce == e) & (cg > g));
+    const bool take = cand & ((valid == 0u) | less | (equal & later));
+    valid = take ? 1u : valid; v = take ? cv : v; s = take ? cs : s; e = take ? ce : e; g = take ? cg : g;
+  }
   // true when candidate (cv/cs, ce, cg) replaces (v/s, e, g) under the reference's scan rule:
   // smaller weight wins, equal weight -> the cell scanned later (larger (e,g)) wins.
   __device__ __forceinline__ bool worse_than(uint32_t cv, uint32_t cs, uint32_t ce, uint32_t cg) const {
@@ -123,7 +144,7 @@ constexpr uint32_t BAND_INF = 0x3FFFFFu;   // "outside the band"; stays below th
 // the row above the first row (`top`) of the next strip; `row_base` = rows before this strip.
 // The boundary values go through memory written and read by one wave: agent-scope atomics keep
 // the per-CU L1 out of the way.
-template <int R, bool WILD, bool DIRS, bool ROWMIN, bool AFFIX, bool BAND = false>
+template <int R, bool WILD, bool DIRS, bool ROWMIN, bool AFFIX, bool BAND = false, bool ASMALL = false>
 __device__ __forceinline__ void lev_sweep(const Operand rows, const uint32_t nr,
                                           const Operand cols, const uint32_t nc,
                                           const uint32_t lane, uint32_t (&cur)[R],
@@ -205,11 +226,8 @@ __device__ __forceinline__ void lev_sweep(const Operand rows, const uint32_t nr,
           if (minv[r] > v) { minv[r] = v; minpos[r] = j; }   // strict: first arg-min
         }
         if constexpr (AFFIX) {
-          const uint32_t e = row_base + row0 + r + 1, sum = e + j;
           // cut_weight = 2*v/(e+g) <= 0.17  <=>  200*v <= 17*(e+g)   (exact)
-          if (rc[r] == ch && 200u * v <= 17u * sum && best.worse_than(v, sum, e, j)) {
-            best.valid = 1; best.v = v; best.s = sum; best.e = e; best.g = j;
-          }
+          best.template consider<ASMALL>(rc[r] == ch, v, row_base + row0 + r + 1, j);
         }
         diag = left;
         cur[r] = v;
@@ -432,6 +450,8 @@ void lev_wave_kernel(const DevJob* __restrict__ jobs, int njobs, DevResult* __re
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       }
+    } else if (job.la + job.lb < 32768u) {
+      lev_sweep<R, false, false, false, true, false, true>(rows, job.la, cols, job.lb, lane, cur, minv, minpos, best, nullptr);
     } else {
       lev_sweep<R, false, false, false, true>(rows, job.la, cols, job.lb, lane, cur, minv, minpos, best, nullptr);
     }
@@ -463,7 +483,7 @@ void lev_wave_kernel(const DevJob* __restrict__ jobs, int njobs, DevResult* __re
 // travel with the wavefront, so only wave 0 reads them from memory.
 constexpr int COOP_W = 4;
 
-template <int R, bool ROWMIN, bool AFFIX>
+template <int R, bool ROWMIN, bool AFFIX, bool ASMALL = false>
 __device__ __forceinline__ void lev_sweep_coop(const Operand rows, const uint32_t nr,
                                                const Operand cols, const uint32_t nc,
                                                const uint32_t w, const uint32_t lane,
@@ -471,7 +491,7 @@ __device__ __forceinline__ void lev_sweep_coop(const Operand rows, const uint32_
                                                uint32_t (&cur)[R], uint32_t (&minv)[R],
                                                uint32_t (&minpos)[R], AffixBest& best) {
   uint32_t rc[R];
-  const uint32_t gl = w * 64u + lane;   // lane index within the job
+  const uint32_t gl = w * 64u + lane;   // lane index within the job (w is wave-uniform)
   const uint32_t row0 = gl * R;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
@@ -524,12 +544,7 @@ __device__ __forceinline__ void lev_sweep_coop(const Operand rows, const uint32_
             if constexpr (ROWMIN) {
               if (minv[r] > v) { minv[r] = v; minpos[r] = j; }
             }
-            if constexpr (AFFIX) {
-              const uint32_t e = row0 + r + 1, sum = e + j;
-              if (rc[r] == ch && 200u * v <= 17u * sum && best.worse_than(v, sum, e, j)) {
-                best.valid = 1; best.v = v; best.s = sum; best.e = e; best.g = j;
-              }
-            }
+            if constexpr (AFFIX) best.template consider<ASMALL>(rc[r] == ch, v, row0 + r + 1, j);
             diag = left;
             cur[r] = v;
             up = v;
@@ -552,7 +567,8 @@ void borders_coop_kernel(const DevJob* __restrict__ jobs, int njobs, DevResult* 
   extern __shared__ uint32_t lds[];      // hand-off [2][COOP_W-1][2][64], then pre, pre_pos, suf, suf_pos
   const DevJob job = jobs[blockIdx.x];
   DevResult* res = &results[job.out_idx];
-  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // scalar: branches on it are uniform
   const uint32_t sweep = wave / COOP_W, w = wave % COOP_W;
   const uint32_t len_p = job.la, len_t = job.lb, max_errs = job.p2;
   const uint32_t t_win = min(len_p + max_errs, len_t);
@@ -605,11 +621,14 @@ void affix_coop_kernel(const DevJob* __restrict__ jobs, int njobs, DevResult* __
   __shared__ uint32_t wbest[COOP_W][5];
   const DevJob job = jobs[blockIdx.x];
   DevResult* res = &results[job.out_idx];
-  const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   uint32_t cur[R], minv[R], minpos[R];
   AffixBest best{0, 0, 0, 0, 0};
   const Operand rows{job.a, 0, false}, cols{job.b, 0, false};
-  lev_sweep_coop<R, false, true>(rows, job.la, cols, job.lb, w, lane, hand, cur, minv, minpos, best);
+  // e + g < 2^15: every product of the cut test fits 24 x 24 -> 32 bits (AffixBest::consider)
+  if (job.la + job.lb < 32768u) lev_sweep_coop<R, false, true, true>(rows, job.la, cols, job.lb, w, lane, hand, cur, minv, minpos, best);
+  else                          lev_sweep_coop<R, false, true, false>(rows, job.la, cols, job.lb, w, lane, hand, cur, minv, minpos, best);
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {
     AffixBest o;
