@@ -170,6 +170,13 @@ def main():
                                "frac": ach / HBM_PEAK_GBS if ach else None, "traffic": pmc_traffic(name),
                                "avg_launch_ms": per_launch_ms, "launches_per_step": dom["launches"],
                                "algo_bytes_per_launch": dom["algo_bytes"] / max(dom["launches"], 1)}
+            # integer DP: the arithmetic bound is VALU issue, not MFMA.  Chip peak = 256 CU x 4 SIMD x 32
+            # lanes/cycle x 2.4 GHz lane-ops/s (MI355X_MICROARCH.md); a unit-cost cell needs >= 6 VALU ops
+            if dom["cells"] and dom["ms"]:
+                peak_cells = 256 * 4 * 32 * 2.4e9 / 6.0
+                ach_cells = dom["cells"] / (dom["ms"] * 1e-3)
+                out["roofline"]["valu"] = {"achieved": ach_cells / 1e9, "peak": peak_cells / 1e9, "unit": "Gcells/s",
+                                           "frac": ach_cells / peak_cells, "ops_per_cell_assumed": 6}
             out["kernels"] = [{"name": n, "ms_per_step": round(k["ms"], 3), "launches": round(k["launches"], 1),
                                "jobs": int(k["jobs"]),
                                "algo_GBs": round(k["algo_bytes"] / (k["ms"] * 1e-3) / 1e9, 1) if k["ms"] and k["algo_bytes"] else None}
