@@ -9,13 +9,18 @@ import dp_cases as D
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def load():
+def load(name="dp_calls.jsonl.gz", genomic=None):
+    """(Case, expected) pairs of a capture file.  `genomic`: for captures whose LCF records only
+    name the length of the genomic prefix (c3_sample_jobs.jsonl.gz)."""
     out = []
-    with gzip.open(os.path.join(GOLD, "dp_calls.jsonl.gz"), "rt") as f:
+    with gzip.open(os.path.join(GOLD, name), "rt") as f:
         for line in f:
             r = json.loads(line)
-            a, b = r["a"].encode("latin1"), r["b"].encode("latin1")
             k = r["k"]
+            if k == "META":
+                continue
+            a = genomic[: r["a_gen_len"]] if "a_gen_len" in r else r["a"].encode("latin1")
+            b = r["b"].encode("latin1")
             if k == "ALIGN":
                 out.append((D.Case(D.ALIGN, a, b), dict(score=r["score"], dim=r["dim"], ea=r["ea"].encode(), ga=r["ga"].encode())))
             elif k == "GAP":
@@ -35,3 +40,13 @@ def load():
             elif k == "AFFIX":
                 out.append((D.Case(D.AFFIX, a, b), dict(valid=r["valid"], ecut=r["ecut"], gcut=r["gcut"])))
     return out
+
+
+def load_c3_sample():
+    """10 061 DP calls the unmodified reference made on a seeded 400-EST C3 sample
+    (tools/make_c3_golden.py) with its answers; the genomic sequence is regenerated."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from pintron_amd import synth
+    w = synth.make("C3", n_est=400, seed=3)
+    return load("c3_sample_jobs.jsonl.gz", genomic=w.genomic)

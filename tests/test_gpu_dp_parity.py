@@ -30,6 +30,12 @@ def test_golden_vectors(gpu_ctx, O):
     run_and_check(gpu_ctx, O, [c for c, _ in pairs], [e for _, e in pairs])
 
 
+def test_c3_sample_golden_vectors(gpu_ctx, O):
+    """10 061 DP calls of the unmodified reference on a C3-shaped sample, with ITS answers."""
+    pairs = G.load_c3_sample()
+    run_and_check(gpu_ctx, O, [c for c, _ in pairs], [e for _, e in pairs])
+
+
 def test_edge_cases(gpu_ctx, O):
     run_and_check(gpu_ctx, O, D.edge_cases())
 

@@ -27,3 +27,11 @@ def test_golden_dp_calls(O):
     assert kinds == set(range(7))
     bad = [(c, e) for c, e in cases if not D.check_case(c, c.expected(O), O, expected=e)]
     assert not bad, "%d golden mismatches, first %r expected %r" % (len(bad), *bad[0])
+
+
+def test_c3_sample_calls(O):
+    """The oracle against every DP call (and answer) of the reference on a C3-shaped sample."""
+    cases = G.load_c3_sample()
+    assert len(cases) > 10000
+    bad = [(c, e) for c, e in cases if not D.check_case(c, c.expected(O), O, expected=e)]
+    assert not bad, "%d golden mismatches, first %r expected %r" % (len(bad), *bad[0])

@@ -8,7 +8,8 @@ interposed, so its calls in search_small_exon_at_prefix (src/factorization-refin
 are reconstructed from the reference's own raw-multifasta-out.txt: one call
 LCF(GEN[0..GEN_start), EST[EST_start-eplen..EST_start)) per output factorization whose first exon
 satisfies the routine's entry condition (:517-519); its expected output comes from the compiled
-static routine (oracle/ref_static_access.c).  bench.py tiles this file to the C3 batch size.
+static routine (oracle/ref_static_access.c).  Used as golden vectors by tests/test_oracle_golden.py
+and tests/test_gpu_dp_parity.py (tests/golden_cases.py: load_c3_sample).
 """
 import gzip
 import json
