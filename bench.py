@@ -35,7 +35,7 @@ N_EST_BATCH = 100_000          # C3
 CPU_SAMPLE = 3000              # ESTs of the same workload given to the reference CPU est-fact
 
 
-from pintron_amd.estfact import Session, gather_bytes, load_host_lib  # noqa: E402
+from pintron_amd.estfact import Session, gather_tensor, load_host_lib  # noqa: E402
 
 
 def rocprof_symbol(group_name):
@@ -114,7 +114,7 @@ def main():
         st = sess.step()
         if world > 1:
             # the only exchange of the sharded path: per-EST output records -> rank 0 (RCCL)
-            gather_bytes(sess.records(), dist, rank, world, "cuda")
+            gather_tensor(sess.output_tensor(0), dist, rank, world, "cuda")
         return st
 
     def fence():

@@ -84,6 +84,19 @@ class Session:
     def records(self) -> bytes:
         return self.output(0)
 
+    def output_tensor(self, which: int):
+        """The same text as a torch uint8 tensor (one copy out of the C buffer, none through bytes)."""
+        import torch
+        n = C.c_size_t()
+        p = self.L.ef_session_output(self.h, which, C.byref(n))
+        try:
+            if n.value == 0:
+                return torch.empty(0, dtype=torch.uint8)
+            view = (C.c_ubyte * n.value).from_address(p)
+            return torch.frombuffer(view, dtype=torch.uint8).clone()
+        finally:
+            C.CDLL(None).free(C.c_void_p(p))
+
     def close(self):
         if self.h:
             self.L.ef_session_close(self.h)
@@ -120,22 +133,32 @@ def partition(weights, world):
     return [(bounds[r], bounds[r + 1]) for r in range(world)]
 
 
-def gather_bytes(data: bytes, dist, rank, world, device):
-    """Variable-length gather to rank 0: all_gather of the byte counts, then one gather of the
-    padded payloads (RCCL on GPUs, gloo on CPU).  Returns the list of payloads on rank 0."""
+def gather_tensor(t, dist, rank, world, device):
+    """Variable-length gather of a uint8 tensor to rank 0: all_gather of the byte counts, then one
+    gather of the padded payloads (RCCL on GPUs, gloo on CPU).  Returns the list of per-rank
+    tensors (on `device`, trimmed) on rank 0, None elsewhere."""
     import torch
-    t = torch.frombuffer(bytearray(data) or bytearray(1), dtype=torch.uint8)[: len(data)].to(device)
-    n = torch.tensor([len(data)], dtype=torch.int64, device=device)
+    n = torch.tensor([t.numel()], dtype=torch.int64, device=device)
     sizes = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(sizes, n)
     sizes = [int(s.item()) for s in sizes]
-    pad = torch.zeros(max(max(sizes), 1), dtype=torch.uint8, device=device)
-    pad[: len(data)] = t
+    pad = torch.empty(max(max(sizes), 1), dtype=torch.uint8, device=device)
+    pad[: t.numel()] = t.to(device)
     outl = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
     dist.gather(pad, outl, dst=0)
     if rank != 0:
         return None
-    return [bytes(o[: sizes[r]].cpu().numpy().tobytes()) for r, o in enumerate(outl)]
+    return [o[: sizes[r]] for r, o in enumerate(outl)]
+
+
+def gather_bytes(data: bytes, dist, rank, world, device):
+    """gather_tensor for a bytes payload; returns the list of payloads (bytes) on rank 0."""
+    import torch
+    t = torch.frombuffer(bytearray(data), dtype=torch.uint8) if data else torch.empty(0, dtype=torch.uint8)
+    parts = gather_tensor(t, dist, rank, world, device)
+    if parts is None:
+        return None
+    return [bytes(o.cpu().numpy().tobytes()) for o in parts]
 
 
 def run_sharded(directory, workdir, dist, rank, world, device, L=None, files=(0, 1)):

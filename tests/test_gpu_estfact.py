@@ -110,5 +110,37 @@ def test_session_steps_are_idempotent(exe, tmp_path):
         assert text == open(tmp_path / f, "rb").read(), f
 
 
+RCCL_WORKER = r"""
+import os, sys
+import torch, torch.distributed as dist          # torch (and its bundled HIP runtime) first, as in bench.py
+sys.path.insert(0, %(root)r)
+from pintron_amd import estfact, synth
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", "29655")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+w = synth.make("C3", n_est=300, seed=12)
+synth.write_files(w, %(tmp)r)
+s = estfact.Session(estfact.load_host_lib(), %(tmp)r)
+s.step()
+parts = estfact.gather_tensor(s.output_tensor(0), dist, 0, 1, "cuda")
+assert len(parts) == 1 and bytes(parts[0].cpu().numpy().tobytes()) == s.records() and len(s.records()) > 10000
+assert estfact.gather_bytes(b"", dist, 0, 1, "cuda") == [b""]
+s.close()
+dist.destroy_process_group()
+print("rccl gather ok")
+"""
+
+
+def test_record_gather_over_rccl_single_rank(exe, tmp_path):
+    """The exchange bench.py performs for N > 1 (all_gather of sizes + gather of the padded records)
+    on a 1-rank RCCL group: API usage and payload integrity on the real backend.  Own process:
+    torch brings its own HIP runtime, which has to be the first one loaded (as in bench.py)."""
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(RCCL_WORKER % dict(root=ROOT, tmp=str(tmp_path)))
+    out = subprocess.run([os.sys.executable, str(script)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "rccl gather ok" in out.stdout, out.stderr[-2000:]
+
+
 def s_units(w):
     return len(w.est_seqs)
