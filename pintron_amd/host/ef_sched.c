@@ -97,6 +97,8 @@ typedef struct fiber {
   struct fiber* pool_next;   /* free fibres (struct + stack) are kept for the next EST */
 } fiber;
 
+static const char FIBER_SENTINEL[16] = "pintron-fibre-s";
+
 /* one input EST: entry `first` of the prepared list, plus the sibling at first+1 if any */
 typedef struct {
   size_t first; bool has_sibling;
@@ -313,6 +315,9 @@ static bool start_fiber(worker* w, int li) {
   else { f = (fiber*)calloc(1, sizeof(fiber)); f->stack = (char*)malloc(sh->stack_size); }
   f->w = w; f->unit = u; f->state = F_RUNNABLE; f->lane = li;
   f->be.self = f; f->be.pairings = fiber_pairings; f->be.dp = fiber_dp; f->be.dp_many = fiber_dp_many;
+  /* the stacks are plain heap blocks (no guard page): a sentinel at the low end tells an
+   * overflow apart from everything else when the fibre is done */
+  memcpy(f->stack, FIBER_SENTINEL, sizeof FIBER_SENTINEL);
   ctx_make(&f->ctx, f->stack, sh->stack_size, fiber_main, f);
   ln->fibers[ln->n_fibers++] = f;
   return true;
@@ -537,7 +542,13 @@ static void* worker_main(void* arg) {
       size_t keep = 0;
       for (size_t i = 0; i < ln->n_fibers; ++i) {
         fiber* f = ln->fibers[i];
-        if (f->state == F_DONE) { f->pool_next = w->free_fibers; w->free_fibers = f; w->stats.units++; }
+        if (f->state == F_DONE) {
+          if (memcmp(f->stack, FIBER_SENTINEL, sizeof FIBER_SENTINEL) != 0) {
+            fprintf(stderr, "* FATAL fibre stack overflow (raise PINTRON_FIBER_STACK_KB, now %zu)\n", sh->stack_size / 1024);
+            abort();
+          }
+          f->pool_next = w->free_fibers; w->free_fibers = f; w->stats.units++;
+        }
         else ln->fibers[keep++] = f;
       }
       ln->n_fibers = keep;
