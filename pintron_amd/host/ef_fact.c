@@ -14,6 +14,14 @@ typedef struct { int p, t, l; } ptl;     /* pairing inside an embedding */
 /* ---------------------------------------------------------------------------------------------- */
 /* small helpers                                                                                  */
 /* ---------------------------------------------------------------------------------------------- */
+/* strlen(real_substring(index, length, s)) for index >= 0 without the copy: the substring read in
+ * place ends at the terminator like the copy would */
+static size_t view_len(const char* s, int index, int length) {
+  size_t n = 0;
+  while ((int)n < length && s[index + n] != '\0') ++n;
+  return n;
+}
+
 char* ef_real_substring(int index, int length, const char* s) {     /* src/util.c:138-158 */
   if (index < 0) { length += index; index = 0; }
   if (length < 0) length = 0;
@@ -318,13 +326,13 @@ static void endpoint_tail_apply(ef_list* fact, ef_factor* tail, const ef_dp_res*
 }
 
 static void endpoint_request(ef_dp_req* q, const ef_factor* x, const char* gen, const char* est) {
-  char* g = ef_real_substring(x->GEN_start, x->GEN_end - x->GEN_start + 1, gen);
-  char* e = ef_real_substring(x->EST_start, x->EST_end - x->EST_start + 1, est);
-  const ef_dp_req r = { EF_DP_ALIGN, e, strlen(e), g, strlen(g), 0, 0, 0, 0 };
+  const ef_dp_req r = { EF_DP_ALIGN, est + x->EST_start, view_len(est, x->EST_start, x->EST_end - x->EST_start + 1),
+                        gen + x->GEN_start, view_len(gen, x->GEN_start, x->GEN_end - x->GEN_start + 1), 0, 0, 0, 0 };
   *q = r;
 }
 static void endpoint_release(ef_dp_req* q, ef_dp_res* r) {
-  free((char*)q->a); free((char*)q->b); free(r->s0); free(r->s1);
+  (void)q;
+  free(r->s0); free(r->s1);
 }
 
 static ef_list* handle_endpoints(ef_list* fact, const char* gen, const char* est, ef_backend* be) {
@@ -511,9 +519,9 @@ ef_list* ef_clean_noisy_exons(ef_list* fact, const char* gen, const char* est, b
     const unsigned max_err = max_edit_for_exon((size_t)(x->GEN_end - x->GEN_start + 1));
     slot[nvis] = -1;
     if (x->GEN_start <= x->GEN_end) {
-      char* g = ef_real_substring(x->GEN_start, x->GEN_end - x->GEN_start + 1, gen);
-      char* e = ef_real_substring(x->EST_start, x->EST_end - x->EST_start + 1, est);
-      const ef_dp_req q = { EF_DP_KBAND, g, strlen(g), e, strlen(e), max_err, 0, 0, 0 };
+      /* the exon on the genomic sequence and on the EST, read in place (the reference copies them) */
+      const ef_dp_req q = { EF_DP_KBAND, gen + x->GEN_start, view_len(gen, x->GEN_start, x->GEN_end - x->GEN_start + 1),
+                            est + x->EST_start, view_len(est, x->EST_start, x->EST_end - x->EST_start + 1), max_err, 0, 0, 0 };
       slot[nvis] = (int)nrq;
       rq[nrq++] = q;
     }
@@ -525,7 +533,6 @@ ef_list* ef_clean_noisy_exons(ef_list* fact, const char* gen, const char* est, b
     const bool ok = slot[v] >= 0 && rs[slot[v]].v[0] != 0;
     if (!ok) idx[n++] = first_index + (int)v;
   }
-  for (size_t k = 0; k < nrq; ++k) { free((char*)rq[k].a); free((char*)rq[k].b); }
   fact = keep_best_run(fact, idx, n);
   free(idx); free(rq); free(rs); free(slot);
   return fact;

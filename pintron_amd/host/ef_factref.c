@@ -290,12 +290,13 @@ static void small_exon_between(ef_factor* p1, ef_factor* p2, ef_iter* it, const 
   if (!((e1len + e2len) >= (LB_SMALL_EXON + 2 * UB_SMALL_EXON))) return;
   const size_t e1slen = zmin(zmin(e1len, g1len), UB_SMALL_EXON), g1slen = e1slen;
   const size_t e1sstart = (size_t)p1->EST_end + 1 - e1slen, g1sstart = (size_t)p1->GEN_end + 1 - g1slen;
-  char* e1s = ef_real_substring((int)e1sstart, (int)e1slen, E);
-  char* g1s = ef_real_substring((int)g1sstart, (int)g1slen, G);
+  /* the border strings lie inside the two exons: they are read in place (the reference copies them) */
+  const char* e1s = E + e1sstart;
+  const char* g1s = G + g1sstart;
   const size_t e2plen = zmin(zmin(e2len, g2len), UB_SMALL_EXON), g2plen = e2plen;
   const size_t e2pstart = (size_t)p2->EST_start, g2pstart = (size_t)p2->GEN_start;
-  char* e2p = ef_real_substring((int)e2pstart, (int)e2plen, E);
-  char* g2p = ef_real_substring((int)g2pstart, (int)g2plen, G);
+  const char* e2p = E + e2pstart;
+  const char* g2p = G + g2pstart;
   /* both edit distances and, for the side(s) that are not identical, the common factors the
    * reference asks for afterwards (:690-718): independent of each other, requested together */
   ef_dp_req q4[4]; ef_dp_res r4[4]; size_t n4 = 0;
@@ -399,7 +400,6 @@ static void small_exon_between(ef_factor* p1, ef_factor* p2, ef_iter* it, const 
       free(efact); free(allg);
     }
   }
-  free(e1s); free(g1s); free(e2p); free(g2p);
 }
 
 /* search_for_new_small_exons (:875-912) */

@@ -352,6 +352,14 @@ static char* padded(const char* s) {
   return r;
 }
 
+/* appends real_substring(index, length, s) (src/util.c:138-158) to dst[n..]; returns the new length */
+static size_t append_substring(char* dst, size_t n, int index, int length, const char* s) {
+  if (index < 0) { length += index; index = 0; }
+  const char* p = s + index;
+  for (int k = 0; k < length && p[k] != '\0'; ++k) dst[n++] = p[k];
+  return n;
+}
+
 /* refine_intron (:47-265) */
 bool ef_refine_intron(const ef_config* cfg, const ef_seq* gen_info, const ef_seq* est_info, ef_factor* donor,
                       ef_factor* acceptor, bool first_intron, ef_backend* be) {
@@ -359,40 +367,38 @@ bool ef_refine_intron(const ef_config* cfg, const ef_seq* gen_info, const ef_seq
   const char* G = gen_info->seq;
   const char* E = est_info->seq;
 
+  /* The two strings of the gap alignment are concatenations of real_substring() pieces
+   * (:60-116): donor suffix + unaligned EST gap + acceptor prefix on the EST, and donor suffix +
+   * intron prefix + intron suffix + acceptor prefix on the genomic sequence.  The pieces are
+   * appended straight into the two buffers (same clamping, same stop at the terminator). */
   int dsl_gen = donor->GEN_start;
   if (donor->GEN_end - sp_gen + 1 >= dsl_gen) dsl_gen = donor->GEN_end - sp_gen + 1;
-  char* donor_suffix_gen = ef_real_substring(dsl_gen, donor->GEN_end - dsl_gen + 1, G);
   int dsl_est = donor->EST_start;
   if (donor->EST_end - sp_est + 1 >= dsl_est) dsl_est = donor->EST_end - sp_est + 1;
-  char* donor_suffix_est = ef_real_substring(dsl_est, donor->EST_end - dsl_est + 1, E);
   int apr_gen = acceptor->GEN_end;
   if (acceptor->GEN_start + sp_gen - 1 <= apr_gen) apr_gen = acceptor->GEN_start + sp_gen - 1;
-  char* acc_prefix_gen = ef_real_substring(acceptor->GEN_start, apr_gen - acceptor->GEN_start + 1, G);
   int apr_est = acceptor->EST_end;
   if (acceptor->EST_start + sp_est - 1 <= apr_est) apr_est = acceptor->EST_start + sp_est - 1;
-  char* acc_prefix_est = ef_real_substring(acceptor->EST_start, apr_est - acceptor->EST_start + 1, E);
-  char* gap_est = NULL;
-  if (donor->EST_end != acceptor->EST_start - 1)
-    gap_est = ef_real_substring(donor->EST_end + 1, acceptor->EST_start - donor->EST_end - 1, E);
-
-  /* the reference sizes this buffer WITHOUT the gap (strlen(donor)+strlen(acceptor)+1) and then
-   * strcat()s the gap into it: heap overflow in the reference, plain concatenation here */
-  const size_t le = strlen(donor_suffix_est) + (gap_est ? strlen(gap_est) : 0) + strlen(acc_prefix_est);
-  char* seq_est = (char*)malloc(le + 1);
-  strcpy(seq_est, donor_suffix_est);
-  if (gap_est) strcat(seq_est, gap_est);
-  strcat(seq_est, acc_prefix_est);
-  free(donor_suffix_est); free(acc_prefix_est); free(gap_est);
-
-  char* intron_prefix = ef_real_substring(donor->GEN_end + 1, sp_int, G);
-  char* intron_suffix = ef_real_substring(acceptor->GEN_start - sp_int, sp_int, G);
-  char* seq_gen = (char*)malloc(strlen(donor_suffix_gen) + strlen(intron_prefix) + strlen(intron_suffix) + strlen(acc_prefix_gen) + 1);
-  strcpy(seq_gen, donor_suffix_gen); strcat(seq_gen, intron_prefix); strcat(seq_gen, intron_suffix); strcat(seq_gen, acc_prefix_gen);
-  free(donor_suffix_gen); free(acc_prefix_gen); free(intron_suffix); free(intron_prefix);
+  const bool has_gap = donor->EST_end != acceptor->EST_start - 1;
+  const int piece_e[3][2] = { { dsl_est, donor->EST_end - dsl_est + 1 },
+                              { donor->EST_end + 1, has_gap ? acceptor->EST_start - donor->EST_end - 1 : 0 },
+                              { acceptor->EST_start, apr_est - acceptor->EST_start + 1 } };
+  const int piece_g[4][2] = { { dsl_gen, donor->GEN_end - dsl_gen + 1 }, { donor->GEN_end + 1, sp_int },
+                              { acceptor->GEN_start - sp_int, sp_int }, { acceptor->GEN_start, apr_gen - acceptor->GEN_start + 1 } };
+  size_t cap_e = 1, cap_g = 1;
+  for (int k = 0; k < 3; ++k) cap_e += piece_e[k][1] > 0 ? (size_t)piece_e[k][1] : 0;
+  for (int k = 0; k < 4; ++k) cap_g += piece_g[k][1] > 0 ? (size_t)piece_g[k][1] : 0;
+  char buf_e[1024], buf_g[1024];
+  char* seq_est = cap_e <= sizeof buf_e ? buf_e : (char*)malloc(cap_e);
+  char* seq_gen = cap_g <= sizeof buf_g ? buf_g : (char*)malloc(cap_g);
+  size_t le = 0, lg = 0;
+  for (int k = 0; k < 3; ++k) le = append_substring(seq_est, le, piece_e[k][0], piece_e[k][1], E);
+  for (int k = 0; k < 4; ++k) lg = append_substring(seq_gen, lg, piece_g[k][0], piece_g[k][1], G);
+  seq_est[le] = '\0'; seq_gen[lg] = '\0';
 
   const int deleted_intron_dim = acceptor->GEN_start - donor->GEN_end - 1 - 2 * sp_int;
 
-  ef_dp_req rq = { EF_DP_GAP, seq_est, strlen(seq_est), seq_gen, strlen(seq_gen), 0, 0, 0, 0 };
+  ef_dp_req rq = { EF_DP_GAP, seq_est, le, seq_gen, lg, 0, 0, 0, 0 };
   ef_dp_res rs;
   memset(&rs, 0, sizeof rs);
   if (be->dp(be->self, &rq, &rs) != 0) { fprintf(stderr, "* FATAL gap alignment backend failed\n"); abort(); }
@@ -404,7 +410,8 @@ bool ef_refine_intron(const ef_config* cfg, const ef_seq* gen_info, const ef_seq
   al.new_acceptor_factor_left = dsl_est + al.factor_cut;
   al.new_donor_right_on_gen = dsl_gen + al.intron_start - 1;
   al.new_acceptor_left_on_gen = dsl_gen + al.intron_end + deleted_intron_dim + 1;
-  free(seq_est); free(seq_gen);
+  if (seq_est != buf_e) free(seq_est);
+  if (seq_gen != buf_g) free(seq_gen);
 
   bool result = false;
   if (al.new_acceptor_factor_left == donor->EST_start) {
