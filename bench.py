@@ -7,8 +7,9 @@ pairings of all prepared sequences over the device suffix-array index (resident 
 per EST: MEG construction, embedding enumeration, candidate cleaning, filters, intron refinement,
 post-refinement -- host C on the worker threads -- with EVERY dynamic program (ALIGN, GAP, ED, KBAND,
 LCF, BORDERS, AFFIX) batched across ESTs onto the GPU through the C-ABI (libpintron_gpu.so).  The
-step ends with the per-EST output records in host memory (what est-fact writes to
-raw-multifasta-out.txt); for N > 1 they are gathered to rank 0 over RCCL inside the step.
+step ends with the text of the six output files in host memory (what est-fact writes to
+raw-multifasta-out.txt etc.) plus the packed factorization records; for N > 1 the packed records are
+gathered to rank 0 over RCCL inside the step.
 Not in the step: reading genomic.txt/ests.txt, strand/polyA preparation, index construction (done
 once, reported as load_s / index_s), writing the files.
 
@@ -35,7 +36,7 @@ N_EST_BATCH = 100_000          # C3
 CPU_SAMPLE = 3000              # ESTs of the same workload given to the reference CPU est-fact
 
 
-from pintron_amd.estfact import Session, gather_tensor, load_host_lib  # noqa: E402
+from pintron_amd.estfact import RECORDS, Session, gather_tensor, load_host_lib  # noqa: E402
 
 
 def rocprof_symbol(group_name):
@@ -113,8 +114,10 @@ def main():
     def step():
         st = sess.step()
         if world > 1:
-            # the only exchange of the sharded path: per-EST output records -> rank 0 (RCCL)
-            gather_tensor(sess.output_tensor(0), dist, rank, world, "cuda")
+            # the only exchange of the sharded path: the factorization records of the rank's ESTs
+            # (packed: 16 B per exon + 4 B per factorization, everything downstream stages parse out
+            # of raw-multifasta-out.txt) -> rank 0 over RCCL
+            gather_tensor(sess.output_tensor(RECORDS), dist, rank, world, "cuda")
         return st
 
     def fence():

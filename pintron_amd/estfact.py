@@ -103,6 +103,46 @@ class Session:
             self.h = None
 
 
+# ---- packed factorization records (SURVEY.md section 8f.1) -----------------------------------------
+RECORDS = 6     # Session.output(RECORDS): see ef_write_factorization_records (pintron_amd/host/ef_estfact.c)
+
+
+def parse_factorization_records(data: bytes):
+    """[(est_index, [(polya, polyad, [(est_start, est_end, gen_start, gen_end), ...]), ...]), ...]
+    with the coordinates exactly as raw-multifasta-out.txt prints them (1-based, inclusive)."""
+    import struct
+    out, pos = [], 0
+    while pos < len(data):
+        est_index, n_fact = struct.unpack_from("<II", data, pos)
+        pos += 8
+        facts = []
+        for _ in range(n_fact):
+            polya, polyad, n_exons = struct.unpack_from("<BBH", data, pos)
+            pos += 4
+            exons = [struct.unpack_from("<4i", data, pos + 16 * k) for k in range(n_exons)]
+            pos += 16 * n_exons
+            facts.append((polya, polyad, exons))
+        out.append((est_index, facts))
+    return out
+
+
+def format_raw_multifasta(records, processed_ests: bytes, genomic_seq: bytes) -> bytes:
+    """raw-multifasta-out.txt rebuilt from the packed records, processed-ests.txt (header and
+    strand-corrected sequence of every aligned EST, in the same order) and the genomic sequence as
+    it stands in genomic.txt -- i.e. the text carries nothing that the records do not."""
+    ests = []
+    lines = processed_ests.split(b"\n")
+    for k in range(0, len(lines) - 1, 2):
+        ests.append((lines[k][1:], lines[k + 1]))
+    out = []
+    for (est_index, facts), (header, seq) in zip(records, ests):
+        for polya, polyad, exons in facts:
+            out.append(b">" + header + b"\n#polya=%d\n#polyad=%d\n" % (polya, polyad))
+            for es, ee, gs, ge in exons:
+                out.append(b"%d %d %d %d %s %s\n" % (es, ee, gs, ge, seq[es - 1:ee], genomic_seq[gs - 1:ge]))
+    return b"".join(out)
+
+
 # ---- sharding -----------------------------------------------------------------------------------
 def read_multifasta_records(path):
     """ests.txt as a list of byte records (header line + sequence lines), in file order."""

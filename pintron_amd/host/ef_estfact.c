@@ -43,6 +43,52 @@ void ef_write_multifasta_output(const ef_seq* gen, const ef_est* e, FILE* f, cha
   }
 }
 
+/* The same factorizations as packed binary records, for consumers that do not want to parse text
+ * (min-factorization reads "%d %d %d %d", #polya=, #polyad= and groups by
+ * header, src/io-factorizations.c:128-231).  Little-endian, per EST with at least one record:
+ *   u32 est_index (position in ests.txt), u32 n_factorizations, then per factorization
+ *   u8 polya, u8 polyad, u16 n_exons, then per exon 4 x i32: EST_start, EST_end, GEN_start, GEN_end
+ *   exactly as printed (1-based, genomic coordinates shifted by the removed N prefix).
+ * The selection rules (retain_externals, polyA suffix) are those of the text writer above. */
+void ef_write_factorization_records(const ef_seq* gen, const ef_est* e, FILE* f, char retain_externals, uint32_t est_index) {
+  if (!e->factorizations || efl_empty(e->factorizations)) return;
+  uint32_t n_fact = 0;
+  size_t cap = 256, len = 8;
+  unsigned char* b = (unsigned char*)malloc(cap);
+  ef_iter fi = efl_begin(e->factorizations), pa = efl_begin(e->polyA_signals), pd = efl_begin(e->polyadenil_signals);
+  while (efi_has_next(&fi)) {
+    ef_list* fact = (ef_list*)efi_next(&fi);
+    int polya = efi_next(&pa) == (void*)1, polyad = efi_next(&pd) == (void*)1;
+    const size_t n = efl_size(fact);
+    if (!(retain_externals || (n > 2 || (n == 2 && e->info->suff_polyA_length != -1)))) continue;
+    if (!retain_externals) { polya = 0; polyad = 0; }
+    const unsigned l_index = retain_externals == 0 ? 1 : 0;
+    const unsigned r_index = retain_externals == 0 ? (e->info->suff_polyA_length == -1 ? (unsigned)n : (unsigned)n + 1) : (unsigned)n + 1;
+    if (len + 4 + 16 * n > cap) { cap = (len + 4 + 16 * n) * 2; b = (unsigned char*)realloc(b, cap); }
+    unsigned char* head = b + len;
+    len += 4;
+    uint16_t n_exons = 0;
+    unsigned counter = 1;
+    ef_iter xi = efl_begin(fact);
+    while (efi_has_next(&xi)) {
+      const ef_factor* x = (const ef_factor*)efi_next(&xi);
+      if (counter > l_index && counter < r_index) {
+        const int32_t v[4] = { x->EST_start + 1, x->EST_end + 1, gen->pref_N_length + x->GEN_start + 1, gen->pref_N_length + x->GEN_end + 1 };
+        memcpy(b + len, v, 16); len += 16;
+        ++n_exons;
+      }
+      ++counter;
+    }
+    head[0] = (unsigned char)polya; head[1] = (unsigned char)polyad; memcpy(head + 2, &n_exons, 2);
+    ++n_fact;
+  }
+  if (n_fact) {
+    memcpy(b, &est_index, 4); memcpy(b + 4, &n_fact, 4);
+    fwrite(b, 1, len, f);
+  }
+  free(b);
+}
+
 /* compute_est_fact (src/compute-est-fact.c:192-293) */
 ef_est* ef_compute_est_fact(const ef_seq* gen, const ef_seq* est, ef_backend* be, const ef_config* cfg,
                             const ef_side_files* side) {

@@ -97,12 +97,14 @@ typedef struct fiber {
   struct fiber* pool_next;   /* free fibres (struct + stack) are kept for the next EST */
 } fiber;
 
+#define EF_N_OUT 7
 static const char FIBER_SENTINEL[16] = "pintron-fibre-s";
 
 /* one input EST: entry `first` of the prepared list, plus the sibling at first+1 if any */
 typedef struct {
   size_t first; bool has_sibling;
-  char* buf[6]; size_t len[6];         /* raw, processed-ests, megs, processed-megs, megs-info, meg-edges */
+  char* buf[EF_N_OUT]; size_t len[EF_N_OUT];   /* raw, processed-ests, megs, processed-megs, megs-info,
+                                                * meg-edges, packed factorization records */
 } unit;
 
 /* ---- GPU service: one thread owns the device queue ------------------------------------------------
@@ -268,9 +270,9 @@ static void fiber_main(void* arg) {
   fiber* f = (fiber*)arg;
   shared* sh = f->w->sh;
   unit* u = &sh->units[f->unit];
-  FILE* fs[6];
-  char* mbuf[6]; size_t mlen[6];
-  for (int k = 0; k < 6; ++k) fs[k] = open_memstream(&mbuf[k], &mlen[k]);
+  FILE* fs[EF_N_OUT];
+  char* mbuf[EF_N_OUT]; size_t mlen[EF_N_OUT];
+  for (int k = 0; k < EF_N_OUT; ++k) fs[k] = open_memstream(&mbuf[k], &mlen[k]);
   ef_side_files side = { fs[2], fs[3], fs[4], fs[5] };
   const ef_inputs* in = sh->in;
   for (size_t k = u->first; k <= u->first + (u->has_sibling ? 1 : 0); ++k) {
@@ -279,12 +281,13 @@ static void fiber_main(void* arg) {
     const bool aligned = !efl_empty(fe->factorizations);
     if (aligned) {
       ef_write_multifasta_output(in->gen, fe, fs[0], in->cfg.retain_externals);
+      ef_write_factorization_records(in->gen, fe, fs[6], in->cfg.retain_externals, (uint32_t)f->unit);
       ef_write_single_est_info(fs[1], fe->info);
     }
     ef_est_free(fe);
     if (aligned) break;
   }
-  for (int k = 0; k < 6; ++k) {
+  for (int k = 0; k < EF_N_OUT; ++k) {
     fclose(fs[k]);
     u->len[k] = mlen[k];
     u->buf[k] = mlen[k] ? out_alloc(f->w, mlen[k]) : NULL;
@@ -700,7 +703,7 @@ ef_session* ef_session_open(int argc, char** argv) {
 /* forget the previous step's output; its chunks are kept for the next step unless `release` */
 static void free_unit_buffers(shared* sh, bool release) {
   for (size_t u = 0; u < sh->n_units; ++u)
-    for (int k = 0; k < 6; ++k) { sh->units[u].buf[k] = NULL; sh->units[u].len[k] = 0; }
+    for (int k = 0; k < EF_N_OUT; ++k) { sh->units[u].buf[k] = NULL; sh->units[u].len[k] = 0; }
   while (sh->chunks) { out_chunk* nx = sh->chunks->next; sh->chunks->next = sh->spare_chunks; sh->spare_chunks = sh->chunks; sh->chunks = nx; }
   if (release) while (sh->spare_chunks) { out_chunk* nx = sh->spare_chunks->next; free(sh->spare_chunks); sh->spare_chunks = nx; }
 }
@@ -829,10 +832,11 @@ int ef_session_write_outputs(ef_session* s) {
 }
 
 /* text of output file `which` of the last step (0 raw-multifasta-out, 1 processed-ests, 2 megs,
- * 3 processed-megs, 4 processed-megs-info, 5 meg-edges), concatenated in input order; caller frees */
+ * 3 processed-megs, 4 processed-megs-info, 5 meg-edges; 6 = the packed factorization records of
+ * ef_write_factorization_records), concatenated in input order; caller frees */
 char* ef_session_output(ef_session* s, int which, size_t* len) {
   shared* sh = &s->sh;
-  if (which < 0 || which > 5) { *len = 0; return NULL; }
+  if (which < 0 || which >= EF_N_OUT) { *len = 0; return NULL; }
   size_t total = 0;
   for (size_t u = 0; u < sh->n_units; ++u) total += sh->units[u].len[which];
   char* r = (char*)malloc(total + 1);

@@ -243,6 +243,7 @@ uint32_t ef_edit_distance(ef_backend* be, const char* a, size_t la, const char* 
 uint32_t ef_compute_edit_distance(ef_backend* be, const char* a, size_t la, const char* b, size_t lb);
 /* write_multifasta_output (src/io-multifasta.c:187-246) */
 void ef_write_multifasta_output(const ef_seq* gen, const ef_est* e, FILE* f, char retain_externals);
+void ef_write_factorization_records(const ef_seq* gen, const ef_est* e, FILE* f, char retain_externals, uint32_t est_index);
 /* compute_est_fact (src/compute-est-fact.c:192-293) without the diagnostics side files */
 typedef struct { FILE *fmeg, *fpmeg, *ftmeg, *fintronic; } ef_side_files;
 ef_est* ef_compute_est_fact(const ef_seq* gen, const ef_seq* est, ef_backend* be, const ef_config* cfg,

@@ -64,3 +64,31 @@ def test_two_ranks_equal_one_rank(tmp_path):
     # and both equal the reference's own output for this input (golden fixture)
     exp = open(os.path.join(AMBN, "expected-raw-multifasta-out.txt"), "rb").read()
     assert outs[2]["raw-multifasta-out.txt"] == exp
+
+
+def test_packed_records_carry_the_whole_output(tmp_path):
+    """the packed factorization records (16 B per exon + 4 B per factorization) plus the
+    sequences reproduce raw-multifasta-out.txt byte for byte (check build of the host library)."""
+    sys.path.insert(0, ROOT)
+    from pintron_amd import estfact
+    subprocess.run(["make", "-s", "-C", HC, "libestfact_check.so"], check=True)
+    for f in ("genomic.txt", "ests.txt"):
+        shutil.copy(os.path.join(AMBN, f), tmp_path)
+    env_threads = os.environ.get("PINTRON_THREADS")
+    os.environ["PINTRON_THREADS"] = "2"
+    try:
+        s = estfact.Session(estfact.load_host_lib(os.path.join(HC, "libestfact_check.so")), str(tmp_path))
+        s.step()
+        raw, pests, packed = s.output(0), s.output(1), s.output(estfact.RECORDS)
+        s.close()
+    finally:
+        if env_threads is None:
+            del os.environ["PINTRON_THREADS"]
+        else:
+            os.environ["PINTRON_THREADS"] = env_threads
+    recs = estfact.parse_factorization_records(packed)
+    assert len(recs) == pests.count(b">") == 25
+    gen = b"".join(open(os.path.join(AMBN, "genomic.txt"), "rb").read().split(b"\n")[1:])
+    assert estfact.format_raw_multifasta(recs, pests, gen) == raw
+    assert raw == open(os.path.join(AMBN, "expected-raw-multifasta-out.txt"), "rb").read()
+    assert len(packed) < len(raw) // 8
