@@ -4,12 +4,21 @@
  * dynamic programs depend on earlier results.  To keep one GPU busy with tens of thousands of
  * small, data-dependent requests, every input EST (the sequence and, when the strand is not fixed,
  * its reverse-complement sibling, tried only if the first fails: src/main-est-fact.c:249-291) runs
- * as a FIBRE (ucontext): a request enqueues a job and yields; when no fibre of a worker can run,
- * the worker submits all pending requests as ONE batch through the C-ABI
- * (pgpu_pairing_plan_* / pgpu_dp_plan_*), hands the results back and resumes the fibres.
- * Workers are host threads (one pgpu_ctx = one HIP stream each), ESTs are dealt to them from a
- * shared counter, and the per-EST output records are written in input order at the end, so the
- * files are byte-identical to a sequential run.
+ * as a FIBRE: a request (or a group of independent requests) is recorded and the fibre yields.
+ *
+ *   workers   host threads; ESTs are dealt to them from a shared counter.  A worker owns a few
+ *             LANES of fibres: it runs the runnable fibres of a lane, posts the lane's pending DP
+ *             requests to the GPU service WITHOUT waiting and goes on with the next lane; it
+ *             sleeps only when the lane it comes back to is still on the GPU.
+ *   service   one or two threads that own the device queues: whatever has been posted is merged
+ *             into ONE pgpu_dp_plan (one upload, one set of launches, one download), run, and the
+ *             posters are woken to decode their slices of the shared result buffers.
+ *   prefetch  the pairings of all ESTs at the configured parameters are computed in a few resident
+ *             chunks (pgpu_pairing_plan_*) by a thread running beside the workers; only retries
+ *             with a longer factor go through per-worker batches.
+ *
+ * The per-EST output text is kept in step-owned chunks and written in input order at the end, so
+ * the files are byte-identical to a sequential run.
  */
 #define _GNU_SOURCE
 #include <malloc.h>
