@@ -71,6 +71,31 @@ def test_other_configs_vs_compiled_reference(exe, tmp_path, cfg, n_est):
         assert filecmp.cmp(my_dir / f, ref_dir / f, shallow=False), f
 
 
+@pytest.mark.parametrize("name,sub", [("test-issue-13", "issue13"), ("dist-docs/example", "example")])
+def test_real_ests_of_the_reference_regression_sets(exe, tmp_path, name, sub):
+    """Real ESTs: the inputs of the reference's regressionTest/test-issue-13 and dist-docs/example
+    (tests/golden/<sub>/*.gz, data files of the reference's own tests).  The checksums of the two
+    main outputs are the reference's (tests/golden/reference_md5.json); when the compiled reference
+    travelled with the snapshot, all five files are compared with its run as well."""
+    import gzip
+    import hashlib
+    import json
+    gold = json.load(open(os.path.join(HERE, "golden", "reference_md5.json")))[name]
+    my_dir, ref_dir = tmp_path / "mine", tmp_path / "ref"
+    for d in (my_dir, ref_dir):
+        d.mkdir()
+        for f in ("genomic.txt", "ests.txt"):
+            (d / f).write_bytes(gzip.open(os.path.join(HERE, "golden", sub, f + ".gz")).read())
+    subprocess.run([exe], cwd=my_dir, check=True)
+    for f, md5 in gold.items():
+        assert hashlib.md5((my_dir / f).read_bytes()).hexdigest() == md5, (name, f)
+    ref = os.path.join(ROOT, "oracle", "_ref", "est-fact-ref")
+    if os.path.exists(ref):
+        subprocess.run([ref], cwd=ref_dir, check=True, stderr=subprocess.DEVNULL)
+        for f in FILES:
+            assert filecmp.cmp(my_dir / f, ref_dir / f, shallow=False), (name, f)
+
+
 def test_long_transcripts_vs_compiled_reference(exe, tmp_path):
     """Full-length transcripts with a 5.6 kb exon: alignments, K-band distances and affix searches
     with more than 4096 rows (strips) inside the whole program."""

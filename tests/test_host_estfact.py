@@ -76,6 +76,23 @@ def test_long_transcripts_match_compiled_reference(bins, tmp_path):
         assert filecmp.cmp(my_dir / f, ref_dir / f, shallow=False), f
 
 
+@pytest.mark.parametrize("name,sub", [("dist-docs/example", "example"), ("test-issue-13", "issue13")])
+def test_reference_regression_inputs_md5(bins, tmp_path, name, sub):
+    """The reference's own example and regression inputs (real ESTs; tests/golden/<sub>/*.gz): the
+    host logic reproduces the checksums of the reference's outputs (tests/golden/reference_md5.json,
+    SURVEY 8c)."""
+    import gzip
+    import hashlib
+    import json
+    gdir = os.path.join(HERE, "golden")
+    gold = json.load(open(os.path.join(gdir, "reference_md5.json")))[name]
+    for f in ("genomic.txt", "ests.txt"):
+        (tmp_path / f).write_bytes(gzip.open(os.path.join(gdir, sub, f + ".gz")).read())
+    run(bins["estfact_sched_check"], tmp_path, {"PINTRON_THREADS": "4"})
+    for f, md5 in gold.items():
+        assert hashlib.md5(open(tmp_path / f, "rb").read()).hexdigest() == md5, (name, f)
+
+
 def test_cli_options_and_config_dump(bins, tmp_path):
     for f in ("genomic.txt", "ests.txt"):
         shutil.copy(os.path.join(GOLD, f), tmp_path)
