@@ -180,3 +180,46 @@ def make_long_transcripts(seed=77):
     g = ">chrL:1:%d:+1\n%s\n" % (len(gen), gen)
     e = "".join(">/gb=LNG%04d /clone_end=3'\n%s\n" % (i, x) for i, x in enumerate(ests))
     return g, e
+
+
+def make_edge_cases(seed=5):
+    """Inputs around the corners of the input handling: N tails and internal N runs in the genomic
+    sequence, negative-strand header, ESTs that are too short / all N / lower case / polyA only /
+    unrelated, duplicated headers, /fixed_strand, RefSeq and token-less headers, exon skipping, an
+    EST read off the genomic flank, wrapped lines.  Returns (genomic_fasta_text, ests_fasta_text)."""
+    import random
+    rng = random.Random(seed)
+
+    def rs(n):
+        return "".join(rng.choice("ACGT") for _ in range(n))
+
+    def rc(s):
+        return s[::-1].translate(str.maketrans("ACGTacgtNn", "TGCAtgcaNn"))
+
+    ex = [rs(200), rs(150), rs(300)]
+    gen = ("NNNNNNNNNN" + rs(500) + ex[0] + "GT" + rs(700) + "AG" + ex[1] + "GT" + rs(50) + "N" * 20 + rs(600) +
+           "AG" + ex[2] + rs(400) + "NNNNN")
+    tr = "".join(ex)
+    ests = [
+        (">/gb=E0001 /clone_end=3'", tr[:10]),
+        (">/gb=E0002 /clone_end=3'", "N" * 120),
+        (">/gb=E0003 /clone_end=5'", tr.lower()),
+        (">/gb=E0004 /clone_end=3'", tr),
+        (">/gb=E0004 /clone_end=3'", tr[50:500]),
+        (">/gb=E0005 /clone_end=3'", "A" * 80),
+        (">/gb=E0006 /clone_end=3' /fixed_strand=1", rc(tr)),
+        (">/gb=E0007 /clone_end=3' /fixed_strand=0", rc(tr)),
+        (">NM_000001.1 some refseq", tr + "A" * 25),
+        (">/gb=E0008", rc(tr[20:600])),
+        (">weird header without tokens", tr[100:640]),
+        (">/gb=E0009 /clone_end=5'", "T" * 30 + rc(tr)[:500]),
+        (">/gb=E0010 /clone_end=3'", tr[:300] + "N" * 5 + tr[305:]),
+        (">/gb=E0011 /clone_end=3'", tr[:180] + tr[360:]),
+        (">/gb=E0012 /clone_end=3'", rs(400)),
+        (">/gb=E0013 /clone_end=3'", gen[10:400]),
+        (">/gb=E0014 /clone_end=3'", ex[0][:14]),
+        (">/gb=E0015 /clone_end=3'", ex[0][:15] + ex[1][:15]),
+    ]
+    g = ">chrE:1000:%d:-1\n" % (999 + len(gen)) + "\n".join(gen[i:i + 70] for i in range(0, len(gen), 70)) + "\n"
+    e = "".join(h + "\n" + "\n".join(x[i:i + 60] for i in range(0, len(x), 60)) + "\n" for h, x in ests)
+    return g, e

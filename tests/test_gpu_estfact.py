@@ -96,6 +96,28 @@ def test_real_ests_of_the_reference_regression_sets(exe, tmp_path, name, sub):
             assert filecmp.cmp(my_dir / f, ref_dir / f, shallow=False), (name, f)
 
 
+def test_edge_case_inputs_vs_compiled_reference(exe, tmp_path):
+    """N tails, negative-strand header, too short / all-N / lower-case / polyA-only ESTs, duplicated
+    and odd headers, /fixed_strand, wrapped lines (pintron_amd/synth.py: make_edge_cases); and an
+    empty ests.txt."""
+    ref = os.path.join(ROOT, "oracle", "_ref", "est-fact-ref")
+    if not os.path.exists(ref):
+        pytest.skip("oracle/_ref/est-fact-ref not present")
+    from pintron_amd import synth
+    g, e = synth.make_edge_cases()
+    for tag, ests in (("edge", e), ("empty", "")):
+        ref_dir, my_dir = tmp_path / (tag + "_ref"), tmp_path / (tag + "_mine")
+        for d in (ref_dir, my_dir):
+            d.mkdir()
+            (d / "genomic.txt").write_text(g)
+            (d / "ests.txt").write_text(ests)
+        subprocess.run([ref], cwd=ref_dir, check=True, stderr=subprocess.DEVNULL)
+        subprocess.run([exe], cwd=my_dir, check=True)
+        for f in FILES:
+            assert filecmp.cmp(my_dir / f, ref_dir / f, shallow=False), (tag, f)
+    assert (tmp_path / "edge_mine" / "raw-multifasta-out.txt").read_text().count(">") == 10
+
+
 def test_long_transcripts_vs_compiled_reference(exe, tmp_path):
     """Full-length transcripts with a 5.6 kb exon: alignments, K-band distances and affix searches
     with more than 4096 rows (strips) inside the whole program."""

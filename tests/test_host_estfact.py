@@ -93,6 +93,22 @@ def test_reference_regression_inputs_md5(bins, tmp_path, name, sub):
         assert hashlib.md5(open(tmp_path / f, "rb").read()).hexdigest() == md5, (name, f)
 
 
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
+def test_edge_case_inputs_match_compiled_reference(bins, tmp_path):
+    from pintron_amd import synth
+    g, e = synth.make_edge_cases()
+    for tag, ests in (("edge", e), ("empty", "")):
+        ref_dir, my_dir = tmp_path / (tag + "_ref"), tmp_path / (tag + "_mine")
+        for d in (ref_dir, my_dir):
+            d.mkdir()
+            (d / "genomic.txt").write_text(g)
+            (d / "ests.txt").write_text(ests)
+        subprocess.run([os.path.join(O.REF_DIR, "est-fact-ref")], cwd=ref_dir, check=True, stderr=subprocess.DEVNULL)
+        run(bins["estfact_sched_check"], my_dir, {"PINTRON_THREADS": "2"})
+        for f in FILES:
+            assert filecmp.cmp(my_dir / f, ref_dir / f, shallow=False), (tag, f)
+
+
 def test_cli_options_and_config_dump(bins, tmp_path):
     for f in ("genomic.txt", "ests.txt"):
         shutil.copy(os.path.join(GOLD, f), tmp_path)
