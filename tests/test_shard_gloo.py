@@ -1,5 +1,5 @@
-"""The N > 1 path on CPU: two gloo ranks run the sharded est-fact driver (pintron_amd/estfact.py)
-over the check build of the host library (tests/hostcheck: scheduler + host C over a CPU stand-in
+"""The N > 1 path on CPU: two gloo ranks run the multi-GPU launcher (python -m pintron_amd.multi ->
+pintron_amd/estfact.py: run_sharded) over the check build of the host library (tests/hostcheck: scheduler + host C over a CPU stand-in
 of the C-ABI) and rank 0 must end up with exactly the files a single rank writes."""
 import os
 import shutil
@@ -11,21 +11,6 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HC = os.path.join(ROOT, "tests", "hostcheck")
 AMBN = os.path.join(ROOT, "tests", "golden", "ambn")
-
-WORKER = r"""
-import os, sys
-sys.path.insert(0, %(root)r)
-import torch, torch.distributed as dist
-from pintron_amd import estfact
-rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-dist.init_process_group("gloo", rank=rank, world_size=world)
-L = estfact.load_host_lib(%(lib)r)
-st = estfact.run_sharded(%(data)r, os.path.join(%(tmp)r, "rank%%d" %% rank), dist, rank, world, "cpu", L=L, files=(0, 1, 2, 5))
-assert st["ests"] > 0
-dist.barrier()
-dist.destroy_process_group()
-"""
-
 
 def test_partition_is_contiguous_and_balanced():
     sys.path.insert(0, ROOT)
@@ -50,14 +35,14 @@ def test_two_ranks_equal_one_rank(tmp_path):
         data.mkdir()
         shutil.copy(os.path.join(AMBN, "genomic.txt"), data / "genomic.txt")
         shutil.copy(os.path.join(AMBN, "ests.txt"), data / "ests.txt")
-        script = tmp_path / ("worker%d.py" % world)
-        script.write_text(WORKER % dict(root=ROOT, lib=lib, data=str(data), tmp=str(tmp_path / ("w%d" % world))))
-        env = dict(os.environ, PINTRON_THREADS="2", PINTRON_FIBERS="16", MASTER_ADDR="127.0.0.1")
+        env = dict(os.environ, PINTRON_THREADS="2", PINTRON_FIBERS="16", MASTER_ADDR="127.0.0.1",
+                   PINTRON_DIST_BACKEND="gloo", PINTRON_ESTFACT_LIB=lib, PYTHONPATH=ROOT)
         subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
-                        "--master-addr", "127.0.0.1", "--master-port", str(29611 + world), str(script)],
+                        "--master-addr", "127.0.0.1", "--master-port", str(29611 + world),
+                        "-m", "pintron_amd.multi", str(data)],
                        check=True, env=env, timeout=600)
         outs[world] = {f: (data / f).read_bytes() for f in
-                       ("raw-multifasta-out.txt", "processed-ests.txt", "megs.txt", "meg-edges.txt")}
+                       ("raw-multifasta-out.txt", "processed-ests.txt", "megs.txt", "processed-megs.txt", "meg-edges.txt")}
     for f, text in outs[1].items():
         assert text, f
         assert outs[2][f] == text, f
