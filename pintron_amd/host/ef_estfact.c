@@ -11,7 +11,7 @@
 #include "estfact.h"
 
 /* write_multifasta_output (src/io-multifasta.c:187-246) */
-void ef_write_multifasta_output(const ef_seq* gen, const ef_est* e, FILE* f, char retain_externals) {
+void ef_write_multifasta_output(const ef_seq* gen, const ef_est* e, ef_sink* f, char retain_externals) {
   if (!e->factorizations || efl_empty(e->factorizations)) return;
   ef_iter fi = efl_begin(e->factorizations), pa = efl_begin(e->polyA_signals), pd = efl_begin(e->polyadenil_signals);
   while (efi_has_next(&fi)) {
@@ -50,7 +50,7 @@ void ef_write_multifasta_output(const ef_seq* gen, const ef_est* e, FILE* f, cha
  *   u8 polya, u8 polyad, u16 n_exons, then per exon 4 x i32: EST_start, EST_end, GEN_start, GEN_end
  *   exactly as printed (1-based, genomic coordinates shifted by the removed N prefix).
  * The selection rules (retain_externals, polyA suffix) are those of the text writer above. */
-void ef_write_factorization_records(const ef_seq* gen, const ef_est* e, FILE* f, char retain_externals, uint32_t est_index) {
+void ef_write_factorization_records(const ef_seq* gen, const ef_est* e, ef_sink* f, char retain_externals, uint32_t est_index) {
   if (!e->factorizations || efl_empty(e->factorizations)) return;
   uint32_t n_fact = 0;
   size_t cap = 256, len = 8;
@@ -84,7 +84,7 @@ void ef_write_factorization_records(const ef_seq* gen, const ef_est* e, FILE* f,
   }
   if (n_fact) {
     memcpy(b, &est_index, 4); memcpy(b + 4, &n_fact, 4);
-    fwrite(b, 1, len, f);
+    ef_sink_write(f, (const char*)b, len);
   }
   free(b);
 }
@@ -106,17 +106,24 @@ ef_est* ef_compute_est_fact(const ef_seq* gen, const ef_seq* est, ef_backend* be
   ef_remove_factorizations_with_very_small_exons(fe->factorizations);
   if (!efl_empty(fe->factorizations)) ef_remove_duplicated_factorizations(fe->factorizations);
   if (side && side->fmeg) {                                   /* report_meg (:73-88) */
-    fprintf(side->fmeg, "\n\n***********\n\n");
+    ef_sink_puts(side->fmeg, "\n\n***********\n\n");
     ef_write_single_est_info(side->fmeg, est);
     ef_meg_write(side->fmeg, V);
-    fflush(side->fmeg);
+    if (side->fmeg->f) fflush(side->fmeg->f);
   }
   if (!efl_empty(fe->factorizations) && side) {
-    if (side->fintronic) { fprintf(side->fintronic, ">%s\n", est->id); ef_intronic_edges_write(side->fintronic, V); }
+    if (side->fintronic) {
+      ef_sink_puts(side->fintronic, ">"); ef_sink_puts(side->fintronic, est->id); ef_sink_puts(side->fintronic, "\n");
+      ef_intronic_edges_write(side->fintronic, V);
+    }
     if (side->fpmeg) { ef_write_single_est_info(side->fpmeg, est); ef_meg_write(side->fpmeg, V); }
     /* "<meg us> <composition us> <#factorizations>": the two timings are inherently not
      * reproducible; written as 0 */
-    if (side->ftmeg) fprintf(side->ftmeg, "0 0 %zu\n", efl_size(fe->factorizations));
+    if (side->ftmeg) {
+      char line[48];
+      snprintf(line, sizeof line, "0 0 %zu\n", efl_size(fe->factorizations));
+      ef_sink_puts(side->ftmeg, line);
+    }
   }
   ef_meg_free(V);
   return fe;
@@ -185,13 +192,16 @@ int ef_open_outputs(ef_outputs* o) {
   char buf[64];
   snprintf(buf, sizeof buf, "info-pid-%u.log", (unsigned)getpid());
   o->flog = fopen(buf, "w");
-  o->fout = fopen("raw-multifasta-out.txt", "w");
-  o->side.fmeg = fopen("megs.txt", "w");
-  o->side.fpmeg = fopen("processed-megs.txt", "w");
-  o->side.ftmeg = fopen("processed-megs-info.txt", "w");
-  o->fests = fopen("processed-ests.txt", "w");
-  o->side.fintronic = fopen("meg-edges.txt", "w");
-  if (!o->flog || !o->fout || !o->fests || !o->side.fmeg || !o->side.fpmeg || !o->side.ftmeg || !o->side.fintronic) {
+  memset(&o->fout, 0, sizeof o->fout); memset(&o->fests, 0, sizeof o->fests); memset(&o->fmeg, 0, sizeof o->fmeg);
+  memset(&o->fpmeg, 0, sizeof o->fpmeg); memset(&o->ftmeg, 0, sizeof o->ftmeg); memset(&o->fintronic, 0, sizeof o->fintronic);
+  o->fout.f = fopen("raw-multifasta-out.txt", "w");
+  o->fmeg.f = fopen("megs.txt", "w");
+  o->fpmeg.f = fopen("processed-megs.txt", "w");
+  o->ftmeg.f = fopen("processed-megs-info.txt", "w");
+  o->fests.f = fopen("processed-ests.txt", "w");
+  o->fintronic.f = fopen("meg-edges.txt", "w");
+  o->side.fmeg = &o->fmeg; o->side.fpmeg = &o->fpmeg; o->side.ftmeg = &o->ftmeg; o->side.fintronic = &o->fintronic;
+  if (!o->flog || !o->fout.f || !o->fests.f || !o->fmeg.f || !o->fpmeg.f || !o->ftmeg.f || !o->fintronic.f) {
     fprintf(stderr, "* FATAL Cannot create an output file! Terminating\n");
     return 1;
   }
@@ -201,8 +211,8 @@ int ef_open_outputs(ef_outputs* o) {
 
 void ef_close_outputs(ef_outputs* o) {
   fprintf(o->flog, "end\n");
-  fclose(o->flog); fclose(o->fout); fclose(o->fests);
-  fclose(o->side.fmeg); fclose(o->side.fpmeg); fclose(o->side.ftmeg); fclose(o->side.fintronic);
+  fclose(o->flog); fclose(o->fout.f); fclose(o->fests.f);
+  fclose(o->fmeg.f); fclose(o->fpmeg.f); fclose(o->ftmeg.f); fclose(o->fintronic.f);
 }
 
 /* main of est-fact (src/main-est-fact.c:90-339), one EST after the other, with the backend
@@ -221,8 +231,8 @@ int ef_run(int argc, char** argv, ef_backend* (*open_backend)(const ef_seq* gen)
     ef_seq* est = in.list[k];
     ef_est* fe = ef_compute_est_fact(in.gen, est, be, &in.cfg, &out.side);
     if (!efl_empty(fe->factorizations)) {
-      ef_write_multifasta_output(in.gen, fe, out.fout, in.cfg.retain_externals);
-      ef_write_single_est_info(out.fests, fe->info);
+      ef_write_multifasta_output(in.gen, fe, &out.fout, in.cfg.retain_externals);
+      ef_write_single_est_info(&out.fests, fe->info);
       if (!est->fixed_strand && !reversed) ++k;        /* skip the reverse-complement sibling */
       reversed = false;
     } else if (reversed || est->fixed_strand) {

@@ -319,7 +319,7 @@ ef_seq* ef_copy_and_reverse(const ef_seq* est) {
   return r;
 }
 
-void ef_write_single_est_info(FILE* f, const ef_seq* s) {
+void ef_write_single_est_info(ef_sink* f, const ef_seq* s) {
   ef_wbuf w; efw_open(&w, f);
   efw_ch(&w, '>'); efw_str(&w, s->id); efw_ch(&w, '\n'); efw_str(&w, s->original_seq); efw_ch(&w, '\n');
   efw_flush(&w);

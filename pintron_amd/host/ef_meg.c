@@ -361,7 +361,7 @@ void ef_transitive_reduction(ef_meg* V) {
   free(star); free(red); free(red_inc); free(T);
 }
 
-void ef_meg_write(FILE* f, ef_meg* V) {
+void ef_meg_write(ef_sink* f, ef_meg* V) {
   ef_wbuf w; efw_open(&w, f);
   int index = 0;
   EF_MEG_FOR_POS(V, i, 0, V->n) {
@@ -387,7 +387,7 @@ void ef_meg_write(FILE* f, ef_meg* V) {
   efw_flush(&w);
 }
 
-void ef_intronic_edges_write(FILE* f, ef_meg* V) {
+void ef_intronic_edges_write(ef_sink* f, ef_meg* V) {
   ef_wbuf w; efw_open(&w, f);
   EF_MEG_FOR_POS(V, i, 0, V->n) {
     ef_iter it = efl_begin(V->v[i]);

@@ -89,6 +89,7 @@ enum { F_RUNNABLE, F_WAIT_DP, F_WAIT_PAIR, F_DONE };
 static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 
 struct worker;
+#define EF_N_OUT 7            /* six output files + the packed factorization records */
 
 typedef struct fiber {
   ef_ctx ctx;
@@ -103,10 +104,10 @@ typedef struct fiber {
   ef_dp_req req1; int rc;
   const char* pat; size_t pat_len; unsigned pat_L; double pat_rate; ef_triple** pat_out; size_t* pat_n;
   ef_backend be;
-  struct fiber* pool_next;   /* free fibres (struct + stack) are kept for the next EST */
+  struct fiber* pool_next;   /* free fibres (struct + stack + sink blocks) are kept for the next EST */
+  ef_sink out[EF_N_OUT];     /* text of the unit being processed */
 } fiber;
 
-#define EF_N_OUT 7
 static const char FIBER_SENTINEL[16] = "pintron-fibre-s";
 
 /* one input EST: entry `first` of the prepared list, plus the sibling at first+1 if any */
@@ -279,29 +280,28 @@ static void fiber_main(void* arg) {
   fiber* f = (fiber*)arg;
   shared* sh = f->w->sh;
   unit* u = &sh->units[f->unit];
-  FILE* fs[EF_N_OUT];
-  char* mbuf[EF_N_OUT]; size_t mlen[EF_N_OUT];
-  for (int k = 0; k < EF_N_OUT; ++k) fs[k] = open_memstream(&mbuf[k], &mlen[k]);
-  ef_side_files side = { fs[2], fs[3], fs[4], fs[5] };
+  /* the text of the unit grows in the fibre's own memory sinks (their blocks are kept when the
+   * fibre is recycled) and is copied into the step's chunks when the unit is done */
+  ef_sink* fs = f->out;
+  for (int k = 0; k < EF_N_OUT; ++k) { fs[k].f = NULL; fs[k].len = 0; }
+  ef_side_files side = { &fs[2], &fs[3], &fs[4], &fs[5] };
   const ef_inputs* in = sh->in;
   for (size_t k = u->first; k <= u->first + (u->has_sibling ? 1 : 0); ++k) {
     f->cur_entry = k;
     ef_est* fe = ef_compute_est_fact(in->gen, in->list[k], &f->be, &in->cfg, &side);
     const bool aligned = !efl_empty(fe->factorizations);
     if (aligned) {
-      ef_write_multifasta_output(in->gen, fe, fs[0], in->cfg.retain_externals);
-      ef_write_factorization_records(in->gen, fe, fs[6], in->cfg.retain_externals, (uint32_t)f->unit);
-      ef_write_single_est_info(fs[1], fe->info);
+      ef_write_multifasta_output(in->gen, fe, &fs[0], in->cfg.retain_externals);
+      ef_write_factorization_records(in->gen, fe, &fs[6], in->cfg.retain_externals, (uint32_t)f->unit);
+      ef_write_single_est_info(&fs[1], fe->info);
     }
     ef_est_free(fe);
     if (aligned) break;
   }
   for (int k = 0; k < EF_N_OUT; ++k) {
-    fclose(fs[k]);
-    u->len[k] = mlen[k];
-    u->buf[k] = mlen[k] ? out_alloc(f->w, mlen[k]) : NULL;
-    if (mlen[k]) memcpy(u->buf[k], mbuf[k], mlen[k]);
-    free(mbuf[k]);
+    u->len[k] = fs[k].len;
+    u->buf[k] = fs[k].len ? out_alloc(f->w, fs[k].len) : NULL;
+    if (fs[k].len) memcpy(u->buf[k], fs[k].mem, fs[k].len);
   }
   f->state = F_DONE;
   ctx_switch(&f->ctx, &f->w->sched);
@@ -323,7 +323,14 @@ static bool start_fiber(worker* w, int li) {
   else if (u != (size_t)-1 && f) w->free_fibers = f->pool_next;
   pthread_mutex_unlock(&sh->mu);
   if (u == (size_t)-1) return false;
-  if (f) { char* st = f->stack; memset(f, 0, sizeof(fiber)); f->stack = st; }
+  if (f) {                       /* recycled: keep the stack and the sink blocks */
+    char* st = f->stack;
+    ef_sink keep[EF_N_OUT];
+    memcpy(keep, f->out, sizeof keep);
+    memset(f, 0, sizeof(fiber));
+    f->stack = st;
+    memcpy(f->out, keep, sizeof keep);
+  }
   else { f = (fiber*)calloc(1, sizeof(fiber)); f->stack = (char*)malloc(sh->stack_size); }
   f->w = w; f->unit = u; f->state = F_RUNNABLE; f->lane = li;
   f->be.self = f; f->be.pairings = fiber_pairings; f->be.dp = fiber_dp; f->be.dp_many = fiber_dp_many;
@@ -828,7 +835,7 @@ int ef_session_write_outputs(ef_session* s) {
   ef_outputs out;
   if (ef_open_outputs(&out)) return 1;
   shared* sh = &s->sh;
-  FILE* dst[6] = { out.fout, out.fests, out.side.fmeg, out.side.fpmeg, out.side.ftmeg, out.side.fintronic };
+  FILE* dst[6] = { out.fout.f, out.fests.f, out.fmeg.f, out.fpmeg.f, out.ftmeg.f, out.fintronic.f };
   file_writer fw[6]; pthread_t th[6]; bool started[6];
   for (int k = 0; k < 6; ++k) {
     fw[k].sh = sh; fw[k].f = dst[k]; fw[k].k = k;
@@ -865,7 +872,12 @@ void ef_session_close(ef_session* s) {
   if (!s) return;
   shared* sh = &s->sh;
   free_unit_buffers(sh, true);
-  while (sh->fiber_pool) { fiber* nx = sh->fiber_pool->pool_next; free(sh->fiber_pool->stack); free(sh->fiber_pool); sh->fiber_pool = nx; }
+  while (sh->fiber_pool) {
+    fiber* nx = sh->fiber_pool->pool_next;
+    for (int k = 0; k < EF_N_OUT; ++k) free(sh->fiber_pool->out[k].mem);
+    free(sh->fiber_pool->stack); free(sh->fiber_pool);
+    sh->fiber_pool = nx;
+  }
   free(sh->units);
   for (int c = 0; c < PRE_CHUNKS; ++c) {
     free(sh->pre_tri[c]); free(sh->pre_first[c]);

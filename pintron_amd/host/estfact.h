@@ -135,19 +135,30 @@ void ef_compact_short_edges(ef_meg* V, const ef_config* cfg);          /* :258 *
 bool ef_is_too_complex_for_compaction(ef_meg* V);                      /* :68 */
 bool ef_is_too_complex(ef_meg* V, const ef_config* cfg);               /* :89 */
 void ef_meg_stats(ef_meg* V, size_t* pairings, size_t* edges);         /* :52 */
-void ef_meg_write(FILE* f, ef_meg* V);                                 /* src/io-meg.c:146 */
-void ef_intronic_edges_write(FILE* f, ef_meg* V);                      /* src/max-emb-graph.c:677 */
+struct ef_sink;
+void ef_meg_write(struct ef_sink* f, ef_meg* V);                                 /* src/io-meg.c:146 */
+void ef_intronic_edges_write(struct ef_sink* f, ef_meg* V);                      /* src/max-emb-graph.c:677 */
 
 /* ---- output text ------------------------------------------------------------------------------
  * The record writers produce a few hundred short numeric fields per EST; they are assembled in a
  * small buffer with a hand-written integer formatter and handed to stdio in large pieces (printf
  * parsing was >10 % of the host time). */
-typedef struct { FILE* f; size_t n; char b[4096]; } ef_wbuf;
-static inline void efw_open(ef_wbuf* w, FILE* f) { w->f = f; w->n = 0; }
-static inline void efw_flush(ef_wbuf* w) { if (w->n) { fwrite(w->b, 1, w->n, w->f); w->n = 0; } }
+/* where output text goes: a stream (sequential runs write the files as they go) or a growing
+ * memory block (the batched runs keep the text of an EST until the files are written in order) */
+typedef struct ef_sink { FILE* f; char* mem; size_t len, cap; } ef_sink;
+static inline void ef_sink_write(ef_sink* s, const char* p, size_t n) {
+  if (s->f) { fwrite(p, 1, n, s->f); return; }
+  if (s->len + n > s->cap) { s->cap = (s->len + n) * 2 + 4096; s->mem = (char*)realloc(s->mem, s->cap); }
+  memcpy(s->mem + s->len, p, n); s->len += n;
+}
+static inline void ef_sink_puts(ef_sink* s, const char* str) { ef_sink_write(s, str, strlen(str)); }
+
+typedef struct { ef_sink* s; size_t n; char b[4096]; } ef_wbuf;
+static inline void efw_open(ef_wbuf* w, ef_sink* s) { w->s = s; w->n = 0; }
+static inline void efw_flush(ef_wbuf* w) { if (w->n) { ef_sink_write(w->s, w->b, w->n); w->n = 0; } }
 static inline void efw_ch(ef_wbuf* w, char c) { if (w->n == sizeof w->b) efw_flush(w); w->b[w->n++] = c; }
 static inline void efw_mem(ef_wbuf* w, const char* s, size_t n) {
-  if (n > sizeof w->b / 2) { efw_flush(w); fwrite(s, 1, n, w->f); return; }
+  if (n > sizeof w->b / 2) { efw_flush(w); ef_sink_write(w->s, s, n); return; }
   if (w->n + n > sizeof w->b) efw_flush(w);
   memcpy(w->b + w->n, s, n); w->n += n;
 }
@@ -242,10 +253,10 @@ uint32_t ef_edit_distance(ef_backend* be, const char* a, size_t la, const char* 
 /* compute_edit_distance (src/compute-alignments.c:240): equal strings short-cut on the host */
 uint32_t ef_compute_edit_distance(ef_backend* be, const char* a, size_t la, const char* b, size_t lb);
 /* write_multifasta_output (src/io-multifasta.c:187-246) */
-void ef_write_multifasta_output(const ef_seq* gen, const ef_est* e, FILE* f, char retain_externals);
-void ef_write_factorization_records(const ef_seq* gen, const ef_est* e, FILE* f, char retain_externals, uint32_t est_index);
+void ef_write_multifasta_output(const ef_seq* gen, const ef_est* e, ef_sink* f, char retain_externals);
+void ef_write_factorization_records(const ef_seq* gen, const ef_est* e, ef_sink* f, char retain_externals, uint32_t est_index);
 /* compute_est_fact (src/compute-est-fact.c:192-293) without the diagnostics side files */
-typedef struct { FILE *fmeg, *fpmeg, *ftmeg, *fintronic; } ef_side_files;
+typedef struct { ef_sink *fmeg, *fpmeg, *ftmeg, *fintronic; } ef_side_files;
 ef_est* ef_compute_est_fact(const ef_seq* gen, const ef_seq* est, ef_backend* be, const ef_config* cfg,
                             const ef_side_files* side);
 
@@ -253,10 +264,10 @@ ef_est* ef_compute_est_fact(const ef_seq* gen, const ef_seq* est, ef_backend* be
  * compaction, complexity retry loop.  *inc_pairing_len is updated like the reference's. */
 ef_meg* ef_build_meg(const ef_seq* est, ef_backend* be, const ef_config* shared_cfg, size_t* inc_pairing_len);
 
-void ef_write_single_est_info(FILE* f, const ef_seq* s);              /* src/io-multifasta.c:270 */
+void ef_write_single_est_info(ef_sink* f, const ef_seq* s);              /* src/io-multifasta.c:270 */
 
 typedef struct { ef_config cfg; ef_seq* gen; ef_seq** list; size_t n; } ef_inputs;
-typedef struct { FILE *flog, *fout, *fests; ef_side_files side; } ef_outputs;
+typedef struct { FILE* flog; ef_sink fout, fests, fmeg, fpmeg, ftmeg, fintronic; ef_side_files side; } ef_outputs;
 int ef_load_inputs(int argc, char** argv, ef_inputs* in);
 void ef_free_inputs(ef_inputs* in);
 int ef_open_outputs(ef_outputs* o);

@@ -33,7 +33,8 @@ int main(int argc, char** argv) {
   if (n < 0) return 1;
   orc_index* ix = orc_index_create(gen->seq, strlen(gen->seq));
   ef_backend be = { ix, oracle_pairings };
-  FILE* f = fopen("megs-check.txt", "w");
+  ef_sink sink = { fopen("megs-check.txt", "w"), NULL, 0, 0 };
+  ef_sink* f = &sink;
   for (long i = 0; i < n; ++i) {
     ef_seq* est = ests[i];
     ef_set_gb_identification(est);
@@ -44,12 +45,12 @@ int main(int argc, char** argv) {
     for (int k = 0; k < 2 && both[k]; ++k) {
       size_t inc = 0;
       ef_meg* V = ef_build_meg(both[k], &be, &cfg, &inc);
-      fprintf(f, "\n\n***********\n\n");
+      ef_sink_puts(f, "\n\n***********\n\n");
       ef_write_single_est_info(f, both[k]);
       ef_meg_write(f, V);
       ef_meg_free(V);
     }
   }
-  fclose(f);
+  fclose(sink.f);
   return 0;
 }
