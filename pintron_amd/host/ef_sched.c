@@ -191,7 +191,7 @@ typedef struct out_chunk { struct out_chunk* next; size_t cap, used; char data[]
 /* A worker keeps several independent sets of fibres ("lanes"): while the requests of one lane are
  * with the GPU service, the fibres of the other lanes run on the CPU, so the worker only sleeps
  * when every lane is waiting. */
-#define MAX_LANES 4
+#define MAX_LANES 8
 typedef struct lane {
   fiber** fibers; size_t n_fibers;
   ef_jobbuf jb;
@@ -692,7 +692,7 @@ ef_session* ef_session_open(int argc, char** argv) {
   pthread_mutex_init(&sh->svc.mu, NULL);
   pthread_cond_init(&sh->svc.posted, NULL);
   pthread_cond_init(&sh->svc.finished, NULL);
-  sh->svc.n_threads = (int)env_size("PINTRON_SERVICES", 2);
+  sh->svc.n_threads = (int)env_size("PINTRON_SERVICES", 3);
   if (sh->svc.n_threads > MAX_SERVICES) sh->svc.n_threads = MAX_SERVICES;
   for (int k = 0; k < sh->svc.n_threads; ++k) {
     if (pgpu_init(ef_gpu_device_from_env(), &sh->svc.threads[k].ctx) != PGPU_OK) { free(s); return NULL; }
@@ -705,11 +705,11 @@ ef_session* ef_session_open(int argc, char** argv) {
   const size_t cores = ncpu > 16 ? 16 : (ncpu > 0 ? (size_t)ncpu : 1);
   s->nthreads = env_size("PINTRON_THREADS", cores);
   if (s->nthreads > sh->n_units) s->nthreads = sh->n_units ? sh->n_units : 1;
-  sh->max_fibers = env_size("PINTRON_FIBERS", 768);
+  sh->max_fibers = env_size("PINTRON_FIBERS", 1024);
   sh->stack_size = env_size("PINTRON_FIBER_STACK_KB", 256) * 1024;
   sh->kernel_timing = env_flag("PINTRON_KERNEL_TIMING");
   sh->gen_len = strlen(in->gen->seq);
-  sh->n_lanes = (int)env_size("PINTRON_LANES", 3);
+  sh->n_lanes = (int)env_size("PINTRON_LANES", 4);
   if (sh->n_lanes > MAX_LANES) sh->n_lanes = MAX_LANES;
   s->load_s = t_loaded - t_start;
   s->index_s = now_s() - t_loaded;
