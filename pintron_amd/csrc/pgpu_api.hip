@@ -458,29 +458,58 @@ extern "C" int pgpu_dp_plan_launch(pgpu_ctx* ctx, pgpu_dp_plan* p) {
     HIP_TRY(ctx, hipEventRecord(ctx->ev_upload, ctx->stream));
     for (auto& a : ctx->aux) HIP_TRY(ctx, hipStreamWaitEvent(a, ctx->ev_upload, 0));
   }
-  size_t key_base = 0;
-  int slot = 0;
-  hipStream_t st = ctx->stream;
-  for (auto& g : p->groups) {
-    const DevJob* jobs = p->d_jobs + g.first;
-    const int n = (int)g.count;
-    if (!g.traceback) st = ctx->fanout ? ctx->aux[slot++ % pgpu_ctx::NAUX] : ctx->stream;   // a traceback follows its DP kernel
-    if (g.ev0) HIP_TRY(ctx, hipEventRecord(g.ev0, st));
-    if (g.traceback) {
-      if (g.family == KF_ALIGN) launch_align_traceback(jobs, n, p->d_results, p->d_ws, p->d_strs, st);
-      else launch_gap_traceback(jobs, n, p->d_results, p->d_ws, p->d_strs, st);
-    } else switch (g.family) {
-      case KF_ALIGN: case KF_ED: case KF_BORDERS: case KF_AFFIX: case KF_KBAND:
-        launch_lev(g.family, g.R, jobs, n, p->d_results, p->d_ws, st); break;
-      case KF_GAP: launch_gap(g.R, jobs, n, p->d_results, p->d_ws, st); break;
-      case KF_LCF:
-        launch_lcf(jobs, n, g.max_chunks, g.max_l2, p->d_keys + key_base, st);
-        launch_lcf_finish(jobs, n, p->d_results, p->d_keys + key_base, st);
-        key_base += g.count; break;
-      default: break;
+  // Launch order: the groups are independent, and the host needs a few microseconds per launch, so
+  // the long poles go first (one-job-per-workgroup sweeps with many rows, then the alignments with
+  // their tracebacks, ...) and the thousands of tiny edit distances last.  A traceback group
+  // directly follows its DP group in p->groups and stays behind it on the same stream.
+  std::vector<size_t> order;
+  std::vector<size_t> key_of(p->groups.size(), 0);
+  {
+    size_t kb = 0;
+    for (size_t gi = 0; gi < p->groups.size(); ++gi) {
+      const Group& g = p->groups[gi];
+      if (g.traceback) continue;
+      order.push_back(gi);
+      if (g.family == KF_LCF) { key_of[gi] = kb; kb += g.count; }
     }
-    if (g.ev1) HIP_TRY(ctx, hipEventRecord(g.ev1, st));
-    HIP_TRY(ctx, hipGetLastError());
+    auto weight = [&](size_t gi) -> long {
+      const Group& g = p->groups[gi];
+      switch (g.family) {
+        case KF_BORDERS: case KF_AFFIX: return g.R >= 2 ? 10000 + g.R : 150;
+        case KF_ALIGN: return 5000 + g.R;
+        case KF_GAP: return 4000 + g.R;
+        case KF_LCF: return 3000;
+        case KF_KBAND: return 2000 + g.R;
+        default: return 1000 + g.R;
+      }
+    };
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return weight(a) > weight(b); });
+  }
+  int slot = 0;
+  for (size_t oi = 0; oi < order.size(); ++oi) {
+    for (size_t gi = order[oi]; gi < p->groups.size() && (gi == order[oi] || p->groups[gi].traceback); ++gi) {
+      Group& g = p->groups[gi];
+      const DevJob* jobs = p->d_jobs + g.first;
+      const int n = (int)g.count;
+      hipStream_t st = ctx->fanout ? ctx->aux[slot % pgpu_ctx::NAUX] : ctx->stream;
+      if (g.ev0) HIP_TRY(ctx, hipEventRecord(g.ev0, st));
+      if (g.traceback) {
+        if (g.family == KF_ALIGN) launch_align_traceback(jobs, n, p->d_results, p->d_ws, p->d_strs, st);
+        else launch_gap_traceback(jobs, n, p->d_results, p->d_ws, p->d_strs, st);
+      } else switch (g.family) {
+        case KF_ALIGN: case KF_ED: case KF_BORDERS: case KF_AFFIX: case KF_KBAND:
+          launch_lev(g.family, g.R, jobs, n, p->d_results, p->d_ws, st); break;
+        case KF_GAP: launch_gap(g.R, jobs, n, p->d_results, p->d_ws, st); break;
+        case KF_LCF:
+          launch_lcf(jobs, n, g.max_chunks, g.max_l2, p->d_keys + key_of[gi], st);
+          launch_lcf_finish(jobs, n, p->d_results, p->d_keys + key_of[gi], st);
+          break;
+        default: break;
+      }
+      if (g.ev1) HIP_TRY(ctx, hipEventRecord(g.ev1, st));
+      HIP_TRY(ctx, hipGetLastError());
+    }
+    ++slot;
   }
   if (ctx->fanout) {            // join: the main stream continues after every auxiliary stream
     const int used = slot < pgpu_ctx::NAUX ? slot : pgpu_ctx::NAUX;
