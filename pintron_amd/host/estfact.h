@@ -153,14 +153,33 @@ static inline void ef_sink_write(ef_sink* s, const char* p, size_t n) {
 }
 static inline void ef_sink_puts(ef_sink* s, const char* str) { ef_sink_write(s, str, strlen(str)); }
 
-typedef struct { ef_sink* s; size_t n; char b[4096]; } ef_wbuf;
-static inline void efw_open(ef_wbuf* w, ef_sink* s) { w->s = s; w->n = 0; }
-static inline void efw_flush(ef_wbuf* w) { if (w->n) { ef_sink_write(w->s, w->b, w->n); w->n = 0; } }
-static inline void efw_ch(ef_wbuf* w, char c) { if (w->n == sizeof w->b) efw_flush(w); w->b[w->n++] = c; }
+/* A writer formats into [p, end): the tail of a memory sink itself (no staging copy), or a small
+ * staging buffer in front of a stream.  efw_flush() publishes what has been written. */
+typedef struct { ef_sink* s; char* p; char* end; char b[4096]; } ef_wbuf;
+static inline void efw_room(ef_wbuf* w, size_t need);
+static inline void efw_open(ef_wbuf* w, ef_sink* s) {
+  w->s = s;
+  if (s->f) { w->p = w->b; w->end = w->b + sizeof w->b; }
+  else { w->p = w->end = NULL; efw_room(w, 1024); }
+}
+static inline void efw_flush(ef_wbuf* w) {
+  if (w->s->f) { if (w->p != w->b) { fwrite(w->b, 1, (size_t)(w->p - w->b), w->s->f); w->p = w->b; } }
+  else if (w->p) w->s->len = (size_t)(w->p - w->s->mem);
+}
+/* at least `need` bytes at w->p (need <= 2048 for streams) */
+static inline void efw_room(ef_wbuf* w, size_t need) {
+  if (w->p && (size_t)(w->end - w->p) >= need) return;
+  ef_sink* s = w->s;
+  if (s->f) { efw_flush(w); return; }
+  if (w->p) s->len = (size_t)(w->p - s->mem);
+  if (s->len + need > s->cap) { s->cap = (s->len + need) * 2 + 4096; s->mem = (char*)realloc(s->mem, s->cap); }
+  w->p = s->mem + s->len; w->end = s->mem + s->cap;
+}
+static inline void efw_ch(ef_wbuf* w, char c) { efw_room(w, 1); *w->p++ = c; }
 static inline void efw_mem(ef_wbuf* w, const char* s, size_t n) {
-  if (n > sizeof w->b / 2) { efw_flush(w); ef_sink_write(w->s, s, n); return; }
-  if (w->n + n > sizeof w->b) efw_flush(w);
-  memcpy(w->b + w->n, s, n); w->n += n;
+  if (w->s->f && n > 2048) { efw_flush(w); fwrite(s, 1, n, w->s->f); return; }
+  efw_room(w, n);
+  memcpy(w->p, s, n); w->p += n;
 }
 static inline void efw_str(ef_wbuf* w, const char* s) { efw_mem(w, s, strlen(s)); }
 /* printf("%.*s"): at most `prec` characters, fewer when the string ends first */
@@ -173,9 +192,9 @@ static inline void efw_int(ef_wbuf* w, long long v) {                     /* pri
   char t[24]; int k = 0;
   unsigned long long u = v < 0 ? 0ull - (unsigned long long)v : (unsigned long long)v;
   do { t[k++] = (char)('0' + u % 10); u /= 10; } while (u);
-  if (w->n + 24 > sizeof w->b) efw_flush(w);
-  if (v < 0) w->b[w->n++] = '-';
-  while (k) w->b[w->n++] = t[--k];
+  efw_room(w, 24);
+  if (v < 0) *w->p++ = '-';
+  while (k) *w->p++ = t[--k];
 }
 
 /* ---- backend: where pairings and dynamic programs are computed ------------------------------ */
