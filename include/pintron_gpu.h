@@ -160,6 +160,13 @@ typedef struct {
 int pgpu_dp_plan_create(pgpu_ctx* ctx, const pgpu_index* idx,
                         const pgpu_dp_job* jobs, size_t n_jobs,
                         const char* arena, size_t arena_len, pgpu_dp_plan** plan);
+/* The same for a batch assembled from several producers (the host program's worker threads): the
+ * jobs of a part address that part's arena; results come back in the order of the parts, jobs of
+ * part 0 first.  Nothing is copied on the caller's side: the library gathers jobs and arenas
+ * straight into its pinned upload image. */
+typedef struct { const pgpu_dp_job* jobs; size_t n_jobs; const char* arena; size_t arena_len; } pgpu_dp_part;
+int pgpu_dp_plan_create_parts(pgpu_ctx* ctx, const pgpu_index* idx, const pgpu_dp_part* parts, size_t n_parts,
+                              pgpu_dp_plan** plan);
 int pgpu_dp_plan_launch(pgpu_ctx* ctx, pgpu_dp_plan* plan);
 int pgpu_dp_plan_sync(pgpu_ctx* ctx, pgpu_dp_plan* plan);
 /* bytes the alignment strings of this plan need in fetch's `strings` buffer */

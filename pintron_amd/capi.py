@@ -47,7 +47,7 @@ EXPORTS = [
     "pgpu_pairing_plan_create", "pgpu_pairing_plan_run", "pgpu_pairing_plan_count",
     "pgpu_pairing_plan_positions", "pgpu_pairing_plan_kernel_ms", "pgpu_pairing_plan_fetch",
     "pgpu_pairing_plan_destroy",
-    "pgpu_dp_plan_create", "pgpu_dp_plan_launch", "pgpu_dp_plan_sync",
+    "pgpu_dp_plan_create", "pgpu_dp_plan_create_parts", "pgpu_dp_plan_launch", "pgpu_dp_plan_sync",
     "pgpu_dp_plan_string_bytes", "pgpu_dp_plan_fetch", "pgpu_dp_plan_destroy",
     "pgpu_dp_plan_results_to_device",
     "pgpu_dp_plan_cells", "pgpu_dp_plan_algo_bytes", "pgpu_dp_plan_kernel_ms",
@@ -93,6 +93,7 @@ def lib():
         L.pgpu_pairing_plan_kernel_ms.restype = C.c_double
         L.pgpu_pairing_plan_fetch.argtypes = [vp, vp, C.POINTER(Pairing), sz, C.POINTER(u64)]
         L.pgpu_pairing_plan_destroy.argtypes = [vp, vp]
+        L.pgpu_dp_plan_create_parts.argtypes = [vp, vp, vp, sz, C.POINTER(vp)]
         L.pgpu_dp_plan_create.argtypes = [vp, vp, C.POINTER(DpJob), sz, C.c_char_p, sz,
                                           C.POINTER(vp)]
         L.pgpu_dp_plan_launch.argtypes = [vp, vp]
@@ -201,6 +202,10 @@ class PairingPlan:
             self.h = C.c_void_p()
 
 
+class DpPart(C.Structure):
+    _fields_ = [("jobs", C.c_void_p), ("n_jobs", C.c_size_t), ("arena", C.c_void_p), ("arena_len", C.c_size_t)]
+
+
 class JobList:
     """Accumulates DP jobs and their operand bytes (the arena)."""
 
@@ -245,6 +250,23 @@ class Plan:
         self.h = C.c_void_p()
         ctx.check(ctx.L.pgpu_dp_plan_create(ctx.h, index.h if index else None, self._jobs, self.n,
                                             self._arena, len(self._arena), C.byref(self.h)))
+
+    @classmethod
+    def from_parts(cls, ctx: Context, joblists, index: Index = None):
+        """One plan over several JobLists, each with its own arena (pgpu_dp_plan_create_parts)."""
+        self = cls.__new__(cls)
+        self.ctx = ctx
+        self.n = sum(len(jl.jobs) for jl in joblists)
+        self._keep = []
+        parts = (DpPart * max(len(joblists), 1))()
+        for k, jl in enumerate(joblists):
+            jobs, arena = jl.arrays()
+            buf = C.create_string_buffer(arena, len(arena) + 1)
+            self._keep += [jobs, buf]
+            parts[k] = DpPart(C.cast(jobs, C.c_void_p), len(jl.jobs), C.cast(buf, C.c_void_p), len(arena))
+        self.h = C.c_void_p()
+        ctx.check(ctx.L.pgpu_dp_plan_create_parts(ctx.h, index.h if index else None, parts, len(joblists), C.byref(self.h)))
+        return self
 
     def launch(self):
         self.ctx.check(self.ctx.L.pgpu_dp_plan_launch(self.ctx.h, self.h))

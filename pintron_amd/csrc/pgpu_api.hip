@@ -230,8 +230,19 @@ static void plan_free(pgpu_dp_plan* p) {
 extern "C" int pgpu_dp_plan_create(pgpu_ctx* ctx, const pgpu_index* idx, const pgpu_dp_job* jobs,
                                    size_t n_jobs, const char* arena, size_t arena_len,
                                    pgpu_dp_plan** out) {
-  if (!ctx || !out || (n_jobs && !jobs) || (arena_len && !arena)) return set_err(ctx, PGPU_EINVAL, "bad argument");
+  const pgpu_dp_part one = { jobs, n_jobs, arena, arena_len };
+  return pgpu_dp_plan_create_parts(ctx, idx, &one, 1, out);
+}
+
+extern "C" int pgpu_dp_plan_create_parts(pgpu_ctx* ctx, const pgpu_index* idx, const pgpu_dp_part* parts,
+                                         size_t n_parts, pgpu_dp_plan** out) {
+  if (!ctx || !out || (n_parts && !parts)) return set_err(ctx, PGPU_EINVAL, "bad argument");
   *out = nullptr;
+  size_t n_jobs = 0, arena_len = 0;
+  for (size_t q = 0; q < n_parts; ++q) {
+    if ((parts[q].n_jobs && !parts[q].jobs) || (parts[q].arena_len && !parts[q].arena)) return set_err(ctx, PGPU_EINVAL, "bad argument");
+    n_jobs += parts[q].n_jobs; arena_len += parts[q].arena_len;
+  }
   if (n_jobs > 0x7fffffffu) return set_err(ctx, PGPU_EINVAL, "too many jobs");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   pgpu_dp_plan* p = new (std::nothrow) pgpu_dp_plan();
@@ -248,18 +259,22 @@ extern "C" int pgpu_dp_plan_create(pgpu_ctx* ctx, const pgpu_index* idx, const p
   struct Keyed { DevJob j; uint64_t a_off, b_off; bool ag, bg; int family; int kind; uint32_t R; uint64_t size; };
   std::vector<Keyed> v;
   v.reserve(n_jobs);
-  for (size_t i = 0; i < n_jobs; ++i) {
-    const pgpu_dp_job& in = jobs[i];
+  // jobs of part q address part q's arena; the arenas are laid out one after the other
+  size_t i = 0, part_base = 0, part_i = 0, part_left = n_parts ? parts[0].n_jobs : 0;
+  for (; i < n_jobs; ++i, --part_left) {
+    while (part_left == 0) { part_base += parts[part_i].arena_len; ++part_i; part_left = parts[part_i].n_jobs; }
+    const pgpu_dp_job& in = parts[part_i].jobs[parts[part_i].n_jobs - part_left];
+    const size_t own_arena = parts[part_i].arena_len;
     pgpu_dp_result& pre = p->prefill[i];
     pre.status = PGPU_EINVAL;
     if (in.kind >= PGPU_DP_NKINDS) continue;
     const bool ag = in.flags & PGPU_JOB_A_GENOMIC, bg = in.flags & PGPU_JOB_B_GENOMIC;
     if ((ag || bg) && !d_gen) continue;
-    const size_t a_space = ag ? gen_len : arena_len, b_space = bg ? gen_len : arena_len;
+    const size_t a_space = ag ? gen_len : own_arena, b_space = bg ? gen_len : own_arena;
     if (in.a_off > a_space || in.a_len > a_space - in.a_off) continue;
     if (in.b_off > b_space || in.b_len > b_space - in.b_off) continue;
     Keyed k{};
-    k.a_off = in.a_off; k.b_off = in.b_off; k.ag = ag; k.bg = bg;
+    k.a_off = in.a_off + (ag ? 0 : part_base); k.b_off = in.b_off + (bg ? 0 : part_base); k.ag = ag; k.bg = bg;
     k.j.la = in.a_len; k.j.lb = in.b_len;
     k.j.p0 = in.p0; k.j.p1 = in.p1; k.j.p2 = in.p2; k.j.tail = in.tail;
     k.j.out_idx = (uint32_t)i;
@@ -333,7 +348,7 @@ extern "C" int pgpu_dp_plan_create(pgpu_ctx* ctx, const pgpu_index* idx, const p
 
   // launch groups
   auto cells_of = [](const Keyed& k) -> uint64_t { return k.size; };
-  size_t i = 0;
+  i = 0;
   while (i < v.size()) {
     size_t j = i;
     Group g{};
@@ -434,7 +449,10 @@ extern "C" int pgpu_dp_plan_create(pgpu_ctx* ctx, const pgpu_index* idx, const p
 
   // the upload image: operands, the sorted job table with device pointers, zeroed LCF keys,
   // prefilled results (status of the jobs that never reach the device)
-  if (arena_len) memcpy(p->h_up + off_arena, arena, arena_len);
+  {
+    size_t at = off_arena;
+    for (size_t q = 0; q < n_parts; ++q) { if (parts[q].arena_len) memcpy(p->h_up + at, parts[q].arena, parts[q].arena_len); at += parts[q].arena_len; }
+  }
   DevJob* hj = (DevJob*)(p->h_up + off_jobs);
   for (size_t q = 0; q < v.size(); ++q) {
     DevJob d = v[q].j;

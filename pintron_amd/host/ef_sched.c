@@ -400,8 +400,7 @@ static void* service_main(void* arg) {
   service_thread* me = (service_thread*)arg;
   service* sv = me->sv;
   shared* sh = sv->sh;
-  pgpu_dp_job* jobs = NULL; size_t jobs_cap = 0;
-  char* arena = NULL; size_t arena_cap = 0;
+  pgpu_dp_part* parts = NULL; size_t parts_cap = 0;
   for (;;) {
     pthread_mutex_lock(&sv->mu);
     const double t_idle = now_s();
@@ -412,21 +411,18 @@ static void* service_main(void* arg) {
     const bool stop = sv->stop;
     pthread_mutex_unlock(&sv->mu);
     if (!list) { if (stop) break; else continue; }
-    size_t nj = 0, na = 0; int nreq = 0;
-    for (dp_request* r = list; r; r = r->next) { nj += r->n; na += r->arena_len; ++nreq; }
-    if (nj > jobs_cap) { jobs_cap = nj * 2; jobs = (pgpu_dp_job*)realloc(jobs, jobs_cap * sizeof(pgpu_dp_job)); }
-    if (na + 16 > arena_cap) { arena_cap = (na + 16) * 2; arena = (char*)realloc(arena, arena_cap); }
-    size_t jpos = 0, apos = 0;
-    for (dp_request* r = list; r; r = r->next) {
-      r->base = jpos;
-      memcpy(jobs + jpos, r->jobs, r->n * sizeof(pgpu_dp_job));
-      memcpy(arena + apos, r->arena, r->arena_len);
-      for (size_t i = 0; i < r->n; ++i) {
-        pgpu_dp_job* j = &jobs[jpos + i];
-        if (!(j->flags & PGPU_JOB_A_GENOMIC)) j->a_off += apos;
-        if (!(j->flags & PGPU_JOB_B_GENOMIC)) j->b_off += apos;
+    /* the requests of the posters become the parts of one plan: the library gathers their jobs and
+     * operand arenas straight into its pinned upload image */
+    size_t nj = 0; int nreq = 0;
+    for (dp_request* r = list; r; r = r->next) ++nreq;
+    if ((size_t)nreq > parts_cap) { parts_cap = (size_t)nreq * 2; parts = (pgpu_dp_part*)realloc(parts, parts_cap * sizeof(pgpu_dp_part)); }
+    {
+      size_t q = 0;
+      for (dp_request* r = list; r; r = r->next, ++q) {
+        r->base = nj;
+        parts[q].jobs = r->jobs; parts[q].n_jobs = r->n; parts[q].arena = r->arena; parts[q].arena_len = r->arena_len;
+        nj += r->n;
       }
-      jpos += r->n; apos += r->arena_len;
     }
     merged_batch* mb = (merged_batch*)calloc(1, sizeof(merged_batch));
     mb->refs = nreq;
@@ -434,7 +430,7 @@ static void* service_main(void* arg) {
     pgpu_dp_plan* plan = NULL;
     const double t_a = now_s();
     me->phase_s[1] += t_a - t_idle - 0;        /* (includes the idle wait; corrected below) */
-    int rc = pgpu_dp_plan_create(me->ctx, sh->idx, jobs, nj, arena, apos, &plan);
+    int rc = pgpu_dp_plan_create_parts(me->ctx, sh->idx, parts, (size_t)nreq, &plan);
     const double t_b = now_s();
     if (rc == PGPU_OK) rc = pgpu_dp_plan_launch(me->ctx, plan);
     const double t_c = now_s();
@@ -466,7 +462,7 @@ static void* service_main(void* arg) {
     pthread_cond_broadcast(&sv->finished);
     pthread_mutex_unlock(&sv->mu);
   }
-  free(jobs); free(arena);
+  free(parts);
   return NULL;
 }
 

@@ -138,6 +138,26 @@ static void cached_job(const pgpu_dp_plan* p, size_t i, char* strs, size_t* spos
   }
 }
 
+int pgpu_dp_plan_create_parts(pgpu_ctx* ctx, const pgpu_index* idx, const pgpu_dp_part* parts, size_t n_parts, pgpu_dp_plan** out) {
+  size_t nj = 0, na = 0;
+  for (size_t q = 0; q < n_parts; ++q) { nj += parts[q].n_jobs; na += parts[q].arena_len; }
+  pgpu_dp_job* jobs = (pgpu_dp_job*)malloc((nj + 1) * sizeof(pgpu_dp_job));
+  char* arena = (char*)malloc(na + 8);
+  size_t jp = 0, ap = 0;
+  for (size_t q = 0; q < n_parts; ++q) {
+    memcpy(jobs + jp, parts[q].jobs, parts[q].n_jobs * sizeof(pgpu_dp_job));
+    memcpy(arena + ap, parts[q].arena, parts[q].arena_len);
+    for (size_t i = 0; i < parts[q].n_jobs; ++i) {
+      if (!(jobs[jp + i].flags & PGPU_JOB_A_GENOMIC)) jobs[jp + i].a_off += ap;
+      if (!(jobs[jp + i].flags & PGPU_JOB_B_GENOMIC)) jobs[jp + i].b_off += ap;
+    }
+    jp += parts[q].n_jobs; ap += parts[q].arena_len;
+  }
+  const int rc = pgpu_dp_plan_create(ctx, idx, jobs, nj, arena, na, out);
+  free(jobs); free(arena);
+  return rc;
+}
+
 int pgpu_dp_plan_launch(pgpu_ctx* ctx, pgpu_dp_plan* p) {
   (void)ctx;
   p->res = (pgpu_dp_result*)malloc((p->n + 1) * sizeof(pgpu_dp_result));

@@ -36,6 +36,32 @@ def test_c3_sample_golden_vectors(gpu_ctx, O):
     run_and_check(gpu_ctx, O, [c for c, _ in pairs], [e for _, e in pairs])
 
 
+def test_plan_from_parts_equals_one_plan(gpu_ctx, O):
+    """pgpu_dp_plan_create_parts: a batch assembled from several producers (each with its own operand
+    arena, one of them empty) gives, part after part, what plans of their own give."""
+    import pintron_amd.capi as capi
+    rng = random.Random(44)
+    groups = [D.random_cases(rng, n_per_kind=4, max_len=200), [], D.random_cases(rng, n_per_kind=2, max_len=500),
+              D.random_cases(rng, n_per_kind=1, max_len=60)]
+    lists = []
+    for cases in groups:
+        jl = capi.JobList()
+        for c in cases:
+            c.add_to(jl)
+        lists.append(jl)
+    separate = [o for jl in lists if jl.jobs for o in capi.run_jobs(gpu_ctx, jl)]
+    plan = capi.Plan.from_parts(gpu_ctx, lists)
+    try:
+        plan.launch()
+        plan.sync()
+        res, strings = plan.fetch()
+        kinds = [j.kind for jl in lists for j in jl.jobs]
+        merged = [capi.decode(kinds[i], res[i], strings) for i in range(plan.n)]
+    finally:
+        plan.close()
+    assert merged == separate and len(merged) == sum(len(g) for g in groups)
+
+
 def test_edge_cases(gpu_ctx, O):
     run_and_check(gpu_ctx, O, D.edge_cases())
 
