@@ -537,18 +537,30 @@ static void* worker_main(void* arg) {
     ef_jobbuf_init(&ln->jb);
   }
   bool more = true;
+  int cursor = 0;
   while (!sh->failed) {
-    bool any = false;
-    for (int li = 0; li < n_lanes && !sh->failed; ++li) {
-      lane* ln = &w->lanes[li];
-      double t0 = now_s();
-      if (collect_dp(w, ln) != 0) { sh->failed = 1; break; }        /* blocks only on THIS lane's batch */
-      w->stats.dp_s += now_s() - t0;
-      while (more && ln->n_fibers < per_lane) more = start_fiber(w, li);
-      if (ln->n_fibers == 0) continue;
-      any = true;
-      /* run every runnable fibre of the lane until it blocks or ends (the other lane's batch,
-       * if any, is executing on the GPU meanwhile) */
+    /* next lane: the first one (round robin) that is not waiting for the GPU -- nothing posted, or
+     * its batch is back; when every lane is in flight, sleep on the one posted longest ago */
+    int li = -1, first_posted = -1;
+    for (int k = 0; k < n_lanes; ++k) {
+      const int idx = (cursor + k) % n_lanes;
+      lane* c = &w->lanes[idx];
+      if (c->posted) {
+        if (__atomic_load_n(&c->rq.done, __ATOMIC_ACQUIRE)) { li = idx; break; }
+        if (first_posted < 0) first_posted = idx;
+      } else if (c->n_fibers > 0 || more) { li = idx; break; }
+    }
+    if (li < 0) li = first_posted;       /* everything that has work is on the GPU: wait for it */
+    if (li < 0) break;                   /* no fibres, no ESTs left, nothing in flight */
+    cursor = (li + 1) % n_lanes;
+    lane* ln = &w->lanes[li];
+    double t0 = now_s();
+    if (collect_dp(w, ln) != 0) { sh->failed = 1; break; }
+    w->stats.dp_s += now_s() - t0;
+    while (more && ln->n_fibers < per_lane) more = start_fiber(w, li);
+    if (ln->n_fibers > 0) {
+      /* run every runnable fibre of the lane until it blocks or ends (the batches of the other
+       * lanes are on the GPU meanwhile) */
       t0 = now_s();
       for (size_t i = 0; i < ln->n_fibers; ++i) {
         fiber* f = ln->fibers[i];
@@ -576,7 +588,6 @@ static void* worker_main(void* arg) {
       w->stats.dp_s += now_s() - t0;
       if (brc != 0) { sh->failed = 1; break; }
     }
-    if (!any && !more) break;
   }
   for (int li = 0; li < n_lanes; ++li) {
     lane* ln = &w->lanes[li];
