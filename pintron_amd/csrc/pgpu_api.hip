@@ -35,6 +35,7 @@ struct pgpu_ctx {
   hipEvent_t ev_upload = nullptr;
   hipEvent_t ev_aux[NAUX] = {nullptr};
   bool fanout = true;        // spread groups over the auxiliary streams (PGPU_FANOUT=0 disables)
+  int n_aux = NAUX;          // how many of them are used (PGPU_STREAMS=1..8)
   // waiting: a blocking-sync event lets the calling thread SLEEP until the batch is done (the
   // default HIP wait spins and would burn a host core that other EST fibres could use)
   hipEvent_t ev_done = nullptr;
@@ -138,6 +139,7 @@ extern "C" int pgpu_init(int device, pgpu_ctx** out) {
   for (auto& e : ctx->ev_aux)
     if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete ctx; return PGPU_EDEVICE; }
   { const char* f = getenv("PGPU_FANOUT"); ctx->fanout = !(f && f[0] == '0'); }
+  { const char* f = getenv("PGPU_STREAMS"); const int v = f ? atoi(f) : 0; if (v >= 1 && v <= pgpu_ctx::NAUX) ctx->n_aux = v; }
   *out = ctx;
   return PGPU_OK;
 }
@@ -509,7 +511,7 @@ extern "C" int pgpu_dp_plan_launch(pgpu_ctx* ctx, pgpu_dp_plan* p) {
       Group& g = p->groups[gi];
       const DevJob* jobs = p->d_jobs + g.first;
       const int n = (int)g.count;
-      hipStream_t st = ctx->fanout ? ctx->aux[slot % pgpu_ctx::NAUX] : ctx->stream;
+      hipStream_t st = ctx->fanout ? ctx->aux[slot % ctx->n_aux] : ctx->stream;
       if (g.ev0) HIP_TRY(ctx, hipEventRecord(g.ev0, st));
       if (g.traceback) {
         if (g.family == KF_ALIGN) launch_align_traceback(jobs, n, p->d_results, p->d_ws, p->d_strs, st);
@@ -530,7 +532,7 @@ extern "C" int pgpu_dp_plan_launch(pgpu_ctx* ctx, pgpu_dp_plan* p) {
     ++slot;
   }
   if (ctx->fanout) {            // join: the main stream continues after every auxiliary stream
-    const int used = slot < pgpu_ctx::NAUX ? slot : pgpu_ctx::NAUX;
+    const int used = slot < ctx->n_aux ? slot : ctx->n_aux;
     for (int i = 0; i < used; ++i) {
       HIP_TRY(ctx, hipEventRecord(ctx->ev_aux[i], ctx->aux[i]));
       HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_aux[i], 0));
