@@ -148,9 +148,15 @@ static void* prep_main(void* arg) {
 
 /* inputs of one est-fact run: configuration, genomic, prepared EST list (siblings interleaved) */
 int ef_load_inputs(int argc, char** argv, ef_inputs* in) {
+  const int rc = ef_load_genomic(argc, argv, in);
+  return rc ? rc : ef_load_ests(in);
+}
+
+/* first half: configuration + genomic.txt (enough to start building the index) */
+int ef_load_genomic(int argc, char** argv, ef_inputs* in) {
   memset(in, 0, sizeof(*in));
   if (ef_config_load(&in->cfg, argc, argv) != 0) return 2;
-  ef_seq** gens = NULL; ef_seq** ests = NULL;
+  ef_seq** gens = NULL;
   const long ng = ef_read_multifasta("genomic.txt", &gens);
   if (ng < 0) { fprintf(stderr, "* FATAL File genomic.txt not found! Terminating\n"); return 1; }
   if (ng != 1) { fprintf(stderr, "* FATAL genomic.txt must hold exactly one sequence\n"); return 1; }
@@ -159,6 +165,12 @@ int ef_load_inputs(int argc, char** argv, ef_inputs* in) {
   ef_parse_genomic_header(in->gen);
   if (ef_ntails_removal(in->gen) != 0) { fprintf(stderr, "* FATAL The sequence is only composed by Ns.\n"); return 1; }
   ef_seq_index_kmers(in->gen);
+  return 0;
+}
+
+/* second half: ests.txt and the preparation of every EST */
+int ef_load_ests(ef_inputs* in) {
+  ef_seq** ests = NULL;
   const long n_in = ef_read_multifasta("ests.txt", &ests);
   if (n_in < 0) { fprintf(stderr, "* FATAL File ests.txt not found! Terminating\n"); return 1; }
   /* preparation loop (src/main-est-fact.c:190-213): every EST is prepared on its own, so the

@@ -630,11 +630,16 @@ struct ef_session {
   double load_s, index_s;
 };
 
-/* bringing up the HIP runtime takes a few tenths of a second: it runs beside the input parsing */
-typedef struct { pgpu_ctx* ctx; int rc; } gpu_boot;
+/* bringing up the HIP runtime takes a few tenths of a second and the index a tenth: both run
+ * beside the parsing and preparation of the ESTs (the genomic sequence is loaded first) */
+typedef struct { pgpu_ctx* ctx; int rc; const char* gen; size_t gen_len; pgpu_index* idx; int idx_rc; } gpu_boot;
 static void* gpu_boot_main(void* arg) {
   gpu_boot* b = (gpu_boot*)arg;
   b->rc = pgpu_init(ef_gpu_device_from_env(), &b->ctx);
+  if (b->rc == PGPU_OK) {
+    if (env_flag("PINTRON_KERNEL_TIMING")) pgpu_set_timing(b->ctx, 1);
+    b->idx_rc = pgpu_index_build(b->ctx, b->gen, b->gen_len, &b->idx);
+  }
   return NULL;
 }
 
@@ -645,10 +650,12 @@ ef_session* ef_session_open(int argc, char** argv) {
   mallopt(M_TRIM_THRESHOLD, 512 << 20);
   mallopt(M_TOP_PAD, 16 << 20);
   ef_session* s = (ef_session*)calloc(1, sizeof(ef_session));
-  gpu_boot boot = { NULL, PGPU_EDEVICE };
+  int load_rc = ef_load_genomic(argc, argv, &s->in);
+  if (load_rc != 0) { free(s); return NULL; }
+  gpu_boot boot = { NULL, PGPU_EDEVICE, s->in.gen->seq, strlen(s->in.gen->seq), NULL, PGPU_EDEVICE };
   pthread_t boot_thread;
   const bool booting = pthread_create(&boot_thread, NULL, gpu_boot_main, &boot) == 0;
-  const int load_rc = ef_load_inputs(argc, argv, &s->in);
+  load_rc = ef_load_ests(&s->in);
   ef_classify_init();
   const double t_loaded = now_s();
   if (booting) pthread_join(boot_thread, NULL); else gpu_boot_main(&boot);
@@ -661,11 +668,11 @@ ef_session* ef_session_open(int argc, char** argv) {
   ef_inputs* in = &s->in;
   shared* sh = &s->sh;
   sh->in = in;
-  if (env_flag("PINTRON_KERNEL_TIMING")) pgpu_set_timing(s->ctx0, 1);
-  if (pgpu_index_build(s->ctx0, in->gen->seq, strlen(in->gen->seq), &sh->idx) != PGPU_OK) {
+  if (boot.idx_rc != PGPU_OK) {
     fprintf(stderr, "* FATAL pgpu_index_build: %s\n", pgpu_last_error(s->ctx0));
     free(s); return NULL;
   }
+  sh->idx = boot.idx;
   sh->units = (unit*)calloc(in->n + 1, sizeof(unit));
   for (size_t k = 0; k < in->n;) {
     unit* u = &sh->units[sh->n_units++];

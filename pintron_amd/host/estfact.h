@@ -287,7 +287,9 @@ void ef_write_single_est_info(ef_sink* f, const ef_seq* s);              /* src/
 
 typedef struct { ef_config cfg; ef_seq* gen; ef_seq** list; size_t n; } ef_inputs;
 typedef struct { FILE* flog; ef_sink fout, fests, fmeg, fpmeg, ftmeg, fintronic; ef_side_files side; } ef_outputs;
-int ef_load_inputs(int argc, char** argv, ef_inputs* in);
+int ef_load_inputs(int argc, char** argv, ef_inputs* in);     /* = ef_load_genomic + ef_load_ests */
+int ef_load_genomic(int argc, char** argv, ef_inputs* in);
+int ef_load_ests(ef_inputs* in);
 void ef_free_inputs(ef_inputs* in);
 int ef_open_outputs(ef_outputs* o);
 void ef_close_outputs(ef_outputs* o);
