@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <new>
 #include <string>
 #include <vector>
@@ -318,12 +319,25 @@ extern "C" int pgpu_dp_plan_create_parts(pgpu_ctx* ctx, const pgpu_index* idx, c
   }
   // order: family, row class, then largest first (long jobs start early; waves of a workgroup
   // and threads of a traceback wave get similar sizes)
-  std::stable_sort(v.begin(), v.end(), [](const Keyed& x, const Keyed& y) {
-    if (x.family != y.family) return x.family < y.family;
-    if (x.R != y.R) return x.R < y.R;
-    return x.size > y.size;
-  });
-
+  // A counting sort does it in three passes: 13-bit key = family, row class, and the size reduced to
+  // its binary order of magnitude (descending); jobs with the same key keep the caller's order.
+  {
+    auto key_of = [](const Keyed& k) -> uint32_t {
+      uint32_t rcls = 0;
+      while ((1u << rcls) < k.R) ++rcls;                                  // R = 0,1,2,4,...,128 -> 0..7
+      const uint32_t mag = 63u - (uint32_t)__builtin_clzll(k.size | 1ull);  // floor(log2(size)), 0..63
+      return ((uint32_t)k.family << 10) | (rcls << 6) | (63u - mag);
+    };
+    constexpr uint32_t NKEYS = 8u << 10;
+    std::vector<uint32_t> start(NKEYS + 1, 0);
+    std::vector<uint32_t> kk(v.size());
+    for (size_t q = 0; q < v.size(); ++q) { kk[q] = key_of(v[q]); ++start[kk[q] + 1]; }
+    for (uint32_t c = 0; c < NKEYS; ++c) start[c + 1] += start[c];
+    std::vector<Keyed> sorted;
+    sorted.resize(v.size());
+    for (size_t q = 0; q < v.size(); ++q) sorted[start[kk[q]]++] = v[q];
+    v.swap(sorted);
+  }
   // workspaces and string slots
   size_t ws = 0, strs = 0, nkeys = 0;
   for (auto& k : v) {
