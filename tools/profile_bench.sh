@@ -7,7 +7,7 @@ python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err 
 tail -1 gpurun_out/bench_default.json | cut -c1-600
 export TMPDIR=/tmp
 rm -rf gpurun_out/prof_bench
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_bench -o bench -- python3 bench.py --steps 3 --warmup 1 --no-cpu > gpurun_out/bench_under_rocprof.json 2> gpurun_out/rocprof.err || { tail -5 gpurun_out/rocprof.err; exit 1; }
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_bench -o bench -- python3 bench.py --steps 5 --warmup 1 --no-cpu > gpurun_out/bench_under_rocprof.json 2> gpurun_out/rocprof.err || { tail -5 gpurun_out/rocprof.err; exit 1; }
 find gpurun_out/prof_bench -name '*kernel_stats.csv' | while read f; do cp "$f" gpurun_out/bench_kernel_stats.csv; done
 find gpurun_out/prof_bench -name '*kernel_trace.csv' -delete
 head -12 gpurun_out/bench_kernel_stats.csv
