@@ -154,9 +154,11 @@ typedef struct {
 #define PGPU_MAX_COLS      1048576u
 
 /* A plan holds a batch of jobs resident in HBM: operands, sorted job table, workspaces, results.
- * create = sort by kernel/size + upload; launch = enqueue every kernel of the batch on the
- * context's stream (asynchronous); sync = wait; fetch = copy results (and alignment strings)
- * back in the caller's job order.  idx may be NULL when no job uses PGPU_JOB_*_GENOMIC. */
+ * create = sort by kernel/size + one upload; launch = enqueue every kernel of the batch (fanned
+ * over the context's streams, asynchronous) and, behind them, the download of results and
+ * alignment strings; sync = wait; fetch = hand the results out in the caller's job order.
+ * idx may be NULL when no job uses PGPU_JOB_*_GENOMIC.  One plan per context at a time is the
+ * fast path (its device and pinned buffers are the context's own). */
 int pgpu_dp_plan_create(pgpu_ctx* ctx, const pgpu_index* idx,
                         const pgpu_dp_job* jobs, size_t n_jobs,
                         const char* arena, size_t arena_len, pgpu_dp_plan** plan);
