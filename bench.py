@@ -43,16 +43,16 @@ def rocprof_symbol(group_name):
     """Kernel symbol (as rocprofv3 prints it) of a kernel group name reported by the library."""
     import re
     modes = {"ED": 0, "ALIGN": 1, "BORDERS": 2, "AFFIX": 3, "KBAND": 4}
-    m = re.match(r"lev_wave<(\w+),R=(\d+)>", group_name)
+    m = re.match(r"lev_wave<(\w+)>$", group_name)                 # every row class in one launch
     if m:
-        return "lev_wave_kernel<%s, %d>" % (m.group(2), modes[m.group(1)])
-    m = re.match(r"gap_wave<R=(\d+)>", group_name)
+        return "lev_any_kernel<%d>" % modes[m.group(1)]
+    m = re.match(r"lev_wave<(\w+),R=1>", group_name)
     if m:
-        return "gap_wave_kernel<%s>" % m.group(1)
-    m = re.match(r"(borders|affix)_coop<rows<=(\d+)>", group_name)
-    if m:
-        return "%s_coop_kernel<%d>" % (m.group(1), max(1, int(m.group(2)) // 256))
-    return {"lcf": "lcf_kernel", "align_traceback": "align_traceback_wave_kernel",
+        return "lev_wave_kernel<1, %d, false>" % modes[m.group(1)]
+    if group_name == "lev_wave<AFFIX,strips>":
+        return "lev_wave_kernel<64, 3, true>"
+    return {"gap_wave": "gap_any_kernel", "borders_coop": "borders_coop_any_kernel", "affix_coop": "affix_coop_any_kernel",
+            "lcf": "lcf_kernel", "align_traceback": "align_traceback_wave_kernel",
             "gap_traceback": "gap_traceback_wave_kernel"}.get(group_name, group_name.split("+")[0] + "_kernel")
 
 

@@ -174,6 +174,7 @@ struct Group {
   int R;                 // row class (0 when not applicable)
   size_t first, count;   // slice of the sorted device job table
   uint32_t max_chunks = 0, max_l2 = 0;
+  uint32_t max_rows = 0;       // largest a_len of the group (LDS of the one-job-per-workgroup BORDERS kernel)
   bool traceback = false;      // this group is the traceback pass of (family)
   uint64_t cells = 0, algo_bytes = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -319,14 +320,15 @@ extern "C" int pgpu_dp_plan_create_parts(pgpu_ctx* ctx, const pgpu_index* idx, c
   }
   // order: family, row class, then largest first (long jobs start early; waves of a workgroup
   // and threads of a traceback wave get similar sizes)
-  // A counting sort does it in three passes: 13-bit key = family, row class, and the size reduced to
-  // its binary order of magnitude (descending); jobs with the same key keep the caller's order.
+  // A counting sort does it in three passes: 13-bit key = family, row class (descending) and the
+  // size reduced to its binary order of magnitude (descending); jobs with the same key keep the
+  // caller's order.
   {
     auto key_of = [](const Keyed& k) -> uint32_t {
       uint32_t rcls = 0;
       while ((1u << rcls) < k.R) ++rcls;                                  // R = 0,1,2,4,...,128 -> 0..7
       const uint32_t mag = 63u - (uint32_t)__builtin_clzll(k.size | 1ull);  // floor(log2(size)), 0..63
-      return ((uint32_t)k.family << 10) | (rcls << 6) | (63u - mag);
+      return ((uint32_t)k.family << 10) | ((7u - rcls) << 6) | (63u - mag);   // long jobs first
     };
     constexpr uint32_t NKEYS = 8u << 10;
     std::vector<uint32_t> start(NKEYS + 1, 0);
@@ -367,9 +369,15 @@ extern "C" int pgpu_dp_plan_create_parts(pgpu_ctx* ctx, const pgpu_index* idx, c
   i = 0;
   while (i < v.size()) {
     size_t j = i;
+    // a launch group = a family; BORDERS and AFFIX split into (up to 64 rows: one wave per job),
+    // (more rows: one job per workgroup) and, AFFIX only, (beyond 4096 rows: strips)
+    auto variant = [](const Keyed& k) -> int {
+      if (k.family != KF_BORDERS && k.family != KF_AFFIX) return 0;
+      return k.R == 1 ? 1 : (k.R == ROW_CLASS_STRIPS ? (int)ROW_CLASS_STRIPS : 0);
+    };
     Group g{};
-    g.family = v[i].family; g.kind = v[i].kind; g.R = (int)v[i].R; g.first = i;
-    while (j < v.size() && v[j].family == g.family && v[j].R == v[i].R &&
+    g.family = v[i].family; g.kind = v[i].kind; g.R = variant(v[i]); g.first = i;
+    while (j < v.size() && v[j].family == g.family && variant(v[j]) == g.R &&
            (g.family != KF_LCF || j - i < 65535)) {
       const Keyed& k = v[j];
       const uint64_t la = k.j.la, lb = k.j.lb;
@@ -377,6 +385,7 @@ extern "C" int pgpu_dp_plan_create_parts(pgpu_ctx* ctx, const pgpu_index* idx, c
       // algorithmic HBM bytes: operands once; 1 B/cell of directions for
       // ALIGN, 3 B/cell for GAP; 8 B per row when row minima are produced
       g.algo_bytes += la + lb;
+      g.max_rows = std::max(g.max_rows, (uint32_t)la);
       if (k.family == KF_ALIGN) g.algo_bytes += la * lb;
       if (k.family == KF_GAP) g.algo_bytes += 3 * la * lb;
       if (k.family == KF_BORDERS) g.algo_bytes += 2 * 8 * la;
@@ -389,13 +398,12 @@ extern "C" int pgpu_dp_plan_create_parts(pgpu_ctx* ctx, const pgpu_index* idx, c
     }
     g.count = j - i;
     char nm[64];
-    static const char* fam[] = {"lev_wave<ALIGN", "gap_wave<", "lev_wave<ED", "lev_wave<KBAND", "lcf",
-                                "lev_wave<BORDERS", "lev_wave<AFFIX"};
-    if (g.family == KF_LCF) snprintf(nm, sizeof nm, "%s", fam[g.family]);
-    else if (g.R == (int)ROW_CLASS_STRIPS) snprintf(nm, sizeof nm, "%s,R=64 strips>", fam[g.family]);
-    else if ((g.family == KF_BORDERS || g.family == KF_AFFIX) && g.R >= 2)   // one job per workgroup
-      snprintf(nm, sizeof nm, "%s<rows<=%d>", g.family == KF_BORDERS ? "borders_coop" : "affix_coop", 64 * g.R);
-    else snprintf(nm, sizeof nm, "%s%sR=%d>", fam[g.family], g.family == KF_GAP ? "" : ",", g.R);
+    static const char* fam[] = {"lev_wave<ALIGN>", "gap_wave", "lev_wave<ED>", "lev_wave<KBAND>", "lcf",
+                                "borders_coop", "affix_coop"};
+    if (g.family == KF_BORDERS && g.R == 1) snprintf(nm, sizeof nm, "lev_wave<BORDERS,R=1>");
+    else if (g.family == KF_AFFIX && g.R == 1) snprintf(nm, sizeof nm, "lev_wave<AFFIX,R=1>");
+    else if (g.family == KF_AFFIX && g.R == (int)ROW_CLASS_STRIPS) snprintf(nm, sizeof nm, "lev_wave<AFFIX,strips>");
+    else snprintf(nm, sizeof nm, "%s", fam[g.family]);
     g.name = nm;
     p->groups.push_back(g);
     if (g.family == KF_ALIGN || g.family == KF_GAP) {          // traceback pass over the same slice
@@ -509,12 +517,12 @@ extern "C" int pgpu_dp_plan_launch(pgpu_ctx* ctx, pgpu_dp_plan* p) {
     auto weight = [&](size_t gi) -> long {
       const Group& g = p->groups[gi];
       switch (g.family) {
-        case KF_BORDERS: case KF_AFFIX: return g.R >= 2 ? 10000 + g.R : 150;
-        case KF_ALIGN: return 5000 + g.R;
-        case KF_GAP: return 4000 + g.R;
+        case KF_BORDERS: case KF_AFFIX: return g.R == 1 ? 150 : 10000 + (long)g.max_rows;
+        case KF_ALIGN: return 5000;
+        case KF_GAP: return 4000;
         case KF_LCF: return 3000;
-        case KF_KBAND: return 2000 + g.R;
-        default: return 1000 + g.R;
+        case KF_KBAND: return 2000;
+        default: return 1000;
       }
     };
     std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return weight(a) > weight(b); });
@@ -532,8 +540,8 @@ extern "C" int pgpu_dp_plan_launch(pgpu_ctx* ctx, pgpu_dp_plan* p) {
         else launch_gap_traceback(jobs, n, p->d_results, p->d_ws, p->d_strs, st);
       } else switch (g.family) {
         case KF_ALIGN: case KF_ED: case KF_BORDERS: case KF_AFFIX: case KF_KBAND:
-          launch_lev(g.family, g.R, jobs, n, p->d_results, p->d_ws, st); break;
-        case KF_GAP: launch_gap(g.R, jobs, n, p->d_results, p->d_ws, st); break;
+          launch_lev(g.family, g.R, g.max_rows, jobs, n, p->d_results, p->d_ws, st); break;
+        case KF_GAP: launch_gap(jobs, n, p->d_results, p->d_ws, st); break;
         case KF_LCF:
           launch_lcf(jobs, n, g.max_chunks, g.max_l2, p->d_keys + key_of[gi], st);
           launch_lcf_finish(jobs, n, p->d_results, p->d_keys + key_of[gi], st);

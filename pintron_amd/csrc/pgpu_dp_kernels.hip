@@ -269,15 +269,8 @@ enum { MODE_ED = 0, MODE_ALIGN = 1, MODE_BORDERS = 2, MODE_AFFIX = 3, MODE_KBAND
 // one block of (columns + 64) * 64 * 16 bytes per strip.
 
 template <int R, int MODE, bool STRIPS = false>
-__global__ __launch_bounds__(MODE == MODE_BORDERS ? 64 : 256)
-void lev_wave_kernel(const DevJob* __restrict__ jobs, int njobs, DevResult* __restrict__ results,
-                     uint8_t* __restrict__ ws) {
-  constexpr int WAVES = MODE == MODE_BORDERS ? 1 : 4;
-  const uint32_t lane = threadIdx.x & 63u;
-  const int w = blockIdx.x * WAVES + (threadIdx.x >> 6);
-  if (w >= njobs) return;
-  const DevJob job = jobs[w];
-  DevResult* res = &results[job.out_idx];
+__device__ __forceinline__ void lev_wave_body(const DevJob& job, DevResult* res, uint8_t* __restrict__ ws,
+                                              const uint32_t lane) {
   uint32_t cur[R], minv[R], minpos[R];
   AffixBest best{0, 0, 0, 0, 0};
 
@@ -469,6 +462,44 @@ void lev_wave_kernel(const DevJob* __restrict__ jobs, int njobs, DevResult* __re
   }
 }
 
+// one row class per launch (BORDERS with up to 64 rows, AFFIX with up to 64 rows or in strips)
+template <int R, int MODE, bool STRIPS = false>
+__global__ __launch_bounds__(MODE == MODE_BORDERS ? 64 : 256)
+void lev_wave_kernel(const DevJob* __restrict__ jobs, int njobs, DevResult* __restrict__ results,
+                     uint8_t* __restrict__ ws) {
+  constexpr int WAVES = MODE == MODE_BORDERS ? 1 : 4;
+  const uint32_t lane = threadIdx.x & 63u;
+  const int w = blockIdx.x * WAVES + (threadIdx.x >> 6);
+  if (w >= njobs) return;
+  const DevJob job = jobs[w];
+  lev_wave_body<R, MODE, STRIPS>(job, &results[job.out_idx], ws, lane);
+}
+
+// ALL row classes of a family in ONE launch: the jobs of a merged batch are few per class, and
+// kernels of one stream or hardware queue run one after the other, so a launch per class costs
+// the sum of the classes' longest jobs; in one launch they overlap.  Every wave picks the body of
+// its job's class (jobs are sorted by class, so the waves of a workgroup mostly agree).
+template <int MODE>
+__global__ __launch_bounds__(256)
+void lev_any_kernel(const DevJob* __restrict__ jobs, int njobs, DevResult* __restrict__ results,
+                    uint8_t* __restrict__ ws) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= njobs) return;
+  const DevJob job = jobs[w];
+  DevResult* res = &results[job.out_idx];
+  switch (job.r_class) {
+    case 1:  lev_wave_body<1, MODE>(job, res, ws, lane); break;
+    case 2:  lev_wave_body<2, MODE>(job, res, ws, lane); break;
+    case 4:  lev_wave_body<4, MODE>(job, res, ws, lane); break;
+    case 8:  lev_wave_body<8, MODE>(job, res, ws, lane); break;
+    case 16: lev_wave_body<16, MODE>(job, res, ws, lane); break;
+    case 32: lev_wave_body<32, MODE>(job, res, ws, lane); break;
+    case 64: lev_wave_body<64, MODE>(job, res, ws, lane); break;
+    default: lev_wave_body<64, MODE, true>(job, res, ws, lane); break;      // ROW_CLASS_STRIPS
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Cooperative sweeps: one job over the W waves of a workgroup
 // ---------------------------------------------------------------------------------------------
@@ -562,11 +593,8 @@ __device__ __forceinline__ void lev_sweep_coop(const Operand rows, const uint32_
 // general_refine_borders (src/refine.c:105-192) for patterns longer than 64: the prefix sweep on
 // waves 0-3 and the reversed-string sweep on waves 4-7 of one 512-thread workgroup.
 template <int R>
-__global__ __launch_bounds__(512)
-void borders_coop_kernel(const DevJob* __restrict__ jobs, int njobs, DevResult* __restrict__ results) {
+__device__ __forceinline__ void borders_coop_body(const DevJob& job, DevResult* res) {
   extern __shared__ uint32_t lds[];      // hand-off [2][COOP_W-1][2][64], then pre, pre_pos, suf, suf_pos
-  const DevJob job = jobs[blockIdx.x];
-  DevResult* res = &results[job.out_idx];
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // scalar: branches on it are uniform
   const uint32_t sweep = wave / COOP_W, w = wave % COOP_W;
@@ -613,14 +641,23 @@ void borders_coop_kernel(const DevJob* __restrict__ jobs, int njobs, DevResult* 
   }
 }
 
-// find_longest_affix (src/factorization-refinement.c:1136-1173) for more than 64 rows
-template <int R>
-__global__ __launch_bounds__(256)
-void affix_coop_kernel(const DevJob* __restrict__ jobs, int njobs, DevResult* __restrict__ results) {
-  __shared__ uint32_t hand[(COOP_W - 1) * 128];
-  __shared__ uint32_t wbest[COOP_W][5];
+// every row class above 64 rows in one launch (one job per workgroup; see lev_any_kernel)
+__global__ __launch_bounds__(512)
+void borders_coop_any_kernel(const DevJob* __restrict__ jobs, int njobs, DevResult* __restrict__ results) {
   const DevJob job = jobs[blockIdx.x];
   DevResult* res = &results[job.out_idx];
+  switch (job.r_class) {                 // rows per lane of the 256-lane sweep = class / COOP_W
+    case 2: case 4: borders_coop_body<1>(job, res); break;
+    case 8:  borders_coop_body<2>(job, res); break;
+    case 16: borders_coop_body<4>(job, res); break;
+    case 32: borders_coop_body<8>(job, res); break;
+    default: borders_coop_body<16>(job, res); break;
+  }
+}
+
+// find_longest_affix (src/factorization-refinement.c:1136-1173) for more than 64 rows
+template <int R>
+__device__ __forceinline__ void affix_coop_body(const DevJob& job, DevResult* res, uint32_t* hand, uint32_t (*wbest)[5]) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   uint32_t cur[R], minv[R], minpos[R];
@@ -645,6 +682,21 @@ void affix_coop_kernel(const DevJob* __restrict__ jobs, int njobs, DevResult* __
     }
     res->status = 0; res->v[0] = (int32_t)best.valid;
     res->v[1] = (int32_t)best.e; res->v[2] = (int32_t)best.g;
+  }
+}
+
+__global__ __launch_bounds__(256)
+void affix_coop_any_kernel(const DevJob* __restrict__ jobs, int njobs, DevResult* __restrict__ results) {
+  __shared__ uint32_t hand[(COOP_W - 1) * 128];
+  __shared__ uint32_t wbest[COOP_W][5];
+  const DevJob job = jobs[blockIdx.x];
+  DevResult* res = &results[job.out_idx];
+  switch (job.r_class) {
+    case 2: case 4: affix_coop_body<1>(job, res, hand, wbest); break;
+    case 8:  affix_coop_body<2>(job, res, hand, wbest); break;
+    case 16: affix_coop_body<4>(job, res, hand, wbest); break;
+    case 32: affix_coop_body<8>(job, res, hand, wbest); break;
+    default: affix_coop_body<16>(job, res, hand, wbest); break;
   }
 }
 
@@ -766,14 +818,8 @@ void align_traceback_wave_kernel(const DevJob* __restrict__ jobs, int njobs,
 // 3-state gap alignment: ComputeGapAlignMatrix with only_one_align (src/refine-intron.c:623-824)
 // ---------------------------------------------------------------------------------------------
 template <int R>
-__global__ __launch_bounds__(256)
-void gap_wave_kernel(const DevJob* __restrict__ jobs, int njobs, DevResult* __restrict__ results,
-                     uint8_t* __restrict__ ws) {
-  const uint32_t lane = threadIdx.x & 63u;
-  const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (w >= njobs) return;
-  const DevJob job = jobs[w];
-  DevResult* res = &results[job.out_idx];
+__device__ __forceinline__ void gap_wave_body(const DevJob& job, DevResult* res, uint8_t* __restrict__ ws,
+                                              const uint32_t lane) {
   const uint32_t n = job.la, m = job.lb;
   int32_t cL[R], cG[R], cR[R];
   uint32_t rc[R];
@@ -857,6 +903,25 @@ void gap_wave_kernel(const DevJob* __restrict__ jobs, int njobs, DevResult* __re
       res->status = 0;
       res->pad = plane;
     }
+  }
+}
+
+// all row classes of a batch's gap alignments in one launch (see lev_any_kernel)
+__global__ __launch_bounds__(256)
+void gap_any_kernel(const DevJob* __restrict__ jobs, int njobs, DevResult* __restrict__ results,
+                    uint8_t* __restrict__ ws) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= njobs) return;
+  const DevJob job = jobs[w];
+  DevResult* res = &results[job.out_idx];
+  switch (job.r_class) {
+    case 1:  gap_wave_body<1>(job, res, ws, lane); break;
+    case 2:  gap_wave_body<2>(job, res, ws, lane); break;
+    case 4:  gap_wave_body<4>(job, res, ws, lane); break;
+    case 8:  gap_wave_body<8>(job, res, ws, lane); break;
+    case 16: gap_wave_body<16>(job, res, ws, lane); break;
+    default: gap_wave_body<32>(job, res, ws, lane); break;
   }
 }
 
@@ -1039,54 +1104,33 @@ __global__ void lcf_finish_kernel(const DevJob* __restrict__ jobs, int njobs,
   res->v[2] = (int32_t)(0xFFFFu - (uint32_t)(key & 0xFFFFu));
 }
 
-template <int MODE, int R>
-void launch_lev_r(const DevJob* jobs, int njobs, DevResult* res, uint8_t* ws, hipStream_t st) {
-  // more than 64 rows: one job per workgroup, rows spread over COOP_W*64 lanes
-  if constexpr ((MODE == MODE_BORDERS || MODE == MODE_AFFIX) && R >= 2) {
-    constexpr int RB = R / COOP_W > 0 ? R / COOP_W : 1;
-    if constexpr (MODE == MODE_BORDERS) {
-      const size_t lds = (2 * (COOP_W - 1) * 128 + 4 * (64 * R + 1)) * sizeof(uint32_t);
-      hipLaunchKernelGGL((borders_coop_kernel<RB>), dim3(njobs), dim3(512), lds, st, jobs, njobs, res);
-    } else {
-      hipLaunchKernelGGL((affix_coop_kernel<RB>), dim3(njobs), dim3(256), 0, st, jobs, njobs, res);
-    }
-  } else if constexpr (MODE == MODE_BORDERS) {
-    const size_t lds = 4 * (64 * R + 1) * sizeof(uint32_t);
-    hipLaunchKernelGGL((lev_wave_kernel<R, MODE>), dim3(njobs), dim3(64), lds, st, jobs, njobs, res, ws);
-  } else {
-    hipLaunchKernelGGL((lev_wave_kernel<R, MODE>), dim3((njobs + 3) / 4), dim3(256), 0, st, jobs, njobs, res, ws);
-  }
-}
-
-template <int MODE>
-void launch_lev_mode(int R, const DevJob* jobs, int njobs, DevResult* res, uint8_t* ws, hipStream_t st) {
-  if (R == (int)ROW_CLASS_STRIPS) {                 // > 4096 rows: one wave per job, strips of 4096 rows
-    if constexpr (MODE != MODE_BORDERS)
-      hipLaunchKernelGGL((lev_wave_kernel<64, MODE, true>), dim3((njobs + 3) / 4), dim3(256), 0, st, jobs, njobs, res, ws);
-    return;
-  }
-  switch (R) {
-    case 1:  launch_lev_r<MODE, 1>(jobs, njobs, res, ws, st); break;
-    case 2:  launch_lev_r<MODE, 2>(jobs, njobs, res, ws, st); break;
-    case 4:  launch_lev_r<MODE, 4>(jobs, njobs, res, ws, st); break;
-    case 8:  launch_lev_r<MODE, 8>(jobs, njobs, res, ws, st); break;
-    case 16: launch_lev_r<MODE, 16>(jobs, njobs, res, ws, st); break;
-    case 32: launch_lev_r<MODE, 32>(jobs, njobs, res, ws, st); break;
-    default: launch_lev_r<MODE, 64>(jobs, njobs, res, ws, st); break;
-  }
-}
-
 }  // namespace
 
-void launch_lev(int family, int R, const DevJob* jobs, int njobs, DevResult* res, uint8_t* ws,
+// R = 0: every row class of the family in one launch (ED, ALIGN, KBAND; BORDERS / AFFIX above 64
+// rows, `max_rows` sizes the dynamic LDS); R = 1: the single-wave BORDERS / AFFIX kernels;
+// R = ROW_CLASS_STRIPS: AFFIX beyond 4096 rows.
+void launch_lev(int family, int R, uint32_t max_rows, const DevJob* jobs, int njobs, DevResult* res, uint8_t* ws,
                 hipStream_t st) {
   if (njobs <= 0) return;
+  const dim3 g4((njobs + 3) / 4), b256(256);
   switch (family) {
-    case KF_ED:      launch_lev_mode<MODE_ED>(R, jobs, njobs, res, ws, st); break;
-    case KF_ALIGN:   launch_lev_mode<MODE_ALIGN>(R, jobs, njobs, res, ws, st); break;
-    case KF_BORDERS: launch_lev_mode<MODE_BORDERS>(R, jobs, njobs, res, ws, st); break;
-    case KF_AFFIX:   launch_lev_mode<MODE_AFFIX>(R, jobs, njobs, res, ws, st); break;
-    case KF_KBAND:   launch_lev_mode<MODE_KBAND>(R, jobs, njobs, res, ws, st); break;
+    case KF_ED:    hipLaunchKernelGGL((lev_any_kernel<MODE_ED>), g4, b256, 0, st, jobs, njobs, res, ws); break;
+    case KF_ALIGN: hipLaunchKernelGGL((lev_any_kernel<MODE_ALIGN>), g4, b256, 0, st, jobs, njobs, res, ws); break;
+    case KF_KBAND: hipLaunchKernelGGL((lev_any_kernel<MODE_KBAND>), g4, b256, 0, st, jobs, njobs, res, ws); break;
+    case KF_BORDERS:
+      if (R == 1) {
+        const size_t lds = 4 * (64 + 1) * sizeof(uint32_t);
+        hipLaunchKernelGGL((lev_wave_kernel<1, MODE_BORDERS>), dim3(njobs), dim3(64), lds, st, jobs, njobs, res, ws);
+      } else {
+        const size_t lds = (2 * (COOP_W - 1) * 128 + 4 * ((size_t)max_rows + 1)) * sizeof(uint32_t);
+        hipLaunchKernelGGL(borders_coop_any_kernel, dim3(njobs), dim3(512), lds, st, jobs, njobs, res);
+      }
+      break;
+    case KF_AFFIX:
+      if (R == 1) hipLaunchKernelGGL((lev_wave_kernel<1, MODE_AFFIX>), g4, b256, 0, st, jobs, njobs, res, ws);
+      else if (R == (int)ROW_CLASS_STRIPS) hipLaunchKernelGGL((lev_wave_kernel<64, MODE_AFFIX, true>), g4, b256, 0, st, jobs, njobs, res, ws);
+      else hipLaunchKernelGGL(affix_coop_any_kernel, dim3(njobs), dim3(256), 0, st, jobs, njobs, res);
+      break;
     default: break;
   }
 }
@@ -1097,17 +1141,9 @@ void launch_align_traceback(const DevJob* jobs, int njobs, DevResult* res, const
   hipLaunchKernelGGL(align_traceback_wave_kernel, dim3((njobs + 3) / 4), dim3(256), 0, st, jobs, njobs, res, ws, strs);
 }
 
-void launch_gap(int R, const DevJob* jobs, int njobs, DevResult* res, uint8_t* ws, hipStream_t st) {
+void launch_gap(const DevJob* jobs, int njobs, DevResult* res, uint8_t* ws, hipStream_t st) {
   if (njobs <= 0) return;
-  const dim3 grid((njobs + 3) / 4), block(256);
-  switch (R) {
-    case 1:  hipLaunchKernelGGL(gap_wave_kernel<1>, grid, block, 0, st, jobs, njobs, res, ws); break;
-    case 2:  hipLaunchKernelGGL(gap_wave_kernel<2>, grid, block, 0, st, jobs, njobs, res, ws); break;
-    case 4:  hipLaunchKernelGGL(gap_wave_kernel<4>, grid, block, 0, st, jobs, njobs, res, ws); break;
-    case 8:  hipLaunchKernelGGL(gap_wave_kernel<8>, grid, block, 0, st, jobs, njobs, res, ws); break;
-    case 16: hipLaunchKernelGGL(gap_wave_kernel<16>, grid, block, 0, st, jobs, njobs, res, ws); break;
-    default: hipLaunchKernelGGL(gap_wave_kernel<32>, grid, block, 0, st, jobs, njobs, res, ws); break;
-  }
+  hipLaunchKernelGGL(gap_any_kernel, dim3((njobs + 3) / 4), dim3(256), 0, st, jobs, njobs, res, ws);
 }
 
 void launch_gap_traceback(const DevJob* jobs, int njobs, DevResult* res, const uint8_t* ws,

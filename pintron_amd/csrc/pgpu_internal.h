@@ -27,11 +27,11 @@ enum KernelFamily {
 };
 
 // launchers (pgpu_dp_kernels.hip)
-void launch_lev(int mode_family, int R, const DevJob* jobs, int njobs, DevResult* res,
+void launch_lev(int mode_family, int R, uint32_t max_rows, const DevJob* jobs, int njobs, DevResult* res,
                 uint8_t* ws, hipStream_t st);
 void launch_align_traceback(const DevJob* jobs, int njobs, DevResult* res, const uint8_t* ws,
                             uint8_t* strs, hipStream_t st);
-void launch_gap(int R, const DevJob* jobs, int njobs, DevResult* res, uint8_t* ws, hipStream_t st);
+void launch_gap(const DevJob* jobs, int njobs, DevResult* res, uint8_t* ws, hipStream_t st);
 void launch_gap_traceback(const DevJob* jobs, int njobs, DevResult* res, const uint8_t* ws,
                           uint8_t* strs, hipStream_t st);
 void launch_lcf(const DevJob* jobs, int njobs, uint32_t max_chunks, uint32_t max_l2,
