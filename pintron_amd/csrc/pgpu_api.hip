@@ -386,8 +386,8 @@ extern "C" int pgpu_dp_plan_create_parts(pgpu_ctx* ctx, const pgpu_index* idx, c
       // ALIGN, 3 B/cell for GAP; 8 B per row when row minima are produced
       g.algo_bytes += la + lb;
       g.max_rows = std::max(g.max_rows, (uint32_t)la);
-      if (k.family == KF_ALIGN) g.algo_bytes += la * lb;
-      if (k.family == KF_GAP) g.algo_bytes += 3 * la * lb;
+      if (k.family == KF_ALIGN) g.algo_bytes += la * lb + 3 * (la + lb);     // + directions read back, two strings
+      if (k.family == KF_GAP) g.algo_bytes += 3 * la * lb + 3 * (la + lb);
       if (k.family == KF_BORDERS) g.algo_bytes += 2 * 8 * la;
       if (k.family == KF_LCF) {
         const uint32_t ch = (uint32_t)((la + lb + 254) / 256);   // ceil((la+lb-1)/256) diagonals
@@ -406,14 +406,6 @@ extern "C" int pgpu_dp_plan_create_parts(pgpu_ctx* ctx, const pgpu_index* idx, c
     else snprintf(nm, sizeof nm, "%s", fam[g.family]);
     g.name = nm;
     p->groups.push_back(g);
-    if (g.family == KF_ALIGN || g.family == KF_GAP) {          // traceback pass over the same slice
-      Group t = g;
-      t.traceback = true; t.cells = 0; t.algo_bytes = 0;
-      for (size_t q = g.first; q < g.first + g.count; ++q)
-        t.algo_bytes += 3ull * (v[q].j.la + v[q].j.lb);      // directions read back + two strings
-      t.name = g.family == KF_ALIGN ? "align_traceback" : "gap_traceback";
-      p->groups.push_back(t);
-    }
     i = j;
   }
   for (auto& g : p->groups) {
@@ -535,13 +527,10 @@ extern "C" int pgpu_dp_plan_launch(pgpu_ctx* ctx, pgpu_dp_plan* p) {
       const int n = (int)g.count;
       hipStream_t st = ctx->fanout ? ctx->aux[slot % ctx->n_aux] : ctx->stream;
       if (g.ev0) HIP_TRY(ctx, hipEventRecord(g.ev0, st));
-      if (g.traceback) {
-        if (g.family == KF_ALIGN) launch_align_traceback(jobs, n, p->d_results, p->d_ws, p->d_strs, st);
-        else launch_gap_traceback(jobs, n, p->d_results, p->d_ws, p->d_strs, st);
-      } else switch (g.family) {
+      switch (g.family) {
         case KF_ALIGN: case KF_ED: case KF_BORDERS: case KF_AFFIX: case KF_KBAND:
-          launch_lev(g.family, g.R, g.max_rows, jobs, n, p->d_results, p->d_ws, st); break;
-        case KF_GAP: launch_gap(jobs, n, p->d_results, p->d_ws, st); break;
+          launch_lev(g.family, g.R, g.max_rows, jobs, n, p->d_results, p->d_ws, p->d_strs, st); break;
+        case KF_GAP: launch_gap(jobs, n, p->d_results, p->d_ws, p->d_strs, st); break;
         case KF_LCF:
           launch_lcf(jobs, n, g.max_chunks, g.max_l2, p->d_keys + key_of[gi], st);
           launch_lcf_finish(jobs, n, p->d_results, p->d_keys + key_of[gi], st);

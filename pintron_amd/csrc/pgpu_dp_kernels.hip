@@ -479,15 +479,49 @@ void lev_wave_kernel(const DevJob* __restrict__ jobs, int njobs, DevResult* __re
 // kernels of one stream or hardware queue run one after the other, so a launch per class costs
 // the sum of the classes' longest jobs; in one launch they overlap.  Every wave picks the body of
 // its job's class (jobs are sorted by class, so the waves of a workgroup mostly agree).
+constexpr int TB_WIN_BYTES = 8192;    // traceback: direction window per wave
+constexpr int TB_PATH = 1024;         // traceback: path steps buffered before the lanes write them out
+__device__ __forceinline__ void align_traceback_wave(const DevJob& job, DevResult* res, const uint8_t* __restrict__ ws,
+                                                     uint8_t* __restrict__ strs, const uint32_t lane,
+                                                     uint8_t* win, uint8_t* path);
+__device__ __forceinline__ void gap_traceback_wave(const DevJob& job, DevResult* res, const uint8_t* __restrict__ ws,
+                                                   uint8_t* __restrict__ strs, const uint32_t lane,
+                                                   uint8_t* win, uint8_t* path);
+
+// The wave that filled a traceback workspace walks it right away (ALIGN, GAP): what it stored has
+// to be visible to its other lanes, and lines of an earlier batch may sit in this CU's L1.
+__device__ __forceinline__ void own_stores_visible() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256)
 void lev_any_kernel(const DevJob* __restrict__ jobs, int njobs, DevResult* __restrict__ results,
-                    uint8_t* __restrict__ ws) {
+                    uint8_t* __restrict__ ws, uint8_t* __restrict__ strs) {
   const uint32_t lane = threadIdx.x & 63u;
   const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (w >= njobs) return;
   const DevJob job = jobs[w];
   DevResult* res = &results[job.out_idx];
+  if constexpr (MODE == MODE_ALIGN) {      // matrix, then the traceback by the same wave
+    __shared__ __attribute__((aligned(16))) uint8_t s_win[4][TB_WIN_BYTES];
+    __shared__ uint8_t s_path[4][TB_PATH];
+    switch (job.r_class) {
+      case 1:  lev_wave_body<1, MODE>(job, res, ws, lane); break;
+      case 2:  lev_wave_body<2, MODE>(job, res, ws, lane); break;
+      case 4:  lev_wave_body<4, MODE>(job, res, ws, lane); break;
+      case 8:  lev_wave_body<8, MODE>(job, res, ws, lane); break;
+      case 16: lev_wave_body<16, MODE>(job, res, ws, lane); break;
+      case 32: lev_wave_body<32, MODE>(job, res, ws, lane); break;
+      case 64: lev_wave_body<64, MODE>(job, res, ws, lane); break;
+      default: lev_wave_body<64, MODE, true>(job, res, ws, lane); break;      // ROW_CLASS_STRIPS
+    }
+    own_stores_visible();
+    align_traceback_wave(job, res, ws, strs, lane, s_win[threadIdx.x >> 6], s_path[threadIdx.x >> 6]);
+    return;
+  }
   switch (job.r_class) {
     case 1:  lev_wave_body<1, MODE>(job, res, ws, lane); break;
     case 2:  lev_wave_body<2, MODE>(job, res, ws, lane); break;
@@ -708,8 +742,6 @@ void affix_coop_any_kernel(const DevJob* __restrict__ jobs, int njobs, DevResult
 // step is one LDS read plus a few scalar instructions.  The walk only records the 2-bit
 // direction per step; the gapped strings are then written by all 64 lanes at once: the character
 // a step consumes is found from a prefix count (ballot + popcount) of the steps before it.
-constexpr int TB_WIN_BYTES = 8192;    // direction window per wave
-constexpr int TB_PATH = 1024;         // path steps buffered before the lanes write them out
 
 __device__ __forceinline__ void tb_flush(const uint8_t* path, uint32_t np, const uint8_t* a, const uint8_t* b,
                                          uint32_t i0, uint32_t j0, uint32_t pos0, uint8_t* ea, uint8_t* ga,
@@ -732,17 +764,9 @@ __device__ __forceinline__ void tb_flush(const uint8_t* path, uint32_t np, const
   }
 }
 
-__global__ __launch_bounds__(256)
-void align_traceback_wave_kernel(const DevJob* __restrict__ jobs, int njobs,
-                                 DevResult* __restrict__ results, const uint8_t* __restrict__ ws,
-                                 uint8_t* __restrict__ strs) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_win[4][TB_WIN_BYTES];
-  __shared__ uint8_t s_path[4][TB_PATH];
-  const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-  const int t = blockIdx.x * 4 + (int)wv;
-  if (t >= njobs) return;                                  // the whole wave leaves
-  const DevJob job = jobs[t];
-  DevResult* res = &results[job.out_idx];
+__device__ __forceinline__ void align_traceback_wave(const DevJob& job, DevResult* res, const uint8_t* __restrict__ ws,
+                                                     uint8_t* __restrict__ strs, const uint32_t lane,
+                                                     uint8_t* win, uint8_t* path) {
   const uint32_t n = job.la, m = job.lb, cap = n + m + 1;
   uint8_t* ea = strs + job.str_off;
   uint8_t* ga = ea + cap;
@@ -756,8 +780,6 @@ void align_traceback_wave_kernel(const DevJob* __restrict__ jobs, int njobs,
     }
     return;
   }
-  uint8_t* win = s_win[wv];
-  uint8_t* path = s_path[wv];
   const bool strips = job.r_class == ROW_CLASS_STRIPS;     // more than 4096 rows: strips of 64*64 rows
   const uint32_t R = strips ? 64u : job.r_class, EB = R <= 4 ? 1u : R / 4;
   const uint32_t lgR = 31u - (uint32_t)__builtin_clz(R);   // R is a power of two
@@ -909,7 +931,9 @@ __device__ __forceinline__ void gap_wave_body(const DevJob& job, DevResult* res,
 // all row classes of a batch's gap alignments in one launch (see lev_any_kernel)
 __global__ __launch_bounds__(256)
 void gap_any_kernel(const DevJob* __restrict__ jobs, int njobs, DevResult* __restrict__ results,
-                    uint8_t* __restrict__ ws) {
+                    uint8_t* __restrict__ ws, uint8_t* __restrict__ strs) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_win[4][TB_WIN_BYTES];
+  __shared__ uint8_t s_path[4][TB_PATH];
   const uint32_t lane = threadIdx.x & 63u;
   const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (w >= njobs) return;
@@ -923,29 +947,21 @@ void gap_any_kernel(const DevJob* __restrict__ jobs, int njobs, DevResult* __res
     case 16: gap_wave_body<16>(job, res, ws, lane); break;
     default: gap_wave_body<32>(job, res, ws, lane); break;
   }
+  own_stores_visible();                  // the planes and the start plane (res->pad)
+  gap_traceback_wave(job, res, ws, strs, lane, s_win[threadIdx.x >> 6], s_path[threadIdx.x >> 6]);
 }
 
 // TracebackGapAlignment (src/refine-intron.c:828-890), one wave per job: same scheme as
 // align_traceback_wave_kernel (direction window in LDS, scalar walk, parallel write-out); the walk
 // additionally carries the plane (R exon -> G intron -> L exon) and notes where it jumps.
-__global__ __launch_bounds__(256)
-void gap_traceback_wave_kernel(const DevJob* __restrict__ jobs, int njobs,
-                               DevResult* __restrict__ results, const uint8_t* __restrict__ ws,
-                               uint8_t* __restrict__ strs) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_win[4][TB_WIN_BYTES];
-  __shared__ uint8_t s_path[4][TB_PATH];
-  const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-  const int t = blockIdx.x * 4 + (int)wv;
-  if (t >= njobs) return;
-  const DevJob job = jobs[t];
-  DevResult* res = &results[job.out_idx];
+__device__ __forceinline__ void gap_traceback_wave(const DevJob& job, DevResult* res, const uint8_t* __restrict__ ws,
+                                                   uint8_t* __restrict__ strs, const uint32_t lane,
+                                                   uint8_t* win, uint8_t* path) {
   const uint32_t n = job.la, m = job.lb, cap = n + m + 1, R = job.r_class;
   const uint32_t lgR = 31u - (uint32_t)__builtin_clz(R);
   const uint32_t WS = TB_WIN_BYTES / (64u * R);            // 1 B per cell: an entry is R bytes
   uint8_t* ea = strs + job.str_off;
   uint8_t* ga = ea + cap;
-  uint8_t* win = s_win[wv];
-  uint8_t* path = s_path[wv];
   const uint8_t* dirs = ws + job.ws_off;
   int plane = __builtin_amdgcn_readfirstlane(res->pad);
   int32_t factor_cut = 0, intron_start = 0, intron_end = 0;
@@ -1110,13 +1126,13 @@ __global__ void lcf_finish_kernel(const DevJob* __restrict__ jobs, int njobs,
 // rows, `max_rows` sizes the dynamic LDS); R = 1: the single-wave BORDERS / AFFIX kernels;
 // R = ROW_CLASS_STRIPS: AFFIX beyond 4096 rows.
 void launch_lev(int family, int R, uint32_t max_rows, const DevJob* jobs, int njobs, DevResult* res, uint8_t* ws,
-                hipStream_t st) {
+                uint8_t* strs, hipStream_t st) {
   if (njobs <= 0) return;
   const dim3 g4((njobs + 3) / 4), b256(256);
   switch (family) {
-    case KF_ED:    hipLaunchKernelGGL((lev_any_kernel<MODE_ED>), g4, b256, 0, st, jobs, njobs, res, ws); break;
-    case KF_ALIGN: hipLaunchKernelGGL((lev_any_kernel<MODE_ALIGN>), g4, b256, 0, st, jobs, njobs, res, ws); break;
-    case KF_KBAND: hipLaunchKernelGGL((lev_any_kernel<MODE_KBAND>), g4, b256, 0, st, jobs, njobs, res, ws); break;
+    case KF_ED:    hipLaunchKernelGGL((lev_any_kernel<MODE_ED>), g4, b256, 0, st, jobs, njobs, res, ws, strs); break;
+    case KF_ALIGN: hipLaunchKernelGGL((lev_any_kernel<MODE_ALIGN>), g4, b256, 0, st, jobs, njobs, res, ws, strs); break;
+    case KF_KBAND: hipLaunchKernelGGL((lev_any_kernel<MODE_KBAND>), g4, b256, 0, st, jobs, njobs, res, ws, strs); break;
     case KF_BORDERS:
       if (R == 1) {
         const size_t lds = 4 * (64 + 1) * sizeof(uint32_t);
@@ -1135,21 +1151,9 @@ void launch_lev(int family, int R, uint32_t max_rows, const DevJob* jobs, int nj
   }
 }
 
-void launch_align_traceback(const DevJob* jobs, int njobs, DevResult* res, const uint8_t* ws,
-                            uint8_t* strs, hipStream_t st) {
+void launch_gap(const DevJob* jobs, int njobs, DevResult* res, uint8_t* ws, uint8_t* strs, hipStream_t st) {
   if (njobs <= 0) return;
-  hipLaunchKernelGGL(align_traceback_wave_kernel, dim3((njobs + 3) / 4), dim3(256), 0, st, jobs, njobs, res, ws, strs);
-}
-
-void launch_gap(const DevJob* jobs, int njobs, DevResult* res, uint8_t* ws, hipStream_t st) {
-  if (njobs <= 0) return;
-  hipLaunchKernelGGL(gap_any_kernel, dim3((njobs + 3) / 4), dim3(256), 0, st, jobs, njobs, res, ws);
-}
-
-void launch_gap_traceback(const DevJob* jobs, int njobs, DevResult* res, const uint8_t* ws,
-                          uint8_t* strs, hipStream_t st) {
-  if (njobs <= 0) return;
-  hipLaunchKernelGGL(gap_traceback_wave_kernel, dim3((njobs + 3) / 4), dim3(256), 0, st, jobs, njobs, res, ws, strs);
+  hipLaunchKernelGGL(gap_any_kernel, dim3((njobs + 3) / 4), dim3(256), 0, st, jobs, njobs, res, ws, strs);
 }
 
 void launch_lcf(const DevJob* jobs, int njobs, uint32_t max_chunks, uint32_t max_l2,
