@@ -23,6 +23,7 @@
 #define _GNU_SOURCE
 #include <malloc.h>
 #include <pthread.h>
+#include <sched.h>
 #include <time.h>
 #include <stdlib.h>
 #include <string.h>
@@ -618,6 +619,37 @@ static size_t env_size(const char* name, size_t dflt) {
   return (v && atol(v) > 0) ? (size_t)atol(v) : dflt;
 }
 
+/* the host cores this process may count on: the online (and allowed) CPUs, cut down to the
+ * container's CPU quota when there is one, shared evenly between the ranks torchrun started on
+ * this node, and at most the 16 cores one GPU of an 8-GPU node comes with */
+static size_t host_core_share(void) {
+  long n = sysconf(_SC_NPROCESSORS_ONLN);
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof set, &set) == 0 && CPU_COUNT(&set) > 0 && CPU_COUNT(&set) < n) n = CPU_COUNT(&set);
+  long long quota = -1, period = 0;
+  FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r");                       /* cgroup v2: "<quota|max> <period>" */
+  if (f) {
+    char q[32];
+    if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
+    fclose(f);
+  } else if ((f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) != NULL) {     /* cgroup v1 */
+    if (fscanf(f, "%lld", &quota) != 1) quota = -1;
+    fclose(f);
+    if ((f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) != NULL) {
+      if (fscanf(f, "%lld", &period) != 1) period = 0;
+      fclose(f);
+    }
+  }
+  if (quota > 0 && period > 0) {
+    const long q = (long)((quota + period - 1) / period);
+    if (q < n) n = q;
+  }
+  const char* lws = getenv("LOCAL_WORLD_SIZE");
+  if (lws && atol(lws) > 1) n /= atol(lws);
+  if (n > 16) n = 16;
+  return n > 0 ? (size_t)n : 1;
+}
+
 /* ---- sessions: inputs + index + patterns resident; a step = the whole per-EST pipeline ------------ */
 struct ef_session {
   ef_inputs in;
@@ -712,12 +744,8 @@ ef_session* ef_session_open(int argc, char** argv) {
     if (pgpu_init(ef_gpu_device_from_env(), &sh->svc.threads[k].ctx) != PGPU_OK) { free(s); return NULL; }
     if (env_flag("PINTRON_KERNEL_TIMING")) pgpu_set_timing(sh->svc.threads[k].ctx, 1);
   }
-  const long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
-  /* default: the host share of one GPU on an 8-GPU node (16 cores; the GPU boxes expose far more,
-   * but their CPU quota is that share).  The workers hide the GPU latency with lanes, not with
-   * oversubscription. */
-  const size_t cores = ncpu > 16 ? 16 : (ncpu > 0 ? (size_t)ncpu : 1);
-  s->nthreads = env_size("PINTRON_THREADS", cores);
+  /* the workers hide the GPU latency with lanes, not with oversubscription */
+  s->nthreads = env_size("PINTRON_THREADS", host_core_share());
   if (s->nthreads > sh->n_units) s->nthreads = sh->n_units ? sh->n_units : 1;
   sh->max_fibers = env_size("PINTRON_FIBERS", 1024);
   sh->stack_size = env_size("PINTRON_FIBER_STACK_KB", 256) * 1024;

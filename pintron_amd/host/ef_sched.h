@@ -30,7 +30,8 @@ char* ef_session_output(ef_session* s, int which, size_t* len);   /* 0..5, see e
 size_t ef_session_n_ests(const ef_session* s);
 void ef_session_close(ef_session* s);
 
-/* environment: PINTRON_THREADS (workers; default min(online CPUs, 16)), PINTRON_LANES (4),
+/* environment: PINTRON_THREADS (workers; default: usable cores (affinity, cgroup quota,
+ * per local rank), at most 16), PINTRON_LANES (4),
  * PINTRON_FIBERS (fibres per worker over all lanes, 1024), PINTRON_FIBER_STACK_KB (256),
  * PINTRON_SERVICES (GPU service threads, 3), PINTRON_GPU_DEVICE (0), PINTRON_NO_PREFETCH,
  * PINTRON_KERNEL_TIMING, PINTRON_VERBOSE */
