@@ -707,12 +707,18 @@ static bool check_gap_errors(ef_list* fact, const char* est, const char* gen, co
     if (gapP > 0) {
       const size_t gapT = (size_t)(a->GEN_start - d->GEN_end - 1);
       const int max_errs = (int)gapP;
-      char* p = ef_real_substring(d->EST_end + 1, (int)gapP, est);
-      char* t = ef_real_substring(d->GEN_end + 1, (int)gapT, gen);
+      /* refine_borders(p, gapP, t, gapT, max_errs) on fresh NUL-terminated copies in the reference
+       * => tail 0: nothing beyond the two windows is looked at, so windows that lie inside the
+       * sequences are passed where they are (the genomic gap is a whole intron: no copy, and
+       * the GPU reads it from the resident genomic) */
+      char *pc = NULL, *tc = NULL;
+      const char* p = est + d->EST_end + 1;
+      const char* t = gen + d->GEN_end + 1;
+      if (d->EST_end + 1 < 0 || view_len(est, d->EST_end + 1, (int)gapP) != gapP) p = pc = ef_real_substring(d->EST_end + 1, (int)gapP, est);
+      if (d->GEN_end + 1 < 0 || (int)gapT < 0 || (size_t)(d->GEN_end + 1) + gapT > ef_genomic_len(gen)) t = tc = ef_real_substring(d->GEN_end + 1, (int)gapT, gen);
       ef_dp_res r;
-      /* refine_borders(p, gapP, t, gapT, max_errs): t is a fresh NUL-terminated copy => tail 0 */
       run_dp(be, EF_DP_BORDERS, p, gapP, t, gapT, 0, (uint32_t)gapP, (uint32_t)max_errs, 0, &r);
-      free(p); free(t);
+      free(pc); free(tc);
       ok = r.v[0] != 0;
       if (ok) {
         tot += (unsigned)r.v[4];
