@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <time.h>
 #include <new>
 #include <string>
 #include <vector>
@@ -37,9 +38,12 @@ struct pgpu_ctx {
   hipEvent_t ev_aux[NAUX] = {nullptr};
   bool fanout = true;        // spread groups over the auxiliary streams (PGPU_FANOUT=0 disables)
   int n_aux = NAUX;          // how many of them are used (PGPU_STREAMS=1..8)
-  // waiting: a blocking-sync event lets the calling thread SLEEP until the batch is done (the
-  // default HIP wait spins and would burn a host core that other EST fibres could use)
+  // waiting: the calling thread must not burn a host core that other EST fibres could use (the
+  // default HIP wait spins).  It naps and polls the event: measured on C3, naps of 50-200 us beat
+  // a blocking-sync event by 5-7 % whole-program (the interrupt path costs more host time than
+  // the naps cost latency).  PGPU_WAIT=<us> sets the nap, 0 = blocking-sync event, -1 = spin.
   hipEvent_t ev_done = nullptr;
+  long wait_poll_us = 100;
   // pinned staging for the device->host result copies (pageable copies block and spin inside HIP)
   void* pin[2] = {nullptr, nullptr};
   size_t pin_cap[2] = {0, 0};
@@ -50,6 +54,14 @@ struct pgpu_ctx {
 
 static int wait_stream(pgpu_ctx* ctx, hipStream_t st) {
   if (hipEventRecord(ctx->ev_done, st) != hipSuccess) return -1;
+  if (ctx->wait_poll_us != 0) {
+    for (;;) {
+      const hipError_t q = hipEventQuery(ctx->ev_done);
+      if (q == hipSuccess) return 0;
+      if (q != hipErrorNotReady) return -1;
+      if (ctx->wait_poll_us > 0) { struct timespec ts = {0, ctx->wait_poll_us * 1000L}; nanosleep(&ts, nullptr); }
+    }
+  }
   return hipEventSynchronize(ctx->ev_done) == hipSuccess ? 0 : -1;
 }
 
@@ -140,6 +152,7 @@ extern "C" int pgpu_init(int device, pgpu_ctx** out) {
   for (auto& e : ctx->ev_aux)
     if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete ctx; return PGPU_EDEVICE; }
   { const char* f = getenv("PGPU_FANOUT"); ctx->fanout = !(f && f[0] == '0'); }
+  { const char* f = getenv("PGPU_WAIT"); if (f) ctx->wait_poll_us = atol(f); }
   { const char* f = getenv("PGPU_STREAMS"); const int v = f ? atoi(f) : 0; if (v >= 1 && v <= pgpu_ctx::NAUX) ctx->n_aux = v; }
   *out = ctx;
   return PGPU_OK;
