@@ -398,6 +398,7 @@ static void kstat_add(ef_sched_stats* st, const ef_kernel_stat* k);
 
 /* service thread: merge everything posted, run it as one plan, publish the results */
 static void* service_main(void* arg) {
+  pthread_setname_np(pthread_self(), "ef-gpu-service");
   service_thread* me = (service_thread*)arg;
   service* sv = me->sv;
   shared* sh = sv->sh;
@@ -527,6 +528,7 @@ static int collect_dp(worker* w, lane* ln) {
 }
 
 static void* worker_main(void* arg) {
+  pthread_setname_np(pthread_self(), "ef-worker");
   worker* w = (worker*)arg;
   shared* sh = w->sh;
   const int n_lanes = sh->n_lanes;
@@ -666,6 +668,7 @@ struct ef_session {
  * beside the parsing and preparation of the ESTs (the genomic sequence is loaded first) */
 typedef struct { pgpu_ctx* ctx; int rc; const char* gen; size_t gen_len; pgpu_index* idx; int idx_rc; } gpu_boot;
 static void* gpu_boot_main(void* arg) {
+  pthread_setname_np(pthread_self(), "ef-gpu-boot");
   gpu_boot* b = (gpu_boot*)arg;
   b->rc = pgpu_init(ef_gpu_device_from_env(), &b->ctx);
   if (b->rc == PGPU_OK) {
@@ -771,6 +774,7 @@ static void free_unit_buffers(shared* sh, bool release) {
 /* prefetch thread: the pairings of chunk after chunk (one resident batch each); every finished
  * chunk releases its units to the workers */
 static void* prefetch_main(void* arg) {
+  pthread_setname_np(pthread_self(), "ef-pairings");
   ef_session* s = (ef_session*)arg;
   shared* sh = &s->sh;
   pgpu_pairing_params prm = { s->in.cfg.min_factor_len, 0, s->in.cfg.min_string_depth_rate };
@@ -866,6 +870,7 @@ int ef_session_step(ef_session* s, ef_sched_stats* stats_out) {
 /* one of the six files: the units' text in input order (one writer thread per file) */
 typedef struct { shared* sh; FILE* f; int k; } file_writer;
 static void* file_writer_main(void* arg) {
+  pthread_setname_np(pthread_self(), "ef-writer");
   file_writer* fw = (file_writer*)arg;
   setvbuf(fw->f, NULL, _IOFBF, 1 << 20);
   for (size_t u = 0; u < fw->sh->n_units; ++u)
