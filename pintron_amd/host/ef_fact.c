@@ -262,14 +262,6 @@ static bool exon_start_end_ok(ef_list* fact) {                        /* :1989-2
   return true;
 }
 
-/* alignment rows copied into zero-padded buffers (the reference scans a little past the end) */
-static char* padded_copy(const char* s) {
-  const size_t n = strlen(s);
-  char* r = (char*)calloc(n + 32, 1);
-  memcpy(r, s, n);
-  return r;
-}
-
 /* handle_endpoints (:2127-2301): the first and the last exon are re-aligned and trimmed.  With two
  * or more exons the two alignments do not depend on each other and are requested together; with a
  * single exon the second alignment sees the trimmed exon, as in the reference. */
@@ -291,7 +283,7 @@ static void endpoint_head_apply(ef_list* fact, ef_factor* head, const ef_dp_res*
 }
 
 static void endpoint_tail_apply(ef_list* fact, ef_factor* tail, const ef_dp_res* r) {
-  char* ea = padded_copy(r->s0); char* ga = padded_copy(r->s1);
+  char* ea = r->s0; char* ga = r->s1;       /* zero-padded and ours to rewrite (ef_dp_res) */
   const int dim = r->v[1];
   int j = dim - 1, matches = 0, cut_factor = tail->EST_end, cut_exon = tail->GEN_end;
   bool stop = false;
@@ -322,7 +314,6 @@ static void endpoint_tail_apply(ef_list* fact, ef_factor* tail, const ef_dp_res*
   }
   if (gen_cleavage >= tail->GEN_start) { tail->EST_end = est_cleavage; tail->GEN_end = gen_cleavage; }
   else free(efl_pop_back(fact));
-  free(ea); free(ga);
 }
 
 static void endpoint_request(ef_dp_req* q, const ef_factor* x, const char* gen, const char* est) {
@@ -332,7 +323,7 @@ static void endpoint_request(ef_dp_req* q, const ef_factor* x, const char* gen, 
 }
 static void endpoint_release(ef_dp_req* q, ef_dp_res* r) {
   (void)q;
-  free(r->s0); free(r->s1);
+  ef_dp_res_release(r);
 }
 
 static ef_list* handle_endpoints(ef_list* fact, const char* gen, const char* est, ef_backend* be) {
@@ -479,7 +470,8 @@ static ef_list* keep_best_run(ef_list* fact, const int* split_idx, int n_split) 
 
 /* clean_low_complexity_exons_2 (:1667-1704) */
 static ef_list* clean_low_complexity(ef_list* fact, const char* gen, const char* est, const ef_config* cfg) {
-  int* idx = (int*)malloc((efl_size(fact) + 1) * sizeof(int));
+  int idx_small[64];
+  int* idx = efl_size(fact) < 64 ? idx_small : (int*)malloc((efl_size(fact) + 1) * sizeof(int));
   int n = 0, index = 1;
   ef_iter it = efl_begin(fact);
   while (efi_has_next(&it)) {
@@ -490,7 +482,7 @@ static ef_list* clean_low_complexity(ef_list* fact, const char* gen, const char*
     ++index;
   }
   fact = keep_best_run(fact, idx, n);
-  free(idx);
+  if (idx != idx_small) free(idx);
   return fact;
 }
 
@@ -504,10 +496,14 @@ static unsigned max_edit_for_exon(size_t exon_length) {                 /* :1828
  * other, so they are requested together */
 ef_list* ef_clean_noisy_exons(ef_list* fact, const char* gen, const char* est, bool only_internals, ef_backend* be) {
   const size_t size = efl_size(fact);
-  int* idx = (int*)malloc((size + 1) * sizeof(int));
-  ef_dp_req* rq = (ef_dp_req*)malloc((size + 1) * sizeof(ef_dp_req));
-  ef_dp_res* rs = (ef_dp_res*)malloc((size + 1) * sizeof(ef_dp_res));
-  int* slot = (int*)malloc((size + 1) * sizeof(int));        /* request of each visited exon, -1 = none */
+  /* factorizations have a handful of exons: the work arrays live on the (fibre) stack */
+  enum { SMALL = 24 };
+  int idx_small[SMALL], slot_small[SMALL]; ef_dp_req rq_small[SMALL]; ef_dp_res rs_small[SMALL];
+  const bool small = size < SMALL;
+  int* idx = small ? idx_small : (int*)malloc((size + 1) * sizeof(int));
+  ef_dp_req* rq = small ? rq_small : (ef_dp_req*)malloc((size + 1) * sizeof(ef_dp_req));
+  ef_dp_res* rs = small ? rs_small : (ef_dp_res*)malloc((size + 1) * sizeof(ef_dp_res));
+  int* slot = small ? slot_small : (int*)malloc((size + 1) * sizeof(int));   /* request of each visited exon, -1 = none */
   size_t nrq = 0, nvis = 0;
   int index = only_internals ? 2 : 1;
   const int first_index = index;
@@ -534,7 +530,7 @@ ef_list* ef_clean_noisy_exons(ef_list* fact, const char* gen, const char* est, b
     if (!ok) idx[n++] = first_index + (int)v;
   }
   fact = keep_best_run(fact, idx, n);
-  free(idx); free(rq); free(rs); free(slot);
+  if (!small) { free(idx); free(rq); free(rs); free(slot); }
   return fact;
 }
 
@@ -768,9 +764,10 @@ static bool detect_polyA(ef_list* fact, const char* gen, const char* est, bool* 
     i = tail->GEN_end - 39 > 0 ? tail->GEN_end - 39 : 0;
     while (i <= tail->GEN_end && !*polyadenil) {
       if (gen[i] == 'a' || gen[i] == 'A') {
-        char* pas = ef_real_substring(i, 6, gen);
+        char pas[8];                                 /* real_substring(i, 6, gen): stops at the terminator */
+        const size_t pl = view_len(gen, i, 6);
+        memcpy(pas, gen + i, pl); pas[pl] = '\0';
         if (!strcmp(pas, "aataaa") || !strcmp(pas, "AATAAA") || !strcmp(pas, "attaaa") || !strcmp(pas, "ATTAAA")) *polyadenil = true;
-        free(pas);
       }
       ++i;
     }

@@ -50,14 +50,19 @@ size_t ef_jobbuf_add(ef_jobbuf* jb, const ef_dp_req* q, const char* gen, size_t 
   return jb->n++;
 }
 
-/* pgpu_dp_result -> ef_dp_res (alignment rows are copied out of the batch's string buffer) */
+/* pgpu_dp_result -> ef_dp_res (alignment rows are copied out of the batch's string buffer into one
+ * padded block, see ef_dp_res) */
 int ef_decode_result(int kind, const pgpu_dp_result* r, const char* strings, ef_dp_res* out) {
   memset(out, 0, sizeof(*out));
   if (r->status != PGPU_OK) return r->status;
   for (int k = 0; k < 6; ++k) out->v[k] = r->v[k];
   if (kind == EF_DP_ALIGN || kind == EF_DP_GAP) {
-    out->s0 = strdup(strings + r->str[0]);
-    out->s1 = strdup(strings + r->str[1]);
+    const char* row0 = strings + r->str[0]; const char* row1 = strings + r->str[1];
+    const size_t n0 = strlen(row0), n1 = strlen(row1);
+    char* blk = (char*)malloc(n0 + n1 + 2 * EF_ROW_PAD);
+    memcpy(blk, row0, n0); memset(blk + n0, 0, EF_ROW_PAD);
+    memcpy(blk + n0 + EF_ROW_PAD, row1, n1); memset(blk + n0 + EF_ROW_PAD + n1, 0, EF_ROW_PAD);
+    out->s0 = blk; out->s1 = blk + n0 + EF_ROW_PAD;
   }
   return 0;
 }

@@ -273,19 +273,30 @@ static int cmp_by_id(const void* a, const void* b) {
 void ef_transitive_reduction(ef_meg* V) {
   size_t nv = 0, dummy;
   ef_meg_stats(V, &nv, &dummy);
-  ef_pairing** G = (ef_pairing**)malloc((nv + 1) * sizeof(ef_pairing*));
+  /* one scratch block for every per-vertex array of this call */
+  const size_t np1 = nv + 1;
+  char* scratch = (char*)malloc(np1 * (5 * sizeof(void*) + 2 * sizeof(int) + 1) + (4 * nv + 16) * sizeof(int));
+  ef_pairing** G = (ef_pairing**)scratch;
+  ef_pairing** T = G + np1;
+  ef_list** star = (ef_list**)(T + np1);
+  ef_list** red = star + np1;
+  ef_list** red_inc = red + np1;
+  int* color = (int*)(red_inc + np1);
+  int* ids = color + np1;
+  int* stack0 = ids + np1;
+  unsigned char* in_star = (unsigned char*)(stack0 + 4 * nv + 16);
   size_t k = 0;
   EF_MEG_FOR_POS(V, i, 0, V->n) {
     ef_iter it = efl_begin(V->v[i]);
     while (efi_has_next(&it)) { G[k] = (ef_pairing*)efi_next(&it); G[k]->id = (int)k; ++k; }
   }
   /* dfs_visit (:358-463): explicit stack, sources first, finishing order gives the ids */
-  int* color = (int*)calloc(nv + 1, sizeof(int));
-  int* ids = (int*)malloc((nv + 1) * sizeof(int));
-  int* stack = (int*)malloc((4 * nv + 16) * sizeof(int));
+  memset(color, 0, np1 * sizeof(int));
+  int* stack = stack0;
   size_t scap = 4 * nv + 16, sp = 0;
   bool acyclic = true;
-#define PUSH(x) do { if (sp == scap) { scap *= 2; stack = (int*)realloc(stack, scap * sizeof(int)); } stack[sp++] = (x); } while (0)
+#define PUSH(x) do { if (sp == scap) { int* bigger = (int*)malloc(2 * scap * sizeof(int)); memcpy(bigger, stack, scap * sizeof(int)); \
+                       if (stack != stack0) free(stack); stack = bigger; scap *= 2; } stack[sp++] = (x); } while (0)
   for (size_t i = 0; i < nv; ++i) if (efl_size(G[i]->incs) == 0) PUSH((int)i);
   if (sp == 0) acyclic = false;
   size_t progr = nv;
@@ -310,22 +321,16 @@ void ef_transitive_reduction(ef_meg* V) {
       if (color[i] == 0) { acyclic = false; PUSH((int)i); }
   } while (sp > 0);
 #undef PUSH
-  free(stack); free(color);
+  if (stack != stack0) free(stack);
   if (!acyclic) {
     fprintf(stderr, "* FATAL The graph is cyclic. Transitive reduction not possible! Terminating.\n");
     abort();
   }
   /* topological order = array order; adjacency lists sorted by id (:465-516) */
-  ef_pairing** T = (ef_pairing**)malloc((nv + 1) * sizeof(ef_pairing*));
   for (size_t i = 0; i < nv; ++i) { G[i]->id = ids[i]; T[ids[i]] = G[i]; }
-  free(ids); free(G);
   for (size_t i = 0; i < nv; ++i) { efl_sort(T[i]->adjs, cmp_by_id); efl_sort(T[i]->incs, cmp_by_id); }
   /* reduction (:518-632) */
-  ef_list** star = (ef_list**)malloc((nv + 1) * sizeof(ef_list*));
-  ef_list** red = (ef_list**)malloc((nv + 1) * sizeof(ef_list*));
-  ef_list** red_inc = (ef_list**)malloc((nv + 1) * sizeof(ef_list*));
   for (size_t i = 0; i < nv; ++i) { star[i] = efl_new(); red[i] = efl_new(); red_inc[i] = efl_new(); }
-  unsigned char* in_star = (unsigned char*)malloc(nv + 1);
   for (size_t i = nv; i-- > 0;) {
     ef_pairing* v = T[i];
     memset(in_star, 0, nv);
@@ -352,13 +357,12 @@ void ef_transitive_reduction(ef_meg* V) {
       }
     }
   }
-  free(in_star);
   for (size_t i = 0; i < nv; ++i) {
     efl_free(star[i], NULL);
     efl_free(T[i]->adjs, NULL); efl_free(T[i]->incs, NULL);
     T[i]->adjs = red[i]; T[i]->incs = red_inc[i];
   }
-  free(star); free(red); free(red_inc); free(T);
+  free(scratch);
 }
 
 void ef_meg_write(ef_sink* f, ef_meg* V) {

@@ -8,7 +8,7 @@
 #include "estfact.h"
 
 typedef struct {
-  char* est_row; char* gen_row;     /* zero-padded copies of the alignment rows */
+  char* est_row; char* gen_row;     /* the zero-padded alignment rows (one block, est_row first) */
   int dim, factor_cut, intron_start, intron_end, intron_start_on_align, intron_end_on_align;
   int new_acceptor_factor_left, new_donor_right_on_gen, new_acceptor_left_on_gen;
 } gap_aln;
@@ -59,11 +59,15 @@ int ef_burset_adaptor(const char* t, size_t cut1, size_t cut2) {        /* :362-
 }
 
 int ef_check_burset_patterns(const char* gen, int donor_left, int acceptor_right) {   /* :346-360 */
-  char* d = ef_real_substring(donor_left + 1, 2, gen);
-  char* a = ef_real_substring(acceptor_right - 2, 2, gen);
-  const int f = ef_burset_frequency(d, a);
-  free(d); free(a);
-  return f;
+  /* real_substring(donor_left + 1, 2, gen) and real_substring(acceptor_right - 2, 2, gen) (clamped
+   * at the start of the sequence, cut at its terminator) without the two allocations */
+  char d[3] = { 0, 0, 0 }, a[3] = { 0, 0, 0 };
+  int di = donor_left + 1, dl = 2, ai = acceptor_right - 2, al = 2;
+  if (di < 0) { dl += di; di = 0; }
+  if (ai < 0) { al += ai; ai = 0; }
+  for (int k = 0; k < dl && gen[di + k] != '\0'; ++k) d[k] = gen[di + k];
+  for (int k = 0; k < al && gen[ai + k] != '\0'; ++k) a[k] = gen[ai + k];
+  return ef_burset_frequency(d, a);
 }
 
 /* ---- searches on the gapped alignment ---------------------------------------------------------- */
@@ -152,13 +156,33 @@ static void find_AG_before_right(const gap_aln* al, int init, int* substr_dim) {
   *substr_dim = al->intron_end_on_align - index - 1;
 }
 
+/* the dozen short strings of one Shift_* call are carved from a block on the (fibre) stack */
+typedef struct { char buf[1024]; size_t used; } strpool;
+static char* sp_get(strpool* sp, size_t n) {
+  if (sp->used + n <= sizeof sp->buf) { char* r = sp->buf + sp->used; sp->used += n; return r; }
+  return (char*)malloc(n);
+}
+static void sp_put(strpool* sp, char* p) {
+  if (p && !(p >= sp->buf && p < sp->buf + sizeof sp->buf)) free(p);
+}
+/* real_substring (src/util.c:138-158) into the pool */
+static char* sp_substring(strpool* sp, int index, int length, const char* s) {
+  if (index < 0) { length += index; index = 0; }
+  if (length < 0) length = 0;
+  char* r = sp_get(sp, (size_t)length + 1);
+  int k = 0;
+  while (k < length && s[index + k] != '\0') { r[k] = s[index + k]; ++k; }
+  r[k] = '\0';
+  return r;
+}
+
 /* Get_genomic/est_substring_from_alignment (:1878-1948): ungapped row segment + mismatch count */
-static char* row_substring(const gap_aln* al, bool genomic, int init, int length, int* error) {
+static char* row_substring(strpool* sp, const gap_aln* al, bool genomic, int init, int length, int* error) {
   const int glen = (int)strlen(al->gen_row);
   if (init < 0 || init >= glen) return NULL;
   const int rlen = (int)strlen(genomic ? al->gen_row : al->est_row);
   const int actual = (rlen - init < length) ? rlen - init : length;
-  char* out = (char*)malloc((size_t)(actual > 0 ? actual : 0) + 1);
+  char* out = sp_get(sp, (size_t)(actual > 0 ? actual : 0) + 1);
   int k = 0, herr = 0;
   const char* row = genomic ? al->gen_row : al->est_row;
   for (int index = init; index < init + actual; ++index) {
@@ -170,8 +194,8 @@ static char* row_substring(const gap_aln* al, bool genomic, int init, int length
   return out;
 }
 
-static char* concat(const char* a, const char* b) {
-  char* r = (char*)malloc(strlen(a) + strlen(b) + 1);
+static char* concat(strpool* sp, const char* a, const char* b) {
+  char* r = sp_get(sp, strlen(a) + strlen(b) + 1);
   strcpy(r, a); strcat(r, b);
   return r;
 }
@@ -190,14 +214,16 @@ static bool shift_generic(const char* est, const char* gen, const gap_aln* al, b
   char *cut_factor[CYCLES], *match_str[CYCLES], *prev_match[CYCLES], *ext_cut[CYCLES], *ext_match[CYCLES];
   int ext_error = -1;
   char *ext_est = NULL, *ext_gen = NULL;
+  strpool pool; pool.used = 0;
+  strpool* sp = &pool;
   if (r2l) {
     int l_substr = 8, start = al->intron_start_on_align - l_substr;
     if (start < 0) { l_substr = l_substr - start; start = 0; }
-    ext_est = row_substring(al, false, start, l_substr, &ext_error);
-    ext_gen = row_substring(al, true, start, l_substr, &ext_error);
+    ext_est = row_substring(sp, al, false, start, l_substr, &ext_error);
+    ext_gen = row_substring(sp, al, true, start, l_substr, &ext_error);
   } else {
-    ext_est = row_substring(al, false, al->intron_end_on_align + 1, 8, &ext_error);
-    ext_gen = row_substring(al, true, al->intron_end_on_align + 1, 8, &ext_error);
+    ext_est = row_substring(sp, al, false, al->intron_end_on_align + 1, 8, &ext_error);
+    ext_gen = row_substring(sp, al, true, al->intron_end_on_align + 1, 8, &ext_error);
   }
   for (int i = 0; i < CYCLES; ++i) {
     if (r2l) find_AG_after_right(al, init_right, &cut_on_align, &gen_cut[i], &est_cut[i]);
@@ -205,33 +231,33 @@ static bool shift_generic(const char* est, const char* gen, const gap_aln* al, b
     prev_match[i] = NULL; cut_factor[i] = NULL; ext_cut[i] = NULL;
     if (est_cut[i] > -1) {
       if (r2l) {
-        prev_match[i] = ef_real_substring(al->new_acceptor_left_on_gen, gen_cut[i], gen);
-        cut_factor[i] = ef_real_substring(al->new_acceptor_factor_left, est_cut[i], est);
+        prev_match[i] = sp_substring(sp, al->new_acceptor_left_on_gen, gen_cut[i], gen);
+        cut_factor[i] = sp_substring(sp, al->new_acceptor_factor_left, est_cut[i], est);
         init_right = cut_on_align + 1;
       } else {
-        prev_match[i] = ef_real_substring(al->new_donor_right_on_gen - gen_cut[i] + 1, gen_cut[i], gen);
-        cut_factor[i] = ef_real_substring(al->new_acceptor_factor_left - est_cut[i], est_cut[i], est);
+        prev_match[i] = sp_substring(sp, al->new_donor_right_on_gen - gen_cut[i] + 1, gen_cut[i], gen);
+        cut_factor[i] = sp_substring(sp, al->new_acceptor_factor_left - est_cut[i], est_cut[i], est);
         init_left = cut_on_align - 1;
       }
       if (ext_error > 0 && ext_est != NULL)
-        ext_cut[i] = r2l ? concat(ext_est, cut_factor[i]) : concat(cut_factor[i], ext_est);
+        ext_cut[i] = r2l ? concat(sp, ext_est, cut_factor[i]) : concat(sp, cut_factor[i], ext_est);
     }
     if (r2l) find_after_left(al, init_left, &sub_dim[i], pat);
     else find_AG_before_right(al, init_right, &sub_dim[i]);
     match_str[i] = NULL; ext_match[i] = NULL;
     if (sub_dim[i] > -1) {
       if (r2l) {
-        match_str[i] = ef_real_substring(al->new_donor_right_on_gen + 1, sub_dim[i], gen);
+        match_str[i] = sp_substring(sp, al->new_donor_right_on_gen + 1, sub_dim[i], gen);
         init_left = al->intron_start_on_align + sub_dim[i] + 1;
       } else {
-        match_str[i] = ef_real_substring(al->new_acceptor_left_on_gen - sub_dim[i], sub_dim[i], gen);
+        match_str[i] = sp_substring(sp, al->new_acceptor_left_on_gen - sub_dim[i], sub_dim[i], gen);
         init_right = al->intron_end_on_align - sub_dim[i] - 1;
       }
       if (cut_factor[i] != NULL && ext_error > 0 && ext_gen != NULL)
-        ext_match[i] = r2l ? concat(ext_gen, match_str[i]) : concat(match_str[i], ext_gen);
+        ext_match[i] = r2l ? concat(sp, ext_gen, match_str[i]) : concat(sp, match_str[i], ext_gen);
     }
   }
-  free(ext_est); free(ext_gen);
+  sp_put(sp, ext_est); sp_put(sp, ext_gen);
 
   /* Every edit distance the decision loops below can ask for is a function of strings that are
    * fixed by now (<= 2 + 4 pairs of at most a few dozen characters): they are requested together
@@ -311,7 +337,7 @@ static bool shift_generic(const char* est, const char* gen, const gap_aln* al, b
       }
     }
   }
-  for (int i = 0; i < CYCLES; ++i) { free(cut_factor[i]); free(match_str[i]); free(prev_match[i]); free(ext_cut[i]); free(ext_match[i]); }
+  for (int i = 0; i < CYCLES; ++i) { sp_put(sp, cut_factor[i]); sp_put(sp, match_str[i]); sp_put(sp, prev_match[i]); sp_put(sp, ext_cut[i]); sp_put(sp, ext_match[i]); }
   return stop;
 }
 
@@ -343,13 +369,6 @@ static void try_burset_after_match(const char* est, const char* gen, int* factor
   }
   if (right_to_left) uf += 1;
   *factor_left = uf; *donor_right = ud; *acc_left = ua;
-}
-
-static char* padded(const char* s) {
-  const size_t n = strlen(s);
-  char* r = (char*)calloc(n + 64, 1);
-  memcpy(r, s, n);
-  return r;
 }
 
 /* appends real_substring(index, length, s) (src/util.c:138-158) to dst[n..]; returns the new length */
@@ -403,8 +422,7 @@ bool ef_refine_intron(const ef_config* cfg, const ef_seq* gen_info, const ef_seq
   memset(&rs, 0, sizeof rs);
   if (be->dp(be->self, &rq, &rs) != 0) { fprintf(stderr, "* FATAL gap alignment backend failed\n"); abort(); }
   gap_aln al;
-  al.est_row = padded(rs.s0); al.gen_row = padded(rs.s1);
-  free(rs.s0); free(rs.s1);
+  al.est_row = rs.s0; al.gen_row = rs.s1;      /* one zero-padded block (ef_dp_res), released at `done` */
   al.dim = rs.v[0]; al.factor_cut = rs.v[1]; al.intron_start = rs.v[2]; al.intron_end = rs.v[3];
   al.intron_start_on_align = rs.v[4]; al.intron_end_on_align = rs.v[5];
   al.new_acceptor_factor_left = dsl_est + al.factor_cut;
@@ -460,6 +478,6 @@ bool ef_refine_intron(const ef_config* cfg, const ef_seq* gen_info, const ef_seq
     result = true;
   }
 done:
-  free(al.est_row); free(al.gen_row);
+  free(al.est_row);                          /* est_row heads the block of both rows */
   return result;
 }

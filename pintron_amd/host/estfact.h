@@ -210,8 +210,18 @@ typedef struct {
                                     by address and sent as PGPU_JOB_*_GENOMIC (no copy) */
 typedef struct {
   int32_t v[6];
-  char* s0; char* s1;            /* ALIGN/GAP: malloc'ed alignment rows (caller frees) */
+  char* s0; char* s1;            /* ALIGN/GAP: the two alignment rows, writable, in ONE block owned by
+                                    the caller (ef_dp_res_release); each row is followed by at least
+                                    EF_ROW_PAD zero bytes (the reference's scans run a little past
+                                    the end of the rows) */
 } ef_dp_res;
+#define EF_ROW_PAD 64
+/* room for two rows of up to `cap` characters each, zero-filled */
+static inline void ef_dp_res_rows(ef_dp_res* r, size_t cap) {
+  r->s0 = (char*)calloc(2 * (cap + EF_ROW_PAD), 1);
+  r->s1 = r->s0 + cap + EF_ROW_PAD;
+}
+static inline void ef_dp_res_release(ef_dp_res* r) { free(r->s0); r->s0 = r->s1 = NULL; }
 
 typedef struct ef_backend {
   void* self;

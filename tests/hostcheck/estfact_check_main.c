@@ -35,14 +35,14 @@ static int oracle_dp_impl(void* self, const ef_dp_req* q, ef_dp_res* r) {
   (void)self;
   switch (q->kind) {
     case EF_DP_ALIGN: {
-      r->s0 = (char*)malloc(q->la + q->lb + 2); r->s1 = (char*)malloc(q->la + q->lb + 2);
+      ef_dp_res_rows(r, q->la + q->lb + 2);
       int32_t dim;
       r->v[0] = (int32_t)orc_align(q->a, q->la, q->b, q->lb, r->s0, r->s1, &dim);
       r->v[1] = dim;
       return 0;
     }
     case EF_DP_GAP: {
-      r->s0 = (char*)malloc(q->la + q->lb + 2); r->s1 = (char*)malloc(q->la + q->lb + 2);
+      ef_dp_res_rows(r, q->la + q->lb + 2);
       orc_gap_result g;
       orc_gap_align(q->a, q->la, q->b, q->lb, r->s0, r->s1, &g);
       r->v[0] = g.dim; r->v[1] = g.factor_cut; r->v[2] = g.intron_start; r->v[3] = g.intron_end;
