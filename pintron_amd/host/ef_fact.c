@@ -841,7 +841,8 @@ ef_est* ef_get_est_factorizations(const ef_seq* est_info, ef_meg* V, const ef_co
   /* FILTER 1: coverage (:278-331) */
   {
     const size_t nf = efl_size(flist);
-    double* cov = (double*)malloc((nf + 1) * sizeof(double));
+    double cov_small[32];
+    double* cov = nf < 32 ? cov_small : (double*)malloc((nf + 1) * sizeof(double));
     double max_cov = 0.0;
     size_t k = 0;
     ef_iter it = efl_begin(flist);
@@ -864,12 +865,13 @@ ef_est* ef_get_est_factorizations(const ef_seq* est_info, ef_meg* V, const ef_co
       if (c == -1.0 || max_cov - c > cfg->max_coverage_diff) efi_remove(&it, ef_factorization_free);
       else if ((max_cov - c) * slen > 100) efi_remove(&it, ef_factorization_free);
     }
-    free(cov);
+    if (cov != cov_small) free(cov);
   }
   /* FILTER 3: gap length on P (:376-414) */
   {
     const size_t nf = efl_size(flist);
-    int* gl = (int*)malloc((nf + 1) * sizeof(int));
+    int gl_small[32];
+    int* gl = nf < 32 ? gl_small : (int*)malloc((nf + 1) * sizeof(int));
     int min_gl = -1;
     size_t k = 0;
     ef_iter it = efl_begin(flist);
@@ -885,7 +887,7 @@ ef_est* ef_get_est_factorizations(const ef_seq* est_info, ef_meg* V, const ef_co
       const int g = gl[k++];
       if (cfg->max_gapLength_diff != -1 && g - min_gl > cfg->max_gapLength_diff) efi_remove(&it, ef_factorization_free);
     }
-    free(gl);
+    if (gl != gl_small) free(gl);
   }
   /* FILTER 4: gap errors (:416-433) */
   {

@@ -140,13 +140,14 @@ static inline bool efl_remove_first(ef_list* l, void* el) {
 static inline void efl_sort(ef_list* l, int (*cmp)(const void*, const void*)) {
   const size_t n = l->size;
   if (n < 2) return;
-  void** base = (void**)malloc(n * sizeof(void*));
+  void* small[64];
+  void** base = n <= 64 ? small : (void**)malloc(n * sizeof(void*));
   size_t i = 0;
   for (ef_node* x = l->sent.next; x != &l->sent; x = x->next) base[i++] = x->el;
   qsort(base, n, sizeof(void*), cmp);
   i = 0;
   for (ef_node* x = l->sent.next; x != &l->sent; x = x->next) x->el = base[i++];
-  free(base);
+  if (base != small) free(base);
 }
 
 #endif
