@@ -45,13 +45,13 @@ def rocprof_symbol(group_name):
     modes = {"ED": 0, "ALIGN": 1, "BORDERS": 2, "AFFIX": 3, "KBAND": 4}
     m = re.match(r"lev_wave<(\w+)>$", group_name)                 # every row class in one launch
     if m:
-        return "lev_any_kernel<%d>" % modes[m.group(1)]
+        return "lev_any_kernel<%d, false>" % modes[m.group(1)]    # the common row classes (<= 16 rows per lane)
     m = re.match(r"lev_wave<(\w+),R=1>", group_name)
     if m:
         return "lev_wave_kernel<1, %d, false>" % modes[m.group(1)]
     if group_name == "lev_wave<AFFIX,strips>":
         return "lev_wave_kernel<64, 3, true>"
-    return {"gap_wave": "gap_any_kernel", "borders_coop": "borders_coop_any_kernel", "affix_coop": "affix_coop_any_kernel",
+    return {"gap_wave": "gap_any_kernel<false>", "borders_coop": "borders_coop_any_kernel", "affix_coop": "affix_coop_any_kernel",
             "lcf": "lcf_kernel", "align_traceback": "align_traceback_wave_kernel",
             "gap_traceback": "gap_traceback_wave_kernel"}.get(group_name, group_name.split("+")[0] + "_kernel")
 

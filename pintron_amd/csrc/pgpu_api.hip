@@ -187,6 +187,7 @@ struct Group {
   int R;                 // row class (0 when not applicable)
   size_t first, count;   // slice of the sorted device job table
   uint32_t max_chunks = 0, max_l2 = 0;
+  uint32_t n_big = 0;          // leading jobs of the large row classes (ED, ALIGN, KBAND: above 16 rows per lane; GAP: above 4)
   uint32_t max_rows = 0;       // largest a_len of the group (LDS of the one-job-per-workgroup BORDERS kernel)
   bool traceback = false;      // this group is the traceback pass of (family)
   uint64_t cells = 0, algo_bytes = 0;
@@ -399,6 +400,7 @@ extern "C" int pgpu_dp_plan_create_parts(pgpu_ctx* ctx, const pgpu_index* idx, c
       // ALIGN, 3 B/cell for GAP; 8 B per row when row minima are produced
       g.algo_bytes += la + lb;
       g.max_rows = std::max(g.max_rows, (uint32_t)la);
+      if (k.R >= (k.family == KF_GAP ? 8u : 32u)) ++g.n_big;
       if (k.family == KF_ALIGN) g.algo_bytes += la * lb + 3 * (la + lb);     // + directions read back, two strings
       if (k.family == KF_GAP) g.algo_bytes += 3 * la * lb + 3 * (la + lb);
       if (k.family == KF_BORDERS) g.algo_bytes += 2 * 8 * la;
@@ -542,8 +544,8 @@ extern "C" int pgpu_dp_plan_launch(pgpu_ctx* ctx, pgpu_dp_plan* p) {
       if (g.ev0) HIP_TRY(ctx, hipEventRecord(g.ev0, st));
       switch (g.family) {
         case KF_ALIGN: case KF_ED: case KF_BORDERS: case KF_AFFIX: case KF_KBAND:
-          launch_lev(g.family, g.R, g.max_rows, jobs, n, p->d_results, p->d_ws, p->d_strs, st); break;
-        case KF_GAP: launch_gap(jobs, n, p->d_results, p->d_ws, p->d_strs, st); break;
+          launch_lev(g.family, g.R, g.max_rows, jobs, n, (int)g.n_big, p->d_results, p->d_ws, p->d_strs, st); break;
+        case KF_GAP: launch_gap(jobs, n, (int)g.n_big, p->d_results, p->d_ws, p->d_strs, st); break;
         case KF_LCF:
           launch_lcf(jobs, n, g.max_chunks, g.max_l2, p->d_keys + key_of[gi], st);
           launch_lcf_finish(jobs, n, p->d_results, p->d_keys + key_of[gi], st);

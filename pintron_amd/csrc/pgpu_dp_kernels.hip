@@ -496,7 +496,30 @@ __device__ __forceinline__ void own_stores_visible() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 
-template <int MODE>
+// BIG = the classes with 32 and 64 rows per lane and the strips (rare in a batch, a few hundred
+// registers per lane); the common classes up to 16 rows per lane get a kernel of their own whose
+// register budget lets several waves share a SIMD.  Jobs are sorted big classes first, so the two
+// launches take the two ends of the family's slice.
+template <int MODE, bool BIG>
+__device__ __forceinline__ void lev_any_dispatch(const DevJob& job, DevResult* res, uint8_t* __restrict__ ws, const uint32_t lane) {
+  if constexpr (BIG) {
+    switch (job.r_class) {
+      case 32: lev_wave_body<32, MODE>(job, res, ws, lane); break;
+      case 64: lev_wave_body<64, MODE>(job, res, ws, lane); break;
+      default: lev_wave_body<64, MODE, true>(job, res, ws, lane); break;      // ROW_CLASS_STRIPS
+    }
+  } else {
+    switch (job.r_class) {
+      case 1:  lev_wave_body<1, MODE>(job, res, ws, lane); break;
+      case 2:  lev_wave_body<2, MODE>(job, res, ws, lane); break;
+      case 4:  lev_wave_body<4, MODE>(job, res, ws, lane); break;
+      case 8:  lev_wave_body<8, MODE>(job, res, ws, lane); break;
+      default: lev_wave_body<16, MODE>(job, res, ws, lane); break;
+    }
+  }
+}
+
+template <int MODE, bool BIG>
 __global__ __launch_bounds__(256)
 void lev_any_kernel(const DevJob* __restrict__ jobs, int njobs, DevResult* __restrict__ results,
                     uint8_t* __restrict__ ws, uint8_t* __restrict__ strs) {
@@ -505,32 +528,12 @@ void lev_any_kernel(const DevJob* __restrict__ jobs, int njobs, DevResult* __res
   if (w >= njobs) return;
   const DevJob job = jobs[w];
   DevResult* res = &results[job.out_idx];
+  lev_any_dispatch<MODE, BIG>(job, res, ws, lane);
   if constexpr (MODE == MODE_ALIGN) {      // matrix, then the traceback by the same wave
     __shared__ __attribute__((aligned(16))) uint8_t s_win[4][TB_WIN_BYTES];
     __shared__ uint8_t s_path[4][TB_PATH];
-    switch (job.r_class) {
-      case 1:  lev_wave_body<1, MODE>(job, res, ws, lane); break;
-      case 2:  lev_wave_body<2, MODE>(job, res, ws, lane); break;
-      case 4:  lev_wave_body<4, MODE>(job, res, ws, lane); break;
-      case 8:  lev_wave_body<8, MODE>(job, res, ws, lane); break;
-      case 16: lev_wave_body<16, MODE>(job, res, ws, lane); break;
-      case 32: lev_wave_body<32, MODE>(job, res, ws, lane); break;
-      case 64: lev_wave_body<64, MODE>(job, res, ws, lane); break;
-      default: lev_wave_body<64, MODE, true>(job, res, ws, lane); break;      // ROW_CLASS_STRIPS
-    }
     own_stores_visible();
     align_traceback_wave(job, res, ws, strs, lane, s_win[threadIdx.x >> 6], s_path[threadIdx.x >> 6]);
-    return;
-  }
-  switch (job.r_class) {
-    case 1:  lev_wave_body<1, MODE>(job, res, ws, lane); break;
-    case 2:  lev_wave_body<2, MODE>(job, res, ws, lane); break;
-    case 4:  lev_wave_body<4, MODE>(job, res, ws, lane); break;
-    case 8:  lev_wave_body<8, MODE>(job, res, ws, lane); break;
-    case 16: lev_wave_body<16, MODE>(job, res, ws, lane); break;
-    case 32: lev_wave_body<32, MODE>(job, res, ws, lane); break;
-    case 64: lev_wave_body<64, MODE>(job, res, ws, lane); break;
-    default: lev_wave_body<64, MODE, true>(job, res, ws, lane); break;      // ROW_CLASS_STRIPS
   }
 }
 
@@ -928,7 +931,9 @@ __device__ __forceinline__ void gap_wave_body(const DevJob& job, DevResult* res,
   }
 }
 
-// all row classes of a batch's gap alignments in one launch (see lev_any_kernel)
+// all row classes of a batch's gap alignments in one launch (see lev_any_kernel); BIG = 8 rows per
+// lane and more (gap alignments of more than 256 EST characters: rare)
+template <bool BIG>
 __global__ __launch_bounds__(256)
 void gap_any_kernel(const DevJob* __restrict__ jobs, int njobs, DevResult* __restrict__ results,
                     uint8_t* __restrict__ ws, uint8_t* __restrict__ strs) {
@@ -939,13 +944,18 @@ void gap_any_kernel(const DevJob* __restrict__ jobs, int njobs, DevResult* __res
   if (w >= njobs) return;
   const DevJob job = jobs[w];
   DevResult* res = &results[job.out_idx];
-  switch (job.r_class) {
-    case 1:  gap_wave_body<1>(job, res, ws, lane); break;
-    case 2:  gap_wave_body<2>(job, res, ws, lane); break;
-    case 4:  gap_wave_body<4>(job, res, ws, lane); break;
-    case 8:  gap_wave_body<8>(job, res, ws, lane); break;
-    case 16: gap_wave_body<16>(job, res, ws, lane); break;
-    default: gap_wave_body<32>(job, res, ws, lane); break;
+  if constexpr (BIG) {
+    switch (job.r_class) {
+      case 8:  gap_wave_body<8>(job, res, ws, lane); break;
+      case 16: gap_wave_body<16>(job, res, ws, lane); break;
+      default: gap_wave_body<32>(job, res, ws, lane); break;
+    }
+  } else {
+    switch (job.r_class) {
+      case 1:  gap_wave_body<1>(job, res, ws, lane); break;
+      case 2:  gap_wave_body<2>(job, res, ws, lane); break;
+      default: gap_wave_body<4>(job, res, ws, lane); break;
+    }
   }
   own_stores_visible();                  // the planes and the start plane (res->pad)
   gap_traceback_wave(job, res, ws, strs, lane, s_win[threadIdx.x >> 6], s_path[threadIdx.x >> 6]);
@@ -1122,17 +1132,27 @@ __global__ void lcf_finish_kernel(const DevJob* __restrict__ jobs, int njobs,
 
 }  // namespace
 
-// R = 0: every row class of the family in one launch (ED, ALIGN, KBAND; BORDERS / AFFIX above 64
+// R = 0: every row class of the family in one launch (ED, ALIGN, KBAND: the first n_big jobs are
+// of the classes above 16 rows per lane and go to the BIG instance; BORDERS / AFFIX above 64
 // rows, `max_rows` sizes the dynamic LDS); R = 1: the single-wave BORDERS / AFFIX kernels;
 // R = ROW_CLASS_STRIPS: AFFIX beyond 4096 rows.
-void launch_lev(int family, int R, uint32_t max_rows, const DevJob* jobs, int njobs, DevResult* res, uint8_t* ws,
+template <int MODE>
+static void launch_lev_any(const DevJob* jobs, int njobs, int n_big, DevResult* res, uint8_t* ws, uint8_t* strs, hipStream_t st) {
+  const dim3 b256(256);
+  if (n_big > 0)
+    hipLaunchKernelGGL((lev_any_kernel<MODE, true>), dim3((n_big + 3) / 4), b256, 0, st, jobs, n_big, res, ws, strs);
+  if (njobs > n_big)
+    hipLaunchKernelGGL((lev_any_kernel<MODE, false>), dim3((njobs - n_big + 3) / 4), b256, 0, st, jobs + n_big, njobs - n_big, res, ws, strs);
+}
+
+void launch_lev(int family, int R, uint32_t max_rows, const DevJob* jobs, int njobs, int n_big, DevResult* res, uint8_t* ws,
                 uint8_t* strs, hipStream_t st) {
   if (njobs <= 0) return;
   const dim3 g4((njobs + 3) / 4), b256(256);
   switch (family) {
-    case KF_ED:    hipLaunchKernelGGL((lev_any_kernel<MODE_ED>), g4, b256, 0, st, jobs, njobs, res, ws, strs); break;
-    case KF_ALIGN: hipLaunchKernelGGL((lev_any_kernel<MODE_ALIGN>), g4, b256, 0, st, jobs, njobs, res, ws, strs); break;
-    case KF_KBAND: hipLaunchKernelGGL((lev_any_kernel<MODE_KBAND>), g4, b256, 0, st, jobs, njobs, res, ws, strs); break;
+    case KF_ED:    launch_lev_any<MODE_ED>(jobs, njobs, n_big, res, ws, strs, st); break;
+    case KF_ALIGN: launch_lev_any<MODE_ALIGN>(jobs, njobs, n_big, res, ws, strs, st); break;
+    case KF_KBAND: launch_lev_any<MODE_KBAND>(jobs, njobs, n_big, res, ws, strs, st); break;
     case KF_BORDERS:
       if (R == 1) {
         const size_t lds = 4 * (64 + 1) * sizeof(uint32_t);
@@ -1151,9 +1171,12 @@ void launch_lev(int family, int R, uint32_t max_rows, const DevJob* jobs, int nj
   }
 }
 
-void launch_gap(const DevJob* jobs, int njobs, DevResult* res, uint8_t* ws, uint8_t* strs, hipStream_t st) {
+void launch_gap(const DevJob* jobs, int njobs, int n_big, DevResult* res, uint8_t* ws, uint8_t* strs, hipStream_t st) {
   if (njobs <= 0) return;
-  hipLaunchKernelGGL(gap_any_kernel, dim3((njobs + 3) / 4), dim3(256), 0, st, jobs, njobs, res, ws, strs);
+  if (n_big > 0)
+    hipLaunchKernelGGL(gap_any_kernel<true>, dim3((n_big + 3) / 4), dim3(256), 0, st, jobs, n_big, res, ws, strs);
+  if (njobs > n_big)
+    hipLaunchKernelGGL(gap_any_kernel<false>, dim3((njobs - n_big + 3) / 4), dim3(256), 0, st, jobs + n_big, njobs - n_big, res, ws, strs);
 }
 
 void launch_lcf(const DevJob* jobs, int njobs, uint32_t max_chunks, uint32_t max_l2,
