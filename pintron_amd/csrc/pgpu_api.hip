@@ -38,6 +38,7 @@ struct pgpu_ctx {
   hipEvent_t ev_aux[NAUX] = {nullptr};
   bool fanout = true;        // spread groups over the auxiliary streams (PGPU_FANOUT=0 disables)
   int n_aux = NAUX;          // how many of them are used (PGPU_STREAMS=1..8)
+  bool packed = true;        // four streams, kernel families packed by expected duration (PGPU_PACK=0: round-robin over n_aux)
   // waiting: the calling thread must not burn a host core that other EST fibres could use (the
   // default HIP wait spins).  It naps and polls the event: measured on C3, naps of 50-200 us beat
   // a blocking-sync event by 5-7 % whole-program (the interrupt path costs more host time than
@@ -153,7 +154,8 @@ extern "C" int pgpu_init(int device, pgpu_ctx** out) {
     if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete ctx; return PGPU_EDEVICE; }
   { const char* f = getenv("PGPU_FANOUT"); ctx->fanout = !(f && f[0] == '0'); }
   { const char* f = getenv("PGPU_WAIT"); if (f) ctx->wait_poll_us = atol(f); }
-  { const char* f = getenv("PGPU_STREAMS"); const int v = f ? atoi(f) : 0; if (v >= 1 && v <= pgpu_ctx::NAUX) ctx->n_aux = v; }
+  { const char* f = getenv("PGPU_PACK"); if (f && atoi(f) == 0) ctx->packed = false; }
+  { const char* f = getenv("PGPU_STREAMS"); const int v = f ? atoi(f) : 0; if (v >= 1 && v <= pgpu_ctx::NAUX) { ctx->n_aux = v; ctx->packed = false; } }
   *out = ctx;
   return PGPU_OK;
 }
@@ -535,12 +537,27 @@ extern "C" int pgpu_dp_plan_launch(pgpu_ctx* ctx, pgpu_dp_plan* p) {
     std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return weight(a) > weight(b); });
   }
   int slot = 0;
+  unsigned used_mask = 0;
   for (size_t oi = 0; oi < order.size(); ++oi) {
     for (size_t gi = order[oi]; gi < p->groups.size() && (gi == order[oi] || p->groups[gi].traceback); ++gi) {
       Group& g = p->groups[gi];
       const DevJob* jobs = p->d_jobs + g.first;
       const int n = (int)g.count;
-      hipStream_t st = ctx->fanout ? ctx->aux[slot % ctx->n_aux] : ctx->stream;
+      // HIP spreads its streams over four hardware queues, and what shares a queue runs one after
+      // the other.  Packed: four streams (one per queue), the families dealt out so that the four
+      // sums of typical durations come out even (affix 247+19 | borders 175+75 | align 157 + lcf 93
+      // | gap 135 + kband 100 + ed 22 us on C3); otherwise round-robin in launch order.
+      int lane_of = slot % ctx->n_aux;
+      if (ctx->packed) {
+        switch (g.family) {
+          case KF_AFFIX: lane_of = 0; break;
+          case KF_BORDERS: lane_of = 1; break;
+          case KF_ALIGN: case KF_LCF: lane_of = 2; break;
+          default: lane_of = 3; break;
+        }
+        used_mask |= 1u << lane_of;
+      }
+      hipStream_t st = ctx->fanout ? ctx->aux[lane_of] : ctx->stream;
       if (g.ev0) HIP_TRY(ctx, hipEventRecord(g.ev0, st));
       switch (g.family) {
         case KF_ALIGN: case KF_ED: case KF_BORDERS: case KF_AFFIX: case KF_KBAND:
@@ -558,8 +575,9 @@ extern "C" int pgpu_dp_plan_launch(pgpu_ctx* ctx, pgpu_dp_plan* p) {
     ++slot;
   }
   if (ctx->fanout) {            // join: the main stream continues after every auxiliary stream
-    const int used = slot < ctx->n_aux ? slot : ctx->n_aux;
+    const int used = ctx->packed ? 4 : (slot < ctx->n_aux ? slot : ctx->n_aux);
     for (int i = 0; i < used; ++i) {
+      if (ctx->packed && !(used_mask & (1u << i))) continue;
       HIP_TRY(ctx, hipEventRecord(ctx->ev_aux[i], ctx->aux[i]));
       HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_aux[i], 0));
     }
