@@ -182,6 +182,46 @@ def make_long_transcripts(seed=77):
     return g, e
 
 
+def make_region_start_repeats(seed=5):
+    """Transcripts that begin with the very first bases of the genomic region (pairings with t == 0,
+    the occurrence without a preceding character: DESIGN.md section 4b), and repeats of those first
+    bases elsewhere in the region with other contexts, so that the t == 0 occurrence is reported at
+    an upper level of the reference's suffix tree while a longer match lies elsewhere.
+    Returns (genomic_fasta_text, ests_fasta_text)."""
+    import random
+    w = make("C2", n_est=10)
+    G = bytearray(w.genomic)
+    rng = random.Random(seed)
+    spots = ((3000, 60), (9000, 45), (12000, 80), (15000, 30))
+    for pos, n in spots:
+        G[pos:pos + n] = G[0:n]
+    G = bytes(G)
+    w.genomic = G
+
+    def rc(s):
+        return s[::-1].translate(bytes.maketrans(b"ACGT", b"TGCA"))
+
+    def mut(s, r):
+        b = bytearray(s)
+        for i in range(len(b)):
+            if rng.random() < r:
+                b[i] = rng.choice(b"ACGT")
+        return bytes(b)
+
+    e1s, e1e = w.exons[1]
+    extra = [G[0:350], G[0:180] + G[e1s:e1e][:150], rc(G[0:260] + G[e1s:e1e][:90]), G[0:25] + G[e1s:e1e],
+             G[0:80] + G[3060:3300]]
+    for pos, n in spots:
+        extra += [G[pos:pos + 300], G[pos - 100:pos + 250], G[pos:pos + n] + G[20000:20200], rc(G[pos:pos + 280])]
+    extra += [mut(x, 0.02) for x in extra]
+    seqs, heads = list(w.est_seqs), list(w.est_headers)
+    for k, x in enumerate(extra):
+        seqs.append(x)
+        heads.append(">/gb=T0%05d /clone_end=3'" % k)
+    w.est_seqs, w.est_headers = seqs, heads
+    return w.genomic_fasta(), w.ests_fasta()
+
+
 def make_edge_cases(seed=5):
     """Inputs around the corners of the input handling: N tails and internal N runs in the genomic
     sequence, negative-strand header, ESTs that are too short / all N / lower case / polyA only /

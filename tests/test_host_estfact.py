@@ -109,6 +109,24 @@ def test_edge_case_inputs_match_compiled_reference(bins, tmp_path):
             assert filecmp.cmp(my_dir / f, ref_dir / f, shallow=False), (tag, f)
 
 
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
+def test_region_start_pairings_match_compiled_reference(bins, tmp_path):
+    """Pairings with t == 0 (transcripts that begin on the first base of the region) and repeats of
+    the region's first bases: the case DESIGN.md section 4b singles out."""
+    from pintron_amd import synth
+    g, e = synth.make_region_start_repeats()
+    ref_dir, my_dir = tmp_path / "ref", tmp_path / "mine"
+    for d in (ref_dir, my_dir):
+        d.mkdir()
+        (d / "genomic.txt").write_text(g)
+        (d / "ests.txt").write_text(e)
+    subprocess.run([os.path.join(O.REF_DIR, "est-fact-ref")], cwd=ref_dir, check=True, stderr=subprocess.DEVNULL)
+    run(bins["estfact_sched_check"], my_dir, {"PINTRON_THREADS": "2"})
+    for f in FILES:
+        assert filecmp.cmp(my_dir / f, ref_dir / f, shallow=False), f
+    assert (my_dir / "raw-multifasta-out.txt").read_text().count(">/gb=T0") >= 30
+
+
 def test_cli_options_and_config_dump(bins, tmp_path):
     for f in ("genomic.txt", "ests.txt"):
         shutil.copy(os.path.join(GOLD, f), tmp_path)
