@@ -129,16 +129,25 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    os.environ["PINTRON_GPU_DEVICE"] = str(local if world > 1 else 0)
-    os.environ.setdefault("PINTRON_KERNEL_TIMING", "1")
     import torch
+    # one rank per GPU over RCCL.  PINTRON_DIST_BACKEND=gloo (as in pintron_amd.multi) keeps the
+    # exchange on the host and lets the ranks share GPUs: the way to exercise the N > 1 flow of this
+    # file on a box with fewer GPUs than ranks
+    backend = os.environ.get("PINTRON_DIST_BACKEND", "nccl")
+    dev_index = local if world > 1 else 0
+    if backend != "nccl":
+        dev_index = local % max(torch.cuda.device_count(), 1)
+    xdev = "cuda" if backend == "nccl" else "cpu"
+    os.environ["PINTRON_GPU_DEVICE"] = str(dev_index)
+    os.environ.setdefault("PINTRON_KERNEL_TIMING", "1")
     dist = None
+    torch.cuda.set_device(dev_index)
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-    else:
-        torch.cuda.set_device(0)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from pintron_amd import synth
     L = load_host_lib()
@@ -155,7 +164,7 @@ def main():
             # the only exchange of the sharded path: the factorization records of the rank's ESTs
             # (packed: 16 B per exon + 4 B per factorization, everything downstream stages parse out
             # of raw-multifasta-out.txt) -> rank 0 over RCCL
-            gather_tensor(sess.output_tensor(RECORDS), dist, rank, world, "cuda")
+            gather_tensor(sess.output_tensor(RECORDS), dist, rank, world, xdev)
         return st
 
     def fence():
@@ -171,7 +180,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device=xdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 

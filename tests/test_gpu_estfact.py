@@ -211,3 +211,21 @@ def test_record_gather_over_rccl_single_rank(exe, tmp_path):
 
 def s_units(w):
     return len(w.est_seqs)
+
+
+def test_bench_flow_with_two_ranks_on_one_gpu(exe, tmp_path):
+    """bench.py's N > 1 flow (barrier, per-step gather of the packed records to rank 0, max over
+    ranks) with two ranks sharing this box's GPU; the exchange runs over gloo because two RCCL
+    ranks cannot sit on one device (PINTRON_DIST_BACKEND, as in pintron_amd.multi)."""
+    import json
+    import sys
+    env = dict(os.environ, PINTRON_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "1", "--warmup", "1", "--ests", "6000", "--no-cpu"]
+    out = subprocess.run(cmd, cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "est-shard x2" and d["scaling"] == "weak"
+    assert d["config"]["ests_per_gpu"] == 6000 and d["value"] > 0
