@@ -144,7 +144,18 @@ static inline void efl_sort(ef_list* l, int (*cmp)(const void*, const void*)) {
   void** base = n <= 64 ? small : (void**)malloc(n * sizeof(void*));
   size_t i = 0;
   for (ef_node* x = l->sent.next; x != &l->sent; x = x->next) base[i++] = x->el;
-  qsort(base, n, sizeof(void*), cmp);
+  if (n <= 16) {
+    /* adjacency lists have a handful of elements: a stable insertion sort (the order glibc's
+     * merge-sort qsort gives) without the library call */
+    for (size_t a = 1; a < n; ++a) {
+      void* key = base[a];
+      size_t b = a;
+      while (b > 0 && cmp(&base[b - 1], &key) > 0) { base[b] = base[b - 1]; --b; }
+      base[b] = key;
+    }
+  } else {
+    qsort(base, n, sizeof(void*), cmp);
+  }
   i = 0;
   for (ef_node* x = l->sent.next; x != &l->sent; x = x->next) x->el = base[i++];
   if (base != small) free(base);

@@ -16,7 +16,7 @@ def snapshot():
             f = open("/proc/self/task/%s/stat" % tid).read()
             name = f[f.index("(") + 1:f.rindex(")")]
             rest = f[f.rindex(")") + 2:].split()
-            out[int(tid)] = (name, (int(rest[11]) + int(rest[12])) / os.sysconf("SC_CLK_TCK"))
+            out[int(tid)] = (name, (int(rest[11]) + int(rest[12])) / os.sysconf("SC_CLK_TCK"), int(rest[12]) / os.sysconf("SC_CLK_TCK"))
         except OSError:
             pass
     return out
@@ -26,8 +26,8 @@ seen = {}
 stop = False
 def sampler():
     while not stop:
-        for tid, (name, sec) in snapshot().items():
-            seen[tid] = (name, sec)
+        for tid, v in snapshot().items():
+            seen[tid] = v
         time.sleep(0.01)
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
@@ -42,17 +42,18 @@ for _ in range(steps):
 wall = time.perf_counter() - t0; cpu = time.process_time() - c0
 b = snapshot()
 stop = True; th.join()
-by_name = collections.defaultdict(lambda: [0, 0.0])
-for tid, (name, sec) in seen.items():
+by_name = collections.defaultdict(lambda: [0, 0.0, 0.0])
+for tid, (name, sec, sys_s) in seen.items():
     base = a[tid][1] if tid in a else 0.0
-    by_name[name][0] += 1; by_name[name][1] += sec - base
+    base_sys = a[tid][2] if tid in a else 0.0
+    by_name[name][0] += 1; by_name[name][1] += sec - base; by_name[name][2] += sys_s - base_sys
 print("sampled (10 ms; short-lived threads lose their last slice):")
-for name, (n, sec) in sorted(by_name.items(), key=lambda kv: -kv[1][1]):
+for name, (n, sec, sys_s) in sorted(by_name.items(), key=lambda kv: -kv[1][1]):
     if sec / steps > 0.002:
-        print("  %-16s %5d threads  %.3f s/step" % (name, n, sec / steps))
+        print("  %-16s %5d threads  %.3f s/step (of which %.3f in the kernel)" % (name, n, sec / steps, sys_s / steps))
 print("steps %d: wall %.3f s/step, process cpu %.3f s/step (%.1f cores busy)" % (steps, wall / steps, cpu / steps, cpu / wall))
-for tid, (name, sec) in sorted(b.items(), key=lambda kv: -kv[1][1]):
-    d = sec - a.get(tid, (name, 0.0))[1]
+for tid, (name, sec, _sys) in sorted(b.items(), key=lambda kv: -kv[1][1]):
+    d = sec - a.get(tid, (name, 0.0, 0.0))[1]
     if d > 0.005 * steps:
         print("  long-lived thread %-18s %s %.3f s/step" % (name, "(main)" if tid == os.getpid() else "(tid %d, not main)" % tid, d / steps))
 s.close(); shutil.rmtree(work, ignore_errors=True)
