@@ -889,9 +889,21 @@ int ef_session_write_outputs(ef_session* s) {
     started[k] = pthread_create(&th[k], NULL, file_writer_main, &fw[k]) == 0;
     if (!started[k]) file_writer_main(&fw[k]);
   }
+  /* PINTRON_RECORDS_FILE=<path>: the packed factorization records (include/pintron_records.h) too */
+  const char* rec_path = getenv("PINTRON_RECORDS_FILE");
+  int rec_rc = 0;
+  if (rec_path && rec_path[0]) {
+    FILE* rf = fopen(rec_path, "wb");
+    if (!rf) { fprintf(stderr, "* cannot write %s\n", rec_path); rec_rc = 1; }
+    else {
+      file_writer rw = { sh, rf, 6 };
+      file_writer_main(&rw);
+      if (fclose(rf) != 0) rec_rc = 1;
+    }
+  }
   for (int k = 0; k < 6; ++k) if (started[k]) pthread_join(th[k], NULL);
   ef_close_outputs(&out);
-  return 0;
+  return rec_rc;
 }
 
 /* text of output file `which` of the last step (0 raw-multifasta-out, 1 processed-ests, 2 megs,

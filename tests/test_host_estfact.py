@@ -127,6 +127,26 @@ def test_region_start_pairings_match_compiled_reference(bins, tmp_path):
     assert (my_dir / "raw-multifasta-out.txt").read_text().count(">/gb=T0") >= 30
 
 
+def test_packed_records_file_and_c_reader(bins, tmp_path):
+    """PINTRON_RECORDS_FILE: est-fact also leaves the packed factorization records; a C consumer of
+    include/pintron_records.h rebuilds raw-multifasta-out.txt from them byte for byte,
+    and reports a truncated blob."""
+    for f in ("genomic.txt", "ests.txt"):
+        shutil.copy(os.path.join(GOLD, f), tmp_path)
+    run(bins["estfact_sched_check"], tmp_path, {"PINTRON_THREADS": "2", "PINTRON_RECORDS_FILE": "records.bin"})
+    conv = os.path.join(HERE, "hostcheck", "records_to_text")
+    out = subprocess.run([conv, "records.bin", "processed-ests.txt", "genomic.txt"], cwd=tmp_path, capture_output=True, check=True)
+    assert out.stdout == (tmp_path / "raw-multifasta-out.txt").read_bytes()
+    assert out.stdout == open(os.path.join(GOLD, "expected-raw-multifasta-out.txt"), "rb").read()
+    blob = (tmp_path / "records.bin").read_bytes()
+    from pintron_amd.estfact import parse_factorization_records
+    recs = parse_factorization_records(blob)
+    assert len(recs) > 0 and all(facts for _, facts in recs)
+    (tmp_path / "cut.bin").write_bytes(blob[:-7])
+    bad = subprocess.run([conv, "cut.bin", "processed-ests.txt", "genomic.txt"], cwd=tmp_path, capture_output=True)
+    assert bad.returncode == 1
+
+
 def test_cli_options_and_config_dump(bins, tmp_path):
     for f in ("genomic.txt", "ests.txt"):
         shutil.copy(os.path.join(GOLD, f), tmp_path)
