@@ -113,12 +113,15 @@ struct AffixBest {          // running best cut of find_longest_affix
   __device__ __forceinline__ void consider(bool match, uint32_t cv, uint32_t ce, uint32_t cg) {
     const uint32_t cs = ce + cg;
     bool cand, less, equal;
+    if constexpr (SMALL) cand = match & (__umul24(200u, cv) <= __umul24(17u, cs));
+    else                 cand = match & (200ull * cv <= 17ull * cs);
+    // candidates are rare (a matching cell within 8.5 % of the diagonal sum): one scalar branch
+    // skips the comparison against the running best for the whole wave
+    if (!__builtin_amdgcn_ballot_w64(cand)) return;
     if constexpr (SMALL) {
-      cand = match & (__umul24(200u, cv) <= __umul24(17u, cs));
       const uint32_t lhs = __umul24(cv, s), rhs = __umul24(v, cs);
       less = lhs < rhs; equal = lhs == rhs;
     } else {
-      cand = match & (200ull * cv <= 17ull * cs);
       const uint64_t lhs = (uint64_t)cv * s, rhs = (uint64_t)v * cs;
       less = lhs < rhs; equal = lhs == rhs;
     }
