@@ -229,7 +229,9 @@ def main():
                                            "frac": ach_cells / peak_cells, "ops_per_cell_assumed": 6}
             out["kernels"] = [{"name": n, "ms_per_step": round(k["ms"], 3), "launches": round(k["launches"], 1),
                                "jobs": int(k["jobs"]),
-                               "algo_GBs": round(k["algo_bytes"] / (k["ms"] * 1e-3) / 1e9, 1) if k["ms"] and k["algo_bytes"] else None}
+                               "algo_GBs": round(k["algo_bytes"] / (k["ms"] * 1e-3) / 1e9, 1) if k["ms"] and k["algo_bytes"] else None,
+                               # cells (reference loop bounds) per second of this kernel's own stream time
+                               "Gcells_s": round(k["cells"] / (k["ms"] * 1e-3) / 1e9, 1) if k["ms"] and k["cells"] else None}
                               for n, k in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"])]
         if world == 1 and not args.no_cpu:
             # bounded sample of the same workload: reference CPU est-fact vs this code, byte for byte
