@@ -363,23 +363,31 @@ __device__ __forceinline__ void lev_wave_body(const DevJob& job, DevResult* res,
     }
     if (lane == 0) { pre[0] = 0; pre_pos[0] = 0; suf[0] = 0; suf_pos[0] = 0; }
     __syncthreads();
-    if (lane == 0) {                     // cut scan of src/refine.c:161-178 (<= len_p+1 steps)
+    // cut scan of src/refine.c:161-178: the first i in [lo, hi] with the smallest total, ties by the
+    // larger Burset frequency.  The lanes take i = lo + lane, lo + lane + 64, ... (each reads its four
+    // genomic characters at once instead of lane 0 walking <= len_p+1 dependent loads) and then agree.
+    {
       const uint32_t avail = len_t + min(job.tail, 2u);
-      const uint32_t lo = job.p0, hi = job.p1;
-      uint32_t off_p = lo, off_t1 = pre_pos[lo], off_t2 = suf_pos[len_p - lo];
-      uint32_t bestv = pre[lo] + suf[len_p - lo];
-      int best_freq = burset_adaptor(job.b, avail, off_t1, len_t - off_t2);
-      for (uint32_t i = lo + 1; i <= hi; ++i) {
+      const uint32_t lo = job.p0, hi = job.p1 > job.p0 ? job.p1 : job.p0;   // i = lo is always a candidate
+      uint32_t bi = 0xFFFFFFFFu, bc = 0xFFFFFFFFu; int bf = -1;
+      for (uint32_t i = lo + lane; i <= hi; i += 64) {
         const int freq = burset_adaptor(job.b, avail, pre_pos[i], len_t - suf_pos[len_p - i]);
         const uint32_t c = pre[i] + suf[len_p - i];
-        if (bestv > c || (bestv == c && freq > best_freq)) {
-          bestv = c; off_p = i; off_t1 = pre_pos[i]; off_t2 = suf_pos[len_p - i]; best_freq = freq;
-        }
+        if (bc > c || (bc == c && freq > bf)) { bc = c; bf = freq; bi = i; }
       }
-      res->status = 0;
-      res->v[0] = bestv <= max_errs ? 1 : 0;
-      res->v[1] = (int32_t)off_p; res->v[2] = (int32_t)off_t1;
-      res->v[3] = (int32_t)(len_t - off_t2); res->v[4] = (int32_t)bestv;
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) {
+        const uint32_t oc = __shfl_xor(bc, off), oi = __shfl_xor(bi, off);
+        const int of = __shfl_xor(bf, off);
+        if (oc < bc || (oc == bc && (of > bf || (of == bf && oi < bi)))) { bc = oc; bf = of; bi = oi; }
+      }
+      if (lane == 0) {
+        const uint32_t off_t1 = pre_pos[bi], off_t2 = suf_pos[len_p - bi];
+        res->status = 0;
+        res->v[0] = bc <= max_errs ? 1 : 0;
+        res->v[1] = (int32_t)bi; res->v[2] = (int32_t)off_t1;
+        res->v[3] = (int32_t)(len_t - off_t2); res->v[4] = (int32_t)bc;
+      }
     }
   } else if constexpr (MODE == MODE_KBAND) {
     // K_band_edit_distance (src/compute-alignments.c:319-453): early exits in the reference's
