@@ -271,6 +271,72 @@ enum { MODE_ED = 0, MODE_ALIGN = 1, MODE_BORDERS = 2, MODE_AFFIX = 3, MODE_KBAND
 // workspace starts with the two boundary rows (strip_bnd_bytes each), ALIGN directions follow,
 // one block of (columns + 64) * 64 * 16 bytes per strip.
 
+__device__ __forceinline__ uint32_t wave_shl1(uint32_t v) {
+  // DPP wave_shl:1 -- lane l receives lane l+1's v; lane 63 keeps its own (the caller masks it)
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x130, 0xf, 0xf, false);
+}
+
+// K_band_edit_distance (src/compute-alignments.c:375-443) with THE BAND ON THE LANES: lane s owns
+// slot s of the reference's 2k+1 wide row buffers, i.e. the diagonal column - row = s - k, and the
+// wave walks down the rows.  Cell (r, s) needs (r-1, s) [diagonal: the lane's own previous value],
+// (r-1, s+1) [up: the right neighbour's previous row] and (r, s-1) [left: the left neighbour's same
+// row], so lane s takes row r at time 2r + s: even lanes in the first half of an iteration, odd
+// lanes in the second, each reading its neighbours' latest value over DPP.  m + k iterations of two
+// single-cell half-steps instead of (n + 63) steps of R cells on the matrix sweep.  Needs 2k+1 <= 64.
+// A lane works on the rows whose column lies in 1..n; before its first row it holds the boundary
+// value next to it -- M[0][s-k] = s-k for the slots right of the main diagonal, M[k-s][0] = k-s for
+// those left of it -- which is what its right neighbour reads as "left" and itself as "diagonal"
+// on its first row.  Slot 0 has no left term and slot 2k no up term, as in the reference's loops.
+__device__ __noinline__ void kband_band_sweep(const uint8_t* __restrict__ lng, const uint32_t n,
+                                              const uint8_t* __restrict__ sht, const uint32_t m,
+                                              const uint32_t k, const uint32_t lane, DevResult* res) {
+  const uint32_t W = 2u * k + 1u;
+  const bool used = lane < W;
+  const bool odd = (lane & 1u) != 0u;
+  const int off = (int)lane - (int)k;            // column - row on this lane's diagonal
+  const uint32_t half = lane >> 1;               // iteration q works on row r = q - half
+  // neighbours that do not exist are pushed out of the minimum
+  const uint32_t up_mask = (lane + 1u < W) ? 0u : BAND_INF, left_mask = lane > 0u ? 0u : BAND_INF;
+  uint32_t val = (uint32_t)(off < 0 ? -off : off);
+  // rows of this lane: 1 <= r <= m with 1 <= off + r <= n
+  const uint32_t r_lo = off < 0 ? (uint32_t)(1 - off) : 1u;
+  const int hi_i = (int)n - off < (int)m ? (int)n - off : (int)m;
+  const uint32_t span = (used && hi_i >= (int)r_lo) ? (uint32_t)hi_i - r_lo : 0xFFFFFFFFu;   // r - r_lo <= span: active
+  const bool any_row = used && hi_i >= (int)r_lo;
+  const uint32_t nq = m + k;
+  // characters of the cell of iteration q (the loads run a group of four iterations ahead)
+  auto row_char = [&](uint32_t q) -> uint32_t {
+    const uint32_t r = q - half;
+    return (any_row && r - r_lo <= span) ? (uint32_t)sht[r - 1u] : 0u;
+  };
+  auto col_char = [&](uint32_t q) -> uint32_t {
+    const uint32_t r = q - half;
+    return (any_row && r - r_lo <= span) ? (uint32_t)lng[(uint32_t)(off + (int)r) - 1u] : 1u;
+  };
+  uint32_t a[4], b[4], an[4], bn[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { a[j] = row_char(1u + j); b[j] = col_char(1u + j); }
+  for (uint32_t q0 = 1; q0 <= nq; q0 += 4) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { an[j] = row_char(q0 + 4u + j); bn[j] = col_char(q0 + 4u + j); }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t r = q0 + j - half;          // wraps for the lanes whose first row lies ahead
+      const bool active = any_row && (r - r_lo <= span);
+      const uint32_t mism = a[j] != b[j] ? 1u : 0u;
+#pragma unroll
+      for (int par = 0; par < 2; ++par) {
+        const uint32_t upv = wave_shl1(val) | up_mask, leftv = wave_shr1(val) | left_mask;
+        const uint32_t nv = min(val + mism, min(upv, leftv) + 1u);
+        val = (active && odd == (par == 1)) ? nv : val;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { a[j] = an[j]; b[j] = bn[j]; }
+  }
+  if (lane == n + k - m) { res->status = 0; res->v[1] = (int32_t)val; res->v[0] = val <= k ? 1 : 0; }
+}
+
 template <int R, int MODE, bool STRIPS = false>
 __device__ __forceinline__ void lev_wave_body(const DevJob& job, DevResult* res, uint8_t* __restrict__ ws,
                                               const uint32_t lane) {
@@ -409,6 +475,7 @@ __device__ __forceinline__ void lev_wave_body(const DevJob& job, DevResult* res,
       return;
     }
     const bool banded = !(2ull * ub + 1 >= n);
+    if (banded && 2u * ub + 1u <= 64u) { kband_band_sweep(lng, n, sht, m, ub, lane, res); return; }
     const Operand rows{sht, 0, false}, cols{lng, 0, false};
     if constexpr (STRIPS) {
       constexpr uint32_t SR = 64u * R;

@@ -196,3 +196,30 @@ def test_properties_at_full_size(gpu_ctx, O):
         jl.add(capi.ALIGN, a, a)
     for o, (a, _, _) in zip(capi.run_jobs(gpu_ctx, jl), meta):
         assert o["score"] == 0 and o["ea"] == a and o["ga"] == a
+
+
+def test_kband_band_on_lanes(gpu_ctx, O):
+    """K-band distances whose band fits a wave (2k+1 <= 64) run with the band on the lanes: every k
+    up to 31 (and 32, the first that does not fit), length differences 0..k in both argument orders,
+    short and long strings, error rates below and above the bound, wildcard characters (which are
+    NOT wildcards here)."""
+    rng = random.Random(77)
+    cases = []
+    for k in (1, 2, 3, 5, 9, 15, 16, 30, 31, 32):
+        for n in (2 * k + 2, 2 * k + 3, 3 * k + 7, 64, 65, 129, 300, 700, 1500):
+            if 2 * k + 1 >= n:
+                continue
+            for rate in (0.0, 0.01, 0.04, 0.12):
+                a = D.rand_seq(rng, n, rng.choice([0.0, 0.01]))
+                b = D.mutate(rng, a, rate)
+                d = rng.randint(0, k)                         # force a length difference of up to k
+                if len(b) > d and rng.random() < 0.5:
+                    b = b[: len(b) - d] if rng.random() < 0.5 else b[d:]
+                cases.append(D.Case(D.KBAND, a, b, p0=k))
+                cases.append(D.Case(D.KBAND, b, a, p0=k))
+    a = D.rand_seq(rng, 400)
+    cases.append(D.Case(D.KBAND, a, a[:395] + b"TTTTT", p0=7))
+    cases.append(D.Case(D.KBAND, a, a[7:], p0=7))              # the result sits on the last slot of the band
+    cases.append(D.Case(D.KBAND, a[7:], a, p0=7))
+    cases.append(D.Case(D.KBAND, a, D.rand_seq(rng, 400), p0=20))   # unrelated: far above the bound
+    run_and_check(gpu_ctx, O, cases)
