@@ -545,15 +545,18 @@ extern "C" int pgpu_dp_plan_launch(pgpu_ctx* ctx, pgpu_dp_plan* p) {
       const int n = (int)g.count;
       // HIP spreads its streams over four hardware queues, and what shares a queue runs one after
       // the other.  Packed: four streams (one per queue), the families dealt out so that the four
-      // sums of typical durations come out even (affix 190+19 | borders 175+27 + ed 22 | align 157 +
-      // lcf 93 | gap 135 + kband 100 us on C3); otherwise round-robin in launch order.
+      // sums of typical durations come out even (on C3, us per launch: affix_coop 190 + single-wave
+      // BORDERS 27 | borders_coop 175 + ED 22 + single-wave AFFIX 19 | ALIGN 157 + KBAND 55 | GAP 135 +
+      // LCF 98); otherwise round-robin in launch order.
       int lane_of = slot % ctx->n_aux;
       if (ctx->packed) {
+        const bool one_wave = g.R == 1;          // BORDERS / AFFIX with up to 64 rows
         switch (g.family) {
-          case KF_AFFIX: lane_of = 0; break;
-          case KF_BORDERS: case KF_ED: lane_of = 1; break;
-          case KF_ALIGN: case KF_LCF: lane_of = 2; break;
-          default: lane_of = 3; break;
+          case KF_AFFIX:   lane_of = one_wave ? 1 : 0; break;
+          case KF_BORDERS: lane_of = one_wave ? 0 : 1; break;
+          case KF_ED:      lane_of = 1; break;
+          case KF_ALIGN: case KF_KBAND: lane_of = 2; break;
+          default: lane_of = 3; break;           // GAP, LCF
         }
         used_mask |= 1u << lane_of;
       }
