@@ -324,7 +324,9 @@ extern "C" int pgpu_dp_plan_create_parts(pgpu_ctx* ctx, const pgpu_index* idx, c
       case PGPU_DP_BORDERS:
         if (la > PGPU_MAX_ROWS_BORDERS || lb > PGPU_MAX_COLS) continue;
         if (in.p0 > in.p1 || in.p1 > la) { pre.status = PGPU_EINVAL; continue; }
-        k.family = KF_BORDERS; k.R = row_class(la); k.size = (uint64_t)la * lb; break;
+        // cells as the reference bounds them: two matrices of len_p x t_win, t_win = min(len_p + max_errs, len_t)
+        // (src/refine.c:117-121); the gap of check_gap_errors is a whole intron, the window a few dozen columns
+        k.family = KF_BORDERS; k.R = row_class(la); k.size = (uint64_t)la * std::min<uint64_t>((uint64_t)la + in.p2, lb); break;
       case PGPU_DP_AFFIX:
         if (la > PGPU_MAX_ROWS_LEV || lb > PGPU_MAX_COLS) continue;
         k.family = KF_AFFIX; k.R = row_class(la); k.size = (uint64_t)la * lb; break;
@@ -400,7 +402,8 @@ extern "C" int pgpu_dp_plan_create_parts(pgpu_ctx* ctx, const pgpu_index* idx, c
       g.cells += (k.family == KF_GAP ? 3 : (k.family == KF_BORDERS ? 2 : 1)) * cells_of(k);
       // algorithmic HBM bytes: operands once; 1 B/cell of directions for
       // ALIGN, 3 B/cell for GAP; 8 B per row when row minima are produced
-      g.algo_bytes += la + lb;
+      // (BORDERS touches the first and the last t_win characters of t only)
+      g.algo_bytes += la + (k.family == KF_BORDERS ? std::min<uint64_t>(lb, 2 * std::min<uint64_t>(la + k.j.p2, lb)) : lb);
       g.max_rows = std::max(g.max_rows, (uint32_t)la);
       if (k.R >= (k.family == KF_GAP ? 8u : 32u)) ++g.n_big;
       if (k.family == KF_ALIGN) g.algo_bytes += la * lb + 3 * (la + lb);     // + directions read back, two strings
