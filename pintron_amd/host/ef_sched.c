@@ -79,6 +79,17 @@ static void ctx_make(ef_ctx* c, char* stack, size_t size, void (*fn)(void*), voi
   makecontext(&c->uc, (void (*)(void))ctx_tramp, 4, (unsigned)(f >> 32), (unsigned)(f & 0xffffffffu), (unsigned)(a >> 32), (unsigned)(a & 0xffffffffu));
 }
 #endif
+/* ThreadSanitizer has to be told about the switches (tools/tsan_hostcheck.py); nothing of this is
+ * compiled otherwise */
+#if defined(__SANITIZE_THREAD__)
+void* __tsan_get_current_fiber(void);
+void* __tsan_create_fiber(unsigned flags);
+void __tsan_destroy_fiber(void* fiber);
+void __tsan_switch_to_fiber(void* fiber, unsigned flags);
+#define EF_TSAN 1
+#else
+#define EF_TSAN 0
+#endif
 #include <unistd.h>
 
 #include "estfact.h"
@@ -87,6 +98,12 @@ static void ctx_make(ef_ctx* c, char* stack, size_t size, void (*fn)(void*), voi
 
 enum { F_RUNNABLE, F_WAIT_DP, F_WAIT_PAIR, F_DONE };
 
+#if EF_TSAN
+static inline void tsan_to(void* fiber) { __tsan_switch_to_fiber(fiber, 0); }
+#else
+static inline void tsan_to(void* fiber) { (void)fiber; }
+#endif
+
 static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 
 struct worker;
@@ -94,6 +111,7 @@ struct worker;
 
 typedef struct fiber {
   ef_ctx ctx;
+  void* tsan;                /* ThreadSanitizer's handle of this fibre (EF_TSAN builds) */
   char* stack;
   struct worker* w;
   int state;
@@ -203,6 +221,7 @@ typedef struct lane {
 typedef struct worker {
   shared* sh;
   ef_ctx sched;
+  void* tsan_sched;          /* the worker thread's own context, for ThreadSanitizer */
   fiber* free_fibers;
   out_chunk* chunk;                      /* current output chunk of this worker */
   lane lanes[MAX_LANES];
@@ -225,6 +244,7 @@ static int fiber_dp_many(void* self, const ef_dp_req* reqs, ef_dp_res* res, size
   fiber* f = (fiber*)self;
   if (n == 0) return 0;
   f->reqs = reqs; f->ress = res; f->nreq = n; f->state = F_WAIT_DP;
+  if (EF_TSAN) tsan_to(f->w->tsan_sched);
   ctx_switch(&f->ctx, &f->w->sched);
   return f->rc;
 }
@@ -251,6 +271,7 @@ static int fiber_pairings(void* self, const char* pattern, size_t m, unsigned L,
   }
   f->pat = pattern; f->pat_len = m; f->pat_L = L; f->pat_rate = rate; f->pat_out = out; f->pat_n = n;
   f->state = F_WAIT_PAIR;
+  if (EF_TSAN) tsan_to(f->w->tsan_sched);
   ctx_switch(&f->ctx, &f->w->sched);
   return f->rc;
 }
@@ -305,6 +326,7 @@ static void fiber_main(void* arg) {
     if (fs[k].len) memcpy(u->buf[k], fs[k].mem, fs[k].len);
   }
   f->state = F_DONE;
+  if (EF_TSAN) tsan_to(f->w->tsan_sched);
   ctx_switch(&f->ctx, &f->w->sched);
 }
 
@@ -326,10 +348,11 @@ static bool start_fiber(worker* w, int li) {
   if (u == (size_t)-1) return false;
   if (f) {                       /* recycled: keep the stack and the sink blocks */
     char* st = f->stack;
+    void* ts = f->tsan;
     ef_sink keep[EF_N_OUT];
     memcpy(keep, f->out, sizeof keep);
     memset(f, 0, sizeof(fiber));
-    f->stack = st;
+    f->stack = st; f->tsan = ts;
     memcpy(f->out, keep, sizeof keep);
   }
   else { f = (fiber*)calloc(1, sizeof(fiber)); f->stack = (char*)malloc(sh->stack_size); }
@@ -338,6 +361,11 @@ static bool start_fiber(worker* w, int li) {
   /* the stacks are plain heap blocks (no guard page): a sentinel at the low end tells an
    * overflow apart from everything else when the fibre is done */
   memcpy(f->stack, FIBER_SENTINEL, sizeof FIBER_SENTINEL);
+#if EF_TSAN
+  if (f->tsan) __tsan_destroy_fiber(f->tsan);
+  f->tsan = __tsan_create_fiber(0);
+  w->tsan_sched = __tsan_get_current_fiber();
+#endif
   ctx_make(&f->ctx, f->stack, sh->stack_size, fiber_main, f);
   ln->fibers[ln->n_fibers++] = f;
   return true;
@@ -460,7 +488,8 @@ static void* service_main(void* arg) {
     if (rc != PGPU_OK) fprintf(stderr, "* FATAL DP batch failed: %s\n", pgpu_last_error(me->ctx));
     me->stats.dp_batches++; me->stats.dp_jobs += nj;
     pthread_mutex_lock(&sv->mu);
-    for (dp_request* r = list; r;) { dp_request* nx = r->next; r->batch = mb; r->rc = rc; r->done = true; r = nx; }
+    /* `done` is also polled without the mutex by the poster's lane choice: release store */
+    for (dp_request* r = list; r;) { dp_request* nx = r->next; r->batch = mb; r->rc = rc; __atomic_store_n(&r->done, true, __ATOMIC_RELEASE); r = nx; }
     pthread_cond_broadcast(&sv->finished);
     pthread_mutex_unlock(&sv->mu);
   }
@@ -567,7 +596,7 @@ static void* worker_main(void* arg) {
       t0 = now_s();
       for (size_t i = 0; i < ln->n_fibers; ++i) {
         fiber* f = ln->fibers[i];
-        if (f->state == F_RUNNABLE) ctx_switch(&w->sched, &f->ctx);
+        if (f->state == F_RUNNABLE) { if (EF_TSAN) tsan_to(f->tsan); ctx_switch(&w->sched, &f->ctx); }
       }
       size_t keep = 0;
       for (size_t i = 0; i < ln->n_fibers; ++i) {

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""CPU only: the fibre scheduler under ThreadSanitizer.
+
+Builds the product's main + scheduler + backend code over the CPU stand-in of the C-ABI
+(tests/hostcheck/fake_pgpu.c) with -fsanitize=thread; ef_sched.c announces its fibre switches to
+the sanitizer in such builds (EF_TSAN).  Runs test-AMBN, a C3 and a C2 sample and the edge cases with
+4 workers x 4 lanes, 3 GPU service threads, prefetch on: worker <-> service <-> prefetch hand-offs,
+the shared fibre pool, the unit queue and the output chunks are all exercised.  Any report is an
+error; outputs are compared with the plain check build's."""
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from pintron_amd import synth  # noqa: E402
+
+H, O, T = (os.path.join(ROOT, p) for p in ("pintron_amd/host", "oracle", "tests/hostcheck"))
+OUT = os.path.join(ROOT, "gpurun_out", "scratch", "tsan")
+shutil.rmtree(OUT, ignore_errors=True)
+os.makedirs(OUT)
+host = [os.path.join(H, f) for f in ("ef_io.c", "ef_meg.c", "ef_config.c", "ef_fact.c", "ef_refine_intron.c",
+                                      "ef_factref.c", "ef_classify.c", "ef_estfact.c")]
+orc = [os.path.join(O, f) for f in ("pairing_oracle.c", "dp_oracle.c", "dp_oracle_batch.c")]
+exe = os.path.join(OUT, "estfact_sched_tsan")
+subprocess.run(["gcc", "-std=gnu99", "-O1", "-g", "-fsanitize=thread", "-fno-omit-frame-pointer", "-pthread", "-o", exe,
+                os.path.join(H, "est_fact_main.c"), os.path.join(H, "ef_gpu_backend.c"), os.path.join(H, "ef_sched.c")]
+               + host + [os.path.join(T, "fake_pgpu.c")] + orc + ["-lm"], check=True, cwd=T)
+subprocess.run(["make", "-s", "-C", T, "estfact_sched_check"], check=True)
+plain = os.path.join(T, "estfact_sched_check")
+
+cases = {"edge": synth.make_edge_cases()}
+for cfg, n in (("C2", 200), ("C3", 300)):
+    w = synth.make(cfg, n_est=n)
+    cases[cfg.lower()] = (w.genomic_fasta(), w.ests_fasta())
+gold = os.path.join(ROOT, "tests", "golden")
+cases["ambn"] = (open(gold + "/ambn/genomic.txt").read(), open(gold + "/ambn/ests.txt").read())
+env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0:second_deadlock_stack=1", PINTRON_THREADS="4", PINTRON_LANES="4",
+           PINTRON_FIBERS="12", PINTRON_SERVICES="3", PINTRON_CLEAN_EXIT="1")
+failed = 0
+for name, (g, e) in cases.items():
+    outs = {}
+    for tag, prog in (("tsan", exe), ("plain", plain)):
+        d = os.path.join(OUT, name + "_" + tag)
+        os.makedirs(d)
+        open(d + "/genomic.txt", "w").write(g)
+        open(d + "/ests.txt", "w").write(e)
+        r = subprocess.run([prog], cwd=d, env=env, capture_output=True, text=True, errors="replace")
+        bad = [ln for ln in r.stderr.splitlines() if "ThreadSanitizer" in ln]
+        outs[tag] = open(d + "/raw-multifasta-out.txt", "rb").read() if os.path.exists(d + "/raw-multifasta-out.txt") else None
+        print("%-6s %-5s rc %d, sanitizer reports %d" % (name, tag, r.returncode, len(bad)))
+        if bad:
+            print("\n".join(r.stderr.splitlines()[:40]))
+        failed += r.returncode != 0 or bool(bad)
+    failed += outs["tsan"] != outs["plain"]
+sys.exit(1 if failed else 0)
