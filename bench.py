@@ -121,7 +121,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--ests", type=int, default=N_EST_BATCH, help="ESTs per GPU per step (default: C3)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / parity leg")
     args = ap.parse_args()
