@@ -44,6 +44,11 @@ int pgpu_abi_version(void);
 /* HIP-event timing of every kernel group of the plans created afterwards (off by default; the
  * measurement hooks below return 0 without it) */
 int pgpu_set_timing(pgpu_ctx* ctx, int enabled);
+/* NUMA node of the host the context's GPU hangs off (its PCI device's numa_node), or -1 when the
+ * platform does not say.  The est-fact host binds its threads to that node: on a two-socket host
+ * that alone is worth 10-14 % (the per-EST logic is memory-latency bound and the batches cross
+ * PCIe on that socket). */
+int pgpu_device_numa_node(pgpu_ctx* ctx);
 
 /* ------------------------------------------------------------------------------------------ */
 /* genomic index -- replaces lst_stree_new (stree_src/lst_stree.c:816) + preprocess_text /     */

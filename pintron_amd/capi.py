@@ -42,7 +42,7 @@ assert C.sizeof(DpJob) == 48 and C.sizeof(DpResult) == 48
 
 # every symbol include/pintron_gpu.h declares
 EXPORTS = [
-    "pgpu_init", "pgpu_destroy", "pgpu_last_error", "pgpu_abi_version", "pgpu_set_timing",
+    "pgpu_init", "pgpu_destroy", "pgpu_last_error", "pgpu_abi_version", "pgpu_set_timing", "pgpu_device_numa_node",
     "pgpu_index_build", "pgpu_index_destroy", "pgpu_index_suffix_array", "pgpu_pairings",
     "pgpu_pairing_plan_create", "pgpu_pairing_plan_run", "pgpu_pairing_plan_count",
     "pgpu_pairing_plan_positions", "pgpu_pairing_plan_kernel_ms", "pgpu_pairing_plan_fetch",

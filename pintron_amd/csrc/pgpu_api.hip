@@ -100,6 +100,21 @@ void* pgpu_ctx_pool_get(pgpu_ctx* ctx, int pool, int slot, size_t bytes) {
 }
 bool pgpu_ctx_timing(const pgpu_ctx* ctx) { return ctx->timing; }
 
+extern "C" int pgpu_device_numa_node(pgpu_ctx* ctx) {
+  if (!ctx) return -1;
+  char bdf[64] = {0};
+  if (hipDeviceGetPCIBusId(bdf, (int)sizeof bdf - 1, ctx->device) != hipSuccess) return -1;
+  for (char* c = bdf; *c; ++c) if (*c >= 'A' && *c <= 'F') *c = (char)(*c - 'A' + 'a');   // sysfs spells it in lower case
+  char path[160];
+  snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bdf);
+  FILE* f = fopen(path, "r");
+  if (!f) return -1;
+  int node = -1;
+  if (fscanf(f, "%d", &node) != 1) node = -1;
+  fclose(f);
+  return node;
+}
+
 extern "C" int pgpu_set_timing(pgpu_ctx* ctx, int enabled) {
   if (!ctx) return PGPU_EINVAL;
   ctx->timing = enabled != 0;

@@ -24,6 +24,7 @@
 #include <malloc.h>
 #include <pthread.h>
 #include <sched.h>
+#include <dirent.h>
 #include <time.h>
 #include <stdlib.h>
 #include <string.h>
@@ -681,6 +682,62 @@ static size_t host_core_share(void) {
   return n > 0 ? (size_t)n : 1;
 }
 
+/* All threads of the step on the socket the GPU hangs off.  On the two-socket hosts of the GPU boxes
+ * the unbound program ran 4-14 % slower (threads and their memory spread over both sockets; the
+ * per-EST logic is bound by memory latency): the calling thread's affinity is cut down to the CPUs
+ * of the GPU's NUMA node, and every thread created from here on inherits it -- the HIP runtime's
+ * helpers included, which is why a first guess is made from sysfs before the runtime is up (the
+ * dev-th render node under /dev/dri) and corrected by the library's answer afterwards.
+ * PINTRON_NUMA=0 leaves the affinity alone, PINTRON_NUMA_NODE=<n> names the node. */
+static cpu_set_t numa_original;            /* the affinity the process came with */
+static int numa_bound = -2;                /* node the calling thread is bound to; -2: untouched */
+
+static int guess_gpu_numa_node(int dev) {
+  int minors[64], n = 0;
+  DIR* d = opendir("/dev/dri");
+  if (!d) return -1;
+  for (struct dirent* e; (e = readdir(d)) != NULL && n < 64;)
+    if (strncmp(e->d_name, "renderD", 7) == 0) minors[n++] = atoi(e->d_name + 7);
+  closedir(d);
+  for (int i = 1; i < n; ++i) for (int j = i; j > 0 && minors[j - 1] > minors[j]; --j) { const int t = minors[j]; minors[j] = minors[j - 1]; minors[j - 1] = t; }
+  if (dev < 0 || dev >= n) return -1;
+  char path[96];
+  snprintf(path, sizeof path, "/sys/class/drm/renderD%d/device/numa_node", minors[dev]);
+  FILE* f = fopen(path, "r");
+  if (!f) return -1;
+  int node = -1;
+  if (fscanf(f, "%d", &node) != 1) node = -1;
+  fclose(f);
+  return node;
+}
+
+static void bind_to_numa_node(int node) {
+  const char* sw = getenv("PINTRON_NUMA");
+  if (sw && sw[0] == '0' && sw[1] == '\0') return;
+  const char* forced = getenv("PINTRON_NUMA_NODE");
+  if (forced && forced[0]) node = atoi(forced);
+  if (node < 0 || node == numa_bound) return;
+  if (numa_bound == -2 && sched_getaffinity(0, sizeof numa_original, &numa_original) != 0) return;
+  char path[96];
+  snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+  FILE* f = fopen(path, "r");
+  if (!f) return;
+  cpu_set_t want;
+  CPU_ZERO(&want);
+  int lo, hi, n = 0;                         /* "a-b,c,d-e" */
+  for (;;) {
+    if (fscanf(f, "%d", &lo) != 1) break;
+    hi = lo;
+    int ch = fgetc(f);
+    if (ch == '-') { if (fscanf(f, "%d", &hi) != 1) break; ch = fgetc(f); }
+    for (int c = lo; c <= hi && c < CPU_SETSIZE; ++c) if (CPU_ISSET(c, &numa_original)) { CPU_SET(c, &want); ++n; }
+    if (ch != ',') break;
+  }
+  fclose(f);
+  if (numa_bound == -2) numa_bound = -1;
+  if (n >= 2 && sched_setaffinity(0, sizeof want, &want) == 0) numa_bound = node;
+}
+
 /* ---- sessions: inputs + index + patterns resident; a step = the whole per-EST pipeline ------------ */
 struct ef_session {
   ef_inputs in;
@@ -713,6 +770,7 @@ ef_session* ef_session_open(int argc, char** argv) {
    * the arenas from returning memory to the system and asking for it again between ESTs */
   mallopt(M_TRIM_THRESHOLD, 512 << 20);
   mallopt(M_TOP_PAD, 16 << 20);
+  bind_to_numa_node(guess_gpu_numa_node(ef_gpu_device_from_env()));   /* before the runtime starts its threads */
   ef_session* s = (ef_session*)calloc(1, sizeof(ef_session));
   int load_rc = ef_load_genomic(argc, argv, &s->in);
   if (load_rc != 0) { free(s); return NULL; }
@@ -729,6 +787,7 @@ ef_session* ef_session_open(int argc, char** argv) {
     free(s); return NULL;
   }
   s->ctx0 = boot.ctx;
+  bind_to_numa_node(pgpu_device_numa_node(s->ctx0));   /* the library's word on the first guess */
   ef_inputs* in = &s->in;
   shared* sh = &s->sh;
   sh->in = in;

@@ -192,6 +192,7 @@ int pgpu_dp_batch(pgpu_ctx* ctx, const pgpu_index* idx, const pgpu_dp_job* jobs,
 }
 
 int pgpu_set_timing(pgpu_ctx* ctx, int enabled) { (void)ctx; (void)enabled; return PGPU_OK; }
+int pgpu_device_numa_node(pgpu_ctx* ctx) { (void)ctx; return -1; }
 int pgpu_dp_plan_n_groups(const pgpu_dp_plan* p) { (void)p; return 0; }
 int pgpu_dp_plan_group_info(const pgpu_dp_plan* p, int i, pgpu_group_info* out) { (void)p; (void)i; (void)out; return PGPU_EINVAL; }
 double pgpu_pairing_plan_kernel_ms(const pgpu_pairing_plan* p, int k) { (void)p; (void)k; return 0.0; }
