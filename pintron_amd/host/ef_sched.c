@@ -724,13 +724,28 @@ static void bind_to_numa_node(int node) {
   if (!f) return;
   cpu_set_t want;
   CPU_ZERO(&want);
+  const char* lws = getenv("LOCAL_WORLD_SIZE");
+  const bool several_ranks = lws && atoi(lws) > 1;
   int lo, hi, n = 0;                         /* "a-b,c,d-e" */
   for (;;) {
     if (fscanf(f, "%d", &lo) != 1) break;
     hi = lo;
     int ch = fgetc(f);
     if (ch == '-') { if (fscanf(f, "%d", &hi) != 1) break; ch = fgetc(f); }
-    for (int c = lo; c <= hi && c < CPU_SETSIZE; ++c) if (CPU_ISSET(c, &numa_original)) { CPU_SET(c, &want); ++n; }
+    for (int c = lo; c <= hi && c < CPU_SETSIZE; ++c) {
+      if (!CPU_ISSET(c, &numa_original)) continue;
+      /* one hardware thread per core (the first of its siblings): the workers are compute-bound
+       * and hide latency with lanes, two of them on one core only share its pipelines.  Not when
+       * several ranks share the node: their threads need the siblings too. */
+      if (several_ranks) { CPU_SET(c, &want); ++n; continue; }
+      char sp[112];
+      snprintf(sp, sizeof sp, "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", c);
+      FILE* sf = fopen(sp, "r");
+      int first = c;
+      if (sf) { if (fscanf(sf, "%d", &first) != 1) first = c; fclose(sf); }
+      if (first != c && CPU_ISSET(first, &numa_original)) continue;
+      CPU_SET(c, &want); ++n;
+    }
     if (ch != ',') break;
   }
   fclose(f);
