@@ -14,7 +14,7 @@ Not in the step: reading genomic.txt/ests.txt, strand/polyA preparation, index c
 once, reported as load_s / index_s), writing the files.
 
 The output of the timed steps is checked: a bounded sample of the same workload is run through the
-reference CPU est-fact (oracle/_ref/est-fact-ref, the cpu_baseline) and through this code, and the
+reference CPU est-fact (oracle/_ref/est-fact-core, the cpu_baseline) and through this code, and the
 two raw-multifasta-out.txt must be byte-identical.
 
 Contract: python bench.py --gpus N --steps K --warmup W ; one JSON line on rank 0.
@@ -71,7 +71,7 @@ def pmc_traffic(group_name):
 
 def cpu_reference(sample_dir):
     """Reference CPU est-fact (oracle/_ref, compiled from /root/reference) on the sample, one core."""
-    exe = os.path.join(ROOT, "oracle", "_ref", "est-fact-ref")
+    exe = os.path.join(ROOT, "oracle", "_ref", "est-fact-core")
     if not os.path.exists(exe):
         return None
     t0 = time.perf_counter()
@@ -102,7 +102,7 @@ def cpu_reference_all_cores(n_proc, base_seed):
     """The embarrassingly parallel CPU figure: one reference est-fact process per
     usable core, each on its own seeded C3 sample of CPU_SAMPLE ESTs, all started together."""
     from pintron_amd import synth
-    exe = os.path.join(ROOT, "oracle", "_ref", "est-fact-ref")
+    exe = os.path.join(ROOT, "oracle", "_ref", "est-fact-core")
     dirs = []
     for k in range(n_proc):
         d = tempfile.mkdtemp(prefix="pintron_bench_refN_")
@@ -250,7 +250,7 @@ def main():
                 if got != ref:
                     raise SystemExit("bench: GPU est-fact output differs from the reference CPU est-fact on the sample")
                 out["cpu_baseline"] = {"value": CPU_SAMPLE / cpu_s, "unit": "ESTs/s", "cores": 1, "kind": "reference",
-                                       "sample": "first-seed C3 sample of %d ESTs through oracle/_ref/est-fact-ref "
+                                       "sample": "first-seed C3 sample of %d ESTs through oracle/_ref/est-fact-core "
                                                  "(%.1f s); output byte-identical to this code's" % (CPU_SAMPLE, cpu_s)}
                 n_proc = usable_cores()
                 wall_all = cpu_reference_all_cores(n_proc, synth.CONFIGS["C3"]["seed"]) if n_proc > 1 else None

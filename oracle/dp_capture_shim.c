@@ -1,11 +1,11 @@
 /*
  * TEST INFRASTRUCTURE ONLY (oracle/): LD_PRELOAD interposer for the reference est-fact.
  *
- * Records every call the *unmodified* reference (oracle/_ref/est-fact-ref) makes to its exported
+ * Records every call the *unmodified* reference (oracle/_ref/est-fact-core) makes to its exported
  * DP routines -- inputs and outputs -- as JSON lines in $PINTRON_DP_CAPTURE.  Used by
  * tools/make_golden.py to produce tests/golden/dp_calls_*.jsonl and the DP job census.
  * The reference sources are not touched: the calls are intercepted at the dynamic-linker level
- * (the routines are default-visibility symbols of libpintron_ref.so reached through the PLT).
+ * (the routines are default-visibility symbols of libpintron_ref_core.so reached through the PLT).
  *
  * Interposed: compute_alignment (src/compute-alignments.c:39), compute_gap_alignment
  * (src/refine-intron.c:560), edit_distance (src/refine.c:50), compute_edit_distance

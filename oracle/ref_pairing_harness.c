@@ -1,6 +1,6 @@
 /*
  * TEST INFRASTRUCTURE ONLY (oracle/): calls the reference's own index construction and
- * build_vertex_set (src/max-emb-graph.c:218) from libpintron_ref.so and flattens the vertex set,
+ * build_vertex_set (src/max-emb-graph.c:218) from libpintron_ref_core.so and flattens the vertex set,
  * so the pairing oracle and the HIP pairing kernel can be compared with the reference per EST.
  * The call sequence is the one of src/main-est-fact.c:224-239 and src/compute-est-fact.c:101-107.
  */
@@ -15,7 +15,15 @@
 #include "aug_suffix_tree.h"
 #include "max-emb-graph.h"
 
-pconfiguration ref_default_config(void);   /* ref_config_glue.c */
+/* build_vertex_set and stree_preprocess take a `pconfiguration`; the harness owns a plain
+ * struct _configuration (include/configuration.h:39-135) and sets the fields they read:
+ * min_factor_len and min_string_depth_rate (src/max-emb-graph.c:273-274, src/aug_suffix_tree.c:247). */
+static pconfiguration harness_config(void) {
+  pconfiguration c = (pconfiguration)calloc(1, sizeof(struct _configuration));
+  c->min_factor_len = 15;            /* src/options.ggo:94-101 */
+  c->min_string_depth_rate = 0.2;    /* :124-137 */
+  return c;
+}
 
 typedef struct {
   pEST_info gen;
@@ -29,7 +37,7 @@ void* ref_index_create(const char* genomic) {
   ix->gen = EST_info_create();
   ix->gen->EST_seq = alloc_and_copy(genomic);
   ix->gen->EST_id = alloc_and_copy(">harness");
-  ix->cfg = ref_default_config();
+  ix->cfg = harness_config();
   LST_StringSet* set = lst_stringset_new();
   LST_String* lst = PALLOC(LST_String);
   lst_string_init(lst, ix->gen->EST_seq, sizeof(char), strlen(ix->gen->EST_seq));
@@ -49,10 +57,10 @@ long ref_build_pairings(void* index, const char* est_seq, unsigned min_factor_le
   pEST_info est = EST_info_create();
   est->EST_seq = alloc_and_copy(est_seq);
   est->EST_id = alloc_and_copy(">est");
-  pconfiguration cfg = config_clone(ix->cfg);
-  cfg->min_factor_len = min_factor_len;
-  cfg->min_string_depth_rate = min_string_depth_rate;
-  pext_array V = build_vertex_set(est, ix->tree, ix->pg, cfg);
+  struct _configuration cfg = *ix->cfg;
+  cfg.min_factor_len = min_factor_len;
+  cfg.min_string_depth_rate = min_string_depth_rate;
+  pext_array V = build_vertex_set(est, ix->tree, ix->pg, &cfg);
   long n = 0;
   const size_t sz = EA_size(V);
   for (size_t i = 1; i + 1 < sz; ++i) {
@@ -65,6 +73,5 @@ long ref_build_pairings(void* index, const char* est_seq, unsigned min_factor_le
     }
     listit_destroy(it);
   }
-  config_destroy(cfg);
   return n;
 }

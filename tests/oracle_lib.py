@@ -127,7 +127,7 @@ def longest_affix(est: bytes, gen: bytes):
 # ---- compiled reference (only where oracle/_ref has been built) ----------------------------
 
 def have_ref() -> bool:
-    return os.path.exists(os.path.join(REF_DIR, "libpintron_ref.so"))
+    return os.path.exists(os.path.join(REF_DIR, "libpintron_ref_core.so"))
 
 
 _ref = None
@@ -137,7 +137,7 @@ _ref_static = None
 def ref():
     global _ref
     if _ref is None:
-        _ref = C.CDLL(os.path.join(REF_DIR, "libpintron_ref.so"), mode=C.RTLD_GLOBAL)
+        _ref = C.CDLL(os.path.join(REF_DIR, "libpintron_ref_core.so"), mode=C.RTLD_GLOBAL)
     return _ref
 
 
@@ -145,5 +145,5 @@ def ref_static():
     global _ref_static
     if _ref_static is None:
         ref()
-        _ref_static = C.CDLL(os.path.join(REF_DIR, "libref_static.so"))
+        _ref_static = C.CDLL(os.path.join(REF_DIR, "libref_harness.so"))
     return _ref_static

@@ -63,7 +63,7 @@ class RefIndex:
     """The reference's own suffix tree + build_vertex_set (oracle/ref_pairing_harness.c)."""
 
     def __init__(self, genomic: bytes):
-        R = O.ref()
+        R = O.ref_static()   # oracle/ref_pairing_harness.c, linked against the core library
         R.ref_index_create.restype = C.c_void_p
         R.ref_index_create.argtypes = [C.c_char_p]
         R.ref_build_pairings.restype = C.c_long

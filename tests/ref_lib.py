@@ -1,4 +1,4 @@
-"""Direct ctypes calls into the compiled reference (oracle/_ref/libpintron_ref.so), used to pin
+"""Direct ctypes calls into the compiled reference (oracle/_ref/libpintron_ref_core.so), used to pin
 the oracle.  TEST INFRASTRUCTURE; only usable where oracle/_ref has been built."""
 import ctypes as C
 

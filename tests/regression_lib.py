@@ -1,0 +1,143 @@
+"""TEST INFRASTRUCTURE: the reference-held whole-pipeline goldens as a pin for est-fact.
+
+The reference's only fixtures that see est-fact's results are regressionTest/*/referenceOutput/
+full.json: per predicted intron the relative start/end, the splice pattern, the number of
+supporting ESTs and, per supporting EST, begin/end of the donor and acceptor factors on the EST
+(compared by regressionTest/testPIntronOutput.c:116-224).  Those fields are a function of
+est-fact's raw-multifasta-out.txt + processed-ests.txt through the reference's stages 2 and 3
+(dist-scripts/pintron.py:889-906): `min-factorization < raw-multifasta-out.txt > out-agree.txt`, then
+`intron-agreement`, which writes predicted-introns.txt and out-after-intron-agree.txt; the JSON
+fields are read off those two files by compute_json (dist-scripts/pintron.py:314-340,475-556).
+
+oracle/_ref/min-factorization-ref and intron-agreement-ref are the reference's own programs,
+compiled from its sources with no file of ours (oracle/Makefile).  `introns_table` restates the
+few lines of compute_json that produce the compared fields.  tests/golden/regression/<case>/ holds
+the reference's input data files, the table extracted from its full.json, and the list of records
+on which the reference's present sources themselves disagree with their own (older, v1.2.57)
+golden -- made by tools/pin_regression.py.
+"""
+import json
+import lzma
+import os
+import re
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+GOLD = os.path.join(HERE, "golden", "regression")
+REFDIR = os.path.join(ROOT, "oracle", "_ref")
+MINFACT = os.path.join(REFDIR, "min-factorization-ref")
+AGREE = os.path.join(REFDIR, "intron-agreement-ref")
+FIELDS = ("donor_start", "donor_end", "acceptor_start", "acceptor_end")
+
+
+def have_stages():
+    return os.path.exists(MINFACT) and os.path.exists(AGREE)
+
+
+def manifest():
+    with open(os.path.join(GOLD, "manifest.json")) as f:
+        return json.load(f)
+
+
+def stage_inputs(case, workdir):
+    """Unpack the reference's genomic.txt / ests.txt of a regression case into workdir."""
+    m = manifest()["cases"][case]
+    os.makedirs(workdir, exist_ok=True)
+    for name, rel in (("genomic.txt", m["genomic"]), ("ests.txt", m["ests"])):
+        with lzma.open(os.path.join(GOLD, rel)) as src, open(os.path.join(workdir, name), "wb") as dst:
+            dst.write(src.read())
+
+
+def expected_raw(case):
+    with lzma.open(os.path.join(GOLD, case, "expected-raw-multifasta-out.txt.xz")) as f:
+        return f.read()
+
+
+def reference_introns(case):
+    with open(os.path.join(GOLD, case, "reference_introns.json")) as f:
+        return json.load(f)
+
+
+def run_stages(workdir):
+    """Stages 2 and 3 of the reference pipeline on est-fact's files in workdir."""
+    with open(os.path.join(workdir, "raw-multifasta-out.txt"), "rb") as fin, \
+            open(os.path.join(workdir, "out-agree.txt"), "wb") as fout:
+        subprocess.run([MINFACT], cwd=workdir, stdin=fin, stdout=fout, stderr=subprocess.DEVNULL, check=True)
+    subprocess.run([AGREE], cwd=workdir, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+
+
+def introns_table(workdir):
+    """The compared fields, from out-after-intron-agree.txt and predicted-introns.txt."""
+    exons = {}
+    cur = None
+    with open(os.path.join(workdir, "out-after-intron-agree.txt")) as f:
+        for line in f:
+            line = line.rstrip()
+            if line.startswith(">"):
+                cur = re.search(r"/gb=([a-zA-Z_0-9]+)", line).group(1)      # pintron.py:320
+                exons[cur] = []
+            else:
+                m = re.match(r"(\d+) (\d+) (\d+) (\d+) (\S+) (\S+)$", line)  # pintron.py:334
+                if m:
+                    exons[cur].append(tuple(int(x) for x in m.groups()[:4]))
+    table = []
+    with open(os.path.join(workdir, "predicted-introns.txt")) as f:
+        for line in f:
+            c = line.rstrip("\n").split("\t")                                # pintron.py:478-485
+            rs, re_ = int(c[0]), int(c[1])
+            sup = {}
+            for est in (e for e in c[6].split(",") if e):
+                left = [x for x in exons[est] if x[3] == rs - 1]             # pintron.py:529-531
+                right = [x for x in exons[est] if x[2] == re_ + 1]
+                if len(left) == 1 and len(right) == 1:
+                    sup[est] = dict(donor_start=left[0][0], donor_end=left[0][1],
+                                    acceptor_start=right[0][0], acceptor_end=right[0][1])
+            table.append(dict(relative_start=rs, relative_end=re_, n_supporting=int(c[5]),
+                              pattern=c[14], supporting=sup))
+    return table
+
+
+def table_from_full_json(path):
+    """The same fields from a reference-held full.json (old key names: testPIntronOutput.c:116-224)."""
+    with open(path) as f:
+        j = json.load(f)
+    table = []
+    for k in sorted(j["introns"], key=int):
+        i = j["introns"][k]
+        sup = {est: dict(donor_start=v["begin EST donor factor"], donor_end=v["end EST donor factor"],
+                         acceptor_start=v["begin EST acceptor factor"], acceptor_end=v["end EST acceptor factor"])
+               for est, v in i["supporting ESTs"].items()}
+        table.append(dict(relative_start=i["relative start"], relative_end=i["relative end"],
+                          n_supporting=i["number supporting EST"], pattern=i["pattern"], supporting=sup))
+    return table
+
+
+def diff_tables(got, exp):
+    """Differences as a sorted list of JSON-able records:
+    ["intron", rs, re, "missing"|"extra"], ["field", rs, re, name, exp, got],
+    ["est", rs, re, est, field, exp, got]  (exp/got None when the EST is absent on one side)."""
+    out = []
+    g = {(i["relative_start"], i["relative_end"]): i for i in got}
+    e = {(i["relative_start"], i["relative_end"]): i for i in exp}
+    for k in sorted(set(g) | set(e)):
+        if k not in g:
+            out.append(["intron", k[0], k[1], "missing"])
+            continue
+        if k not in e:
+            out.append(["intron", k[0], k[1], "extra"])
+            continue
+        for name in ("n_supporting", "pattern"):
+            if g[k][name] != e[k][name]:
+                out.append(["field", k[0], k[1], name, e[k][name], g[k][name]])
+        for est in sorted(set(g[k]["supporting"]) | set(e[k]["supporting"])):
+            a, b = e[k]["supporting"].get(est), g[k]["supporting"].get(est)
+            for fld in FIELDS:
+                va, vb = (a or {}).get(fld), (b or {}).get(fld)
+                if va != vb:
+                    out.append(["est", k[0], k[1], est, fld, va, vb])
+    return out
+
+
+def count_records(table):
+    return sum(len(i["supporting"]) for i in table)

@@ -38,10 +38,10 @@ def test_ambn_golden(exe, tmp_path, env):
 
 def test_c3_sample_vs_compiled_reference(exe, tmp_path):
     """2 000 C3-shaped ESTs (200 kb genomic, 3 % errors): byte-identical to the reference binary
-    (oracle/_ref/est-fact-ref travels with the repository snapshot)."""
-    ref = os.path.join(ROOT, "oracle", "_ref", "est-fact-ref")
+    (oracle/_ref/est-fact-core travels with the repository snapshot)."""
+    ref = os.path.join(ROOT, "oracle", "_ref", "est-fact-core")
     if not os.path.exists(ref):
-        pytest.skip("oracle/_ref/est-fact-ref not present")
+        pytest.skip("oracle/_ref/est-fact-core not present")
     from pintron_amd import synth
     w = synth.make("C3", n_est=2000)
     ref_dir, my_dir = tmp_path / "ref", tmp_path / "mine"
@@ -57,9 +57,9 @@ def test_c3_sample_vs_compiled_reference(exe, tmp_path):
 def test_other_configs_vs_compiled_reference(exe, tmp_path, cfg, n_est):
     """BASELINE.json's other shapes as parity cases: C2 (50 kb x 1 000 ESTs ~500 bp) in full, C5
     (1 Mb genomic, 150 bp reads) on a 3 000-read sample."""
-    ref = os.path.join(ROOT, "oracle", "_ref", "est-fact-ref")
+    ref = os.path.join(ROOT, "oracle", "_ref", "est-fact-core")
     if not os.path.exists(ref):
-        pytest.skip("oracle/_ref/est-fact-ref not present")
+        pytest.skip("oracle/_ref/est-fact-core not present")
     from pintron_amd import synth
     w = synth.make(cfg, n_est=n_est)
     ref_dir, my_dir = tmp_path / "ref", tmp_path / "mine"
@@ -89,7 +89,7 @@ def test_real_ests_of_the_reference_regression_sets(exe, tmp_path, name, sub):
     subprocess.run([exe], cwd=my_dir, check=True)
     for f, md5 in gold.items():
         assert hashlib.md5((my_dir / f).read_bytes()).hexdigest() == md5, (name, f)
-    ref = os.path.join(ROOT, "oracle", "_ref", "est-fact-ref")
+    ref = os.path.join(ROOT, "oracle", "_ref", "est-fact-core")
     if os.path.exists(ref):
         subprocess.run([ref], cwd=ref_dir, check=True, stderr=subprocess.DEVNULL)
         for f in FILES:
@@ -100,9 +100,9 @@ def test_edge_case_inputs_vs_compiled_reference(exe, tmp_path):
     """N tails, negative-strand header, too short / all-N / lower-case / polyA-only ESTs, duplicated
     and odd headers, /fixed_strand, wrapped lines (pintron_amd/synth.py: make_edge_cases); and an
     empty ests.txt."""
-    ref = os.path.join(ROOT, "oracle", "_ref", "est-fact-ref")
+    ref = os.path.join(ROOT, "oracle", "_ref", "est-fact-core")
     if not os.path.exists(ref):
-        pytest.skip("oracle/_ref/est-fact-ref not present")
+        pytest.skip("oracle/_ref/est-fact-core not present")
     from pintron_amd import synth
     g, e = synth.make_edge_cases()
     for tag, ests in (("edge", e), ("empty", "")):
@@ -121,9 +121,9 @@ def test_edge_case_inputs_vs_compiled_reference(exe, tmp_path):
 def test_region_start_pairings_vs_compiled_reference(exe, tmp_path):
     """Transcripts that begin on the first base of the genomic region (t == 0 pairings) and repeats
     of the region's first bases through the GPU pairing kernels."""
-    ref = os.path.join(ROOT, "oracle", "_ref", "est-fact-ref")
+    ref = os.path.join(ROOT, "oracle", "_ref", "est-fact-core")
     if not os.path.exists(ref):
-        pytest.skip("oracle/_ref/est-fact-ref not present")
+        pytest.skip("oracle/_ref/est-fact-core not present")
     from pintron_amd import synth
     g, e = synth.make_region_start_repeats()
     ref_dir, my_dir = tmp_path / "ref", tmp_path / "mine"
@@ -141,9 +141,9 @@ def test_region_start_pairings_vs_compiled_reference(exe, tmp_path):
 def test_long_transcripts_vs_compiled_reference(exe, tmp_path):
     """Full-length transcripts with a 5.6 kb exon: alignments, K-band distances and affix searches
     with more than 4096 rows (strips) inside the whole program."""
-    ref = os.path.join(ROOT, "oracle", "_ref", "est-fact-ref")
+    ref = os.path.join(ROOT, "oracle", "_ref", "est-fact-core")
     if not os.path.exists(ref):
-        pytest.skip("oracle/_ref/est-fact-ref not present")
+        pytest.skip("oracle/_ref/est-fact-core not present")
     from pintron_amd import synth
     g, e = synth.make_long_transcripts()
     ref_dir, my_dir = tmp_path / "ref", tmp_path / "mine"

@@ -53,7 +53,7 @@ def test_synthetic_sample_matches_compiled_reference(bins, tmp_path):
     ref_dir, my_dir = tmp_path / "ref", tmp_path / "mine"
     for d in (ref_dir, my_dir):
         synth.write_files(w, str(d))
-    subprocess.run([os.path.join(O.REF_DIR, "est-fact-ref")], cwd=ref_dir, check=True, stderr=subprocess.DEVNULL)
+    subprocess.run([os.path.join(O.REF_DIR, "est-fact-core")], cwd=ref_dir, check=True, stderr=subprocess.DEVNULL)
     run(bins["estfact_sched_check"], my_dir, {"PINTRON_THREADS": "3"})
     for f in FILES:
         assert filecmp.cmp(my_dir / f, ref_dir / f, shallow=False), f
@@ -70,7 +70,7 @@ def test_long_transcripts_match_compiled_reference(bins, tmp_path):
         d.mkdir()
         (d / "genomic.txt").write_text(g)
         (d / "ests.txt").write_text(e)
-    subprocess.run([os.path.join(O.REF_DIR, "est-fact-ref")], cwd=ref_dir, check=True, stderr=subprocess.DEVNULL)
+    subprocess.run([os.path.join(O.REF_DIR, "est-fact-core")], cwd=ref_dir, check=True, stderr=subprocess.DEVNULL)
     run(bins["estfact_sched_check"], my_dir, {"PINTRON_THREADS": "2"})
     for f in FILES:
         assert filecmp.cmp(my_dir / f, ref_dir / f, shallow=False), f
@@ -103,7 +103,7 @@ def test_edge_case_inputs_match_compiled_reference(bins, tmp_path):
             d.mkdir()
             (d / "genomic.txt").write_text(g)
             (d / "ests.txt").write_text(ests)
-        subprocess.run([os.path.join(O.REF_DIR, "est-fact-ref")], cwd=ref_dir, check=True, stderr=subprocess.DEVNULL)
+        subprocess.run([os.path.join(O.REF_DIR, "est-fact-core")], cwd=ref_dir, check=True, stderr=subprocess.DEVNULL)
         run(bins["estfact_sched_check"], my_dir, {"PINTRON_THREADS": "2"})
         for f in FILES:
             assert filecmp.cmp(my_dir / f, ref_dir / f, shallow=False), (tag, f)
@@ -120,7 +120,7 @@ def test_region_start_pairings_match_compiled_reference(bins, tmp_path):
         d.mkdir()
         (d / "genomic.txt").write_text(g)
         (d / "ests.txt").write_text(e)
-    subprocess.run([os.path.join(O.REF_DIR, "est-fact-ref")], cwd=ref_dir, check=True, stderr=subprocess.DEVNULL)
+    subprocess.run([os.path.join(O.REF_DIR, "est-fact-core")], cwd=ref_dir, check=True, stderr=subprocess.DEVNULL)
     run(bins["estfact_sched_check"], my_dir, {"PINTRON_THREADS": "2"})
     for f in FILES:
         assert filecmp.cmp(my_dir / f, ref_dir / f, shallow=False), f

@@ -18,7 +18,7 @@ for cfg, n, seed in (("C3", 24000, 11), ("C2", 12000, 12), ("C5", 60000, 13)):
         d = os.path.join(base, cfg, "ref%02d" % c); os.makedirs(d)
         open(d + "/genomic.txt", "w").write(w.genomic_fasta())
         open(d + "/ests.txt", "w").write("".join("%s\n%s\n" % (h, s.decode()) for h, s in zip(w.est_headers[c*per:(c+1)*per], w.est_seqs[c*per:(c+1)*per])))
-        procs.append(subprocess.Popen([os.path.join(ROOT, "oracle/_ref/est-fact-ref")], cwd=d, stderr=subprocess.DEVNULL))
+        procs.append(subprocess.Popen([os.path.join(ROOT, "oracle/_ref/est-fact-core")], cwd=d, stderr=subprocess.DEVNULL))
     t0 = time.time(); rcs = [p.wait() for p in procs]; t_r = time.time() - t0
     for f in ("raw-multifasta-out.txt", "processed-ests.txt", "megs.txt", "processed-megs.txt", "meg-edges.txt"):
         ref = b"".join(open(os.path.join(base, cfg, "ref%02d" % c, f), "rb").read() for c in range(chunks))

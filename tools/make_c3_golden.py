@@ -35,7 +35,7 @@ def main():
     cap = os.path.join(tmp, "cap.jsonl")
     env = dict(os.environ, PINTRON_DP_CAPTURE=cap,
                LD_PRELOAD=os.path.join(ROOT, "oracle", "_ref", "libdpcapture.so"))
-    subprocess.run([os.path.join(ROOT, "oracle", "_ref", "est-fact-ref")], cwd=tmp, env=env,
+    subprocess.run([os.path.join(ROOT, "oracle", "_ref", "est-fact-core")], cwd=tmp, env=env,
                    stderr=subprocess.DEVNULL, check=True)
     lines = open(cap).read().splitlines()
     # LCF reconstruction from the reference output

@@ -25,7 +25,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = os.environ.get("PINTRON_REF", "/root/reference")
-REFBIN = os.path.join(ROOT, "oracle", "_ref", "est-fact-ref")
+REFBIN = os.path.join(ROOT, "oracle", "_ref", "est-fact-core")
 SHIM = os.path.join(ROOT, "oracle", "_ref", "libdpcapture.so")
 GOLD = os.path.join(ROOT, "tests", "golden")
 
