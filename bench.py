@@ -39,6 +39,38 @@ CPU_SAMPLE = 3000              # ESTs of the same workload given to the referenc
 from pintron_amd.estfact import RECORDS, Session, gather_tensor, load_host_lib  # noqa: E402
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes
+    (torch.distributed.run, one per GPU) and relay rank 0's JSON line.  Never an exec: under
+    rocprofv3 this process already has the GPU initialised.  The parent touches no GPU."""
+    import socket
+    import torch
+    have = torch.cuda.device_count()          # does not initialise the GPU
+    if have < args.gpus and os.environ.get("PINTRON_DIST_BACKEND", "nccl") == "nccl":
+        raise SystemExit("bench: --gpus %d but %d visible (PINTRON_DIST_BACKEND=gloo lets ranks share GPUs, for tests only)"
+                         % (args.gpus, have))
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for l in proc.stdout.splitlines():
+        if l.startswith("{") and '"metric"' in l:
+            line = l
+        else:
+            print(l, file=sys.stderr)
+    if proc.returncode != 0 or line is None:
+        raise SystemExit("bench: the %d-rank run failed (exit %d)" % (args.gpus, proc.returncode))
+    if json.loads(line)["n_gpus"] != args.gpus:
+        raise SystemExit("bench: asked for %d ranks, the run reports %s" % (args.gpus, json.loads(line)["n_gpus"]))
+    print(line, flush=True)
+
+
 def rocprof_symbol(group_name):
     """Kernel symbol (as rocprofv3 prints it) of a kernel group name reported by the library."""
     import re
@@ -124,10 +156,17 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--ests", type=int, default=N_EST_BATCH, help="ESTs per GPU per step (default: C3)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / parity leg")
+    ap.add_argument("--workload", choices=("C3", "C4"), default="C3",
+                    help="C3 (default, the metric's configuration): one 200 kb gene x --ests per GPU; "
+                         "C4: 8 genes x 200 kb, --ests ESTs each (62 500 = BASELINE.json configs[3]), gene g on rank g mod N")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     # one rank per GPU over RCCL.  PINTRON_DIST_BACKEND=gloo (as in pintron_amd.multi) keeps the
@@ -151,21 +190,32 @@ def main():
 
     from pintron_amd import synth
     L = load_host_lib()
-    # every rank gets its own C3 batch (weak scaling); rank r uses seed 3 + r so batches differ
-    wl = synth.make("C3", n_est=args.ests, seed=synth.CONFIGS["C3"]["seed"] + rank)
-    work = tempfile.mkdtemp(prefix="pintron_bench_r%d_" % rank)
-    synth.write_files(wl, work)
-    sess = Session(L, work)
-    n_est = sess.n_ests()
+    if args.workload == "C3":
+        # every rank gets its own C3 batch (weak scaling); rank r uses seed 3 + r so batches differ
+        genes = [("C3", synth.CONFIGS["C3"]["seed"] + rank, args.ests)]
+    else:
+        # C4: eight independent est-fact problems; gene g runs on rank g mod N (strong scaling)
+        per_gene = synth.CONFIGS["C4"]["n_est"] if args.ests == N_EST_BATCH else args.ests
+        genes = [("C4", synth.CONFIGS["C4"]["seed"] + g, per_gene)
+                 for g in range(synth.CONFIGS["C4"]["genes"]) if g % world == rank]
+    works, sessions = [], []
+    for name, seed, n in genes:
+        work = tempfile.mkdtemp(prefix="pintron_bench_r%d_" % rank)
+        synth.write_files(synth.make(name, n_est=n, seed=seed), work)
+        works.append(work)
+        sessions.append(Session(L, work))
+    n_est = sum(s.n_ests() for s in sessions)
 
     def step():
-        st = sess.step()
-        if world > 1:
-            # the only exchange of the sharded path: the factorization records of the rank's ESTs
-            # (packed: 16 B per exon + 4 B per factorization, everything downstream stages parse out
-            # of raw-multifasta-out.txt) -> rank 0 over RCCL
-            gather_tensor(sess.output_tensor(RECORDS), dist, rank, world, xdev)
-        return st
+        sts = []
+        for sess in sessions:
+            sts.append(sess.step())
+            if world > 1:
+                # the only exchange of the sharded path: the factorization records of the rank's ESTs
+                # (packed: 16 B per exon + 4 B per factorization, everything downstream stages parse out
+                # of raw-multifasta-out.txt) -> rank 0 over RCCL
+                gather_tensor(sess.output_tensor(RECORDS), dist, rank, world, xdev)
+        return sts
 
     def fence():
         if world > 1:
@@ -184,10 +234,15 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    total_est = n_est
+    if world > 1:
+        tn = torch.tensor([n_est], dtype=torch.int64, device=xdev)
+        dist.all_reduce(tn)
+        total_est = int(tn.item())
     if rank == 0:
-        st = stats[-1]
+        st = stats[-1][-1]
         kernels = {}
-        for s in stats:
+        for s in (x for per_step in stats for x in per_step):
             for k in range(s.n_kernels):
                 ks = s.kernels[k]
                 d = kernels.setdefault(ks.name.decode(), dict(ms=0.0, launches=0, jobs=0, cells=0, algo_bytes=0))
@@ -197,17 +252,23 @@ def main():
         step_s = dt / args.steps
         out = {
             "metric": "ESTs aligned/sec (whole node) + DP Mcells/s; bit-exact factorizations vs ref",
-            "value": n_est * world / step_s, "unit": "ESTs/s", "n_gpus": world, "steps": args.steps,
+            "value": total_est / step_s, "unit": "ESTs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": step_s * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u8/int32", "data": "synthetic",
-            "config": {"workload": "C3: 200 kb genomic x %d ESTs ~600 bp, 3%% errors, per GPU" % n_est,
+            "scaling": "weak" if args.workload == "C3" else "strong", "vs_baseline": None, "dtype": "u8/int32", "data": "synthetic",
+            "config": {"workload": ("C3: 200 kb genomic x %d ESTs ~600 bp, 3%% errors, per GPU" % n_est) if args.workload == "C3" else
+                                   ("C4: %d genes x 200 kb, %d ESTs ~600 bp each, gene g on rank g mod %d (%d ESTs in all)"
+                                    % (synth.CONFIGS["C4"]["genes"], genes[0][2], world, total_est)),
                        "stages": "whole est-fact hot path per step: GPU pairings over the device index + host MEG/"
                                  "embeddings/filters/refinement (%d threads, fibres) with all DPs batched on the GPU"
                                  % st.threads,
-                       "ests_per_gpu": n_est, "aligned_per_gpu": int(st.aligned),
-                       "dp_jobs_per_step": int(st.dp_jobs), "dp_batches_per_step": int(st.dp_batches),
+                       "ests_per_gpu": n_est, "aligned_per_gpu": int(sum(x.aligned for x in stats[-1])),
+                       "dp_jobs_per_step": int(sum(x.dp_jobs for x in stats[-1])),
+                       "dp_batches_per_step": int(sum(x.dp_batches for x in stats[-1])),
                        "parallelism": "est-shard x%d" % world},
             "dp_mcells_per_s": sum(k["cells"] for k in kernels.values()) * world / step_s / 1e6,
+            # md5 of rank 0's raw-multifasta-out text of the LAST TIMED step (tools/big_parity_check.py
+            # produces the same checksum from the reference CPU est-fact: tests/golden/bench_md5.json)
+            "timed_output_md5": hashlib.md5(b"".join(sess.records() for sess in sessions)).hexdigest(),
             "phases_s": {"load_once": st.load_s, "index_once": st.index_s, "prefetch_pairings": st.prefetch_s,
                          "workers_wall": st.workers_s, "host_cpu_per_thread": st.host_s / st.threads,
                          "dp_batches_per_thread": st.dp_s / st.threads},
@@ -233,7 +294,7 @@ def main():
                                # cells (reference loop bounds) per second of this kernel's own stream time
                                "Gcells_s": round(k["cells"] / (k["ms"] * 1e-3) / 1e9, 1) if k["ms"] and k["cells"] else None}
                               for n, k in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"])]
-        if world == 1 and not args.no_cpu:
+        if world == 1 and not args.no_cpu and args.workload == "C3":
             # bounded sample of the same workload: reference CPU est-fact vs this code, byte for byte
             sample = synth.make("C3", n_est=CPU_SAMPLE, seed=synth.CONFIGS["C3"]["seed"] + rank)
             sdir_ref = tempfile.mkdtemp(prefix="pintron_bench_ref_")
@@ -262,8 +323,10 @@ def main():
             shutil.rmtree(sdir_ref, ignore_errors=True)
             shutil.rmtree(sdir_gpu, ignore_errors=True)
         print(json.dumps(out), flush=True)
-    sess.close()
-    shutil.rmtree(work, ignore_errors=True)
+    for sess in sessions:
+        sess.close()
+    for work in works:
+        shutil.rmtree(work, ignore_errors=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -140,6 +140,10 @@ static int set_err(pgpu_ctx* ctx, int code, const char* fmt, ...) {
   } while (0)
 
 hipStream_t pgpu_ctx_stream(pgpu_ctx* ctx) { return ctx->stream; }
+int pgpu_ctx_bind(pgpu_ctx* ctx) {
+  const hipError_t e = hipSetDevice(ctx->device);
+  return e == hipSuccess ? PGPU_OK : set_err(ctx, PGPU_EDEVICE, "hipSetDevice(%d) failed: %s", ctx->device, hipGetErrorString(e));
+}
 int pgpu_ctx_fail(pgpu_ctx* ctx, int code, const char* msg) { return set_err(ctx, code, "%s", msg); }
 
 extern "C" int pgpu_abi_version(void) { return 1; }

@@ -378,6 +378,7 @@ extern "C" int pgpu_index_build(pgpu_ctx* ctx, const char* genomic, size_t len, 
   if (!ctx || !out || (len && !genomic)) return PGPU_EINVAL;
   *out = nullptr;
   if (len >= (1u << 28)) return pgpu_ctx_fail(ctx, PGPU_ERANGE, "genomic longer than 2^28");
+  if (pgpu_ctx_bind(ctx) != PGPU_OK) return PGPU_EDEVICE;
   pgpu_index* idx = new (std::nothrow) pgpu_index();
   if (!idx) return pgpu_ctx_fail(ctx, PGPU_ENOMEM, "out of host memory");
   idx->len = len;
@@ -441,6 +442,7 @@ done:
 
 extern "C" int pgpu_index_destroy(pgpu_ctx* ctx, pgpu_index* idx) {
   if (!ctx || !idx) return PGPU_EINVAL;
+  if (pgpu_ctx_bind(ctx) != PGPU_OK) return PGPU_EDEVICE;
   hipStreamSynchronize(pgpu_ctx_stream(ctx));
   hipFree(idx->d_gen); hipFree(idx->d_sa); hipFree(idx->d_lcp); hipFree(idx->d_klo); hipFree(idx->d_khi);
   delete idx;
@@ -450,6 +452,7 @@ extern "C" int pgpu_index_destroy(pgpu_ctx* ctx, pgpu_index* idx) {
 extern "C" int pgpu_index_suffix_array(pgpu_ctx* ctx, const pgpu_index* idx, uint32_t* sa_out, size_t cap) {
   if (!ctx || !idx || !sa_out) return PGPU_EINVAL;
   if (cap < idx->len) return pgpu_ctx_fail(ctx, PGPU_ENOSPC, "suffix array buffer too small");
+  if (pgpu_ctx_bind(ctx) != PGPU_OK) return PGPU_EDEVICE;
   hipStream_t st = pgpu_ctx_stream(ctx);
   if (idx->len && (hipMemcpyAsync(sa_out, idx->d_sa, idx->len * sizeof(uint32_t), hipMemcpyDeviceToHost, st) != hipSuccess ||
                    hipStreamSynchronize(st) != hipSuccess))
@@ -509,6 +512,7 @@ extern "C" int pgpu_pairing_plan_create(pgpu_ctx* ctx, const pgpu_index* idx, co
   *out = nullptr;
   for (size_t i = 0; i < n_pat; ++i)
     if (pat_off[i + 1] < pat_off[i] || pat_off[i + 1] - pat_off[i] > 0x7fffffffull) return pgpu_ctx_fail(ctx, PGPU_EINVAL, "bad pattern offsets");
+  if (pgpu_ctx_bind(ctx) != PGPU_OK) return PGPU_EDEVICE;
   pgpu_pairing_plan* p = new (std::nothrow) pgpu_pairing_plan();
   if (!p) return pgpu_ctx_fail(ctx, PGPU_ENOMEM, "out of host memory");
   int rc = PGPU_OK;
@@ -547,6 +551,7 @@ done:
 // costs one stream synchronisation after each scan (the totals are needed on the host anyway)
 extern "C" int pgpu_pairing_plan_run(pgpu_ctx* ctx, pgpu_pairing_plan* p, const pgpu_pairing_params* params) {
   if (!ctx || !p || !params || params->min_factor_len == 0) return PGPU_EINVAL;
+  if (pgpu_ctx_bind(ctx) != PGPU_OK) return PGPU_EDEVICE;
   int rc = PGPU_OK;
   hipStream_t st = pgpu_ctx_stream(ctx);
   const pgpu_index* ix = p->idx;
@@ -611,6 +616,7 @@ extern "C" int pgpu_pairing_plan_fetch(pgpu_ctx* ctx, pgpu_pairing_plan* p, pgpu
                                        uint64_t* out_first) {
   if (!ctx || !p || !out_first) return PGPU_EINVAL;
   if (out_cap < p->n_out) return pgpu_ctx_fail(ctx, PGPU_ENOSPC, "pairing buffer too small");
+  if (pgpu_ctx_bind(ctx) != PGPU_OK) return PGPU_EDEVICE;
   int rc = PGPU_OK;
   hipStream_t st = pgpu_ctx_stream(ctx);
   if (p->n_pat == 0) { out_first[0] = 0; return PGPU_OK; }
@@ -623,6 +629,7 @@ done:
 
 extern "C" int pgpu_pairing_plan_destroy(pgpu_ctx* ctx, pgpu_pairing_plan* p) {
   if (!ctx || !p) return PGPU_EINVAL;
+  if (pgpu_ctx_bind(ctx) != PGPU_OK) return PGPU_EDEVICE;
   hipStreamSynchronize(pgpu_ctx_stream(ctx));
   pairing_plan_free(p);
   return PGPU_OK;

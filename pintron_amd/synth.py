@@ -4,6 +4,7 @@ input generation only (numpy), not part of the accelerated path.
 
 Config shapes (BASELINE.json `configs`):
   C2: 50 kb x 1 000 ESTs ~500 bp, 1 % errors      C3: 200 kb x 100 000 ESTs ~600 bp, 3 % errors
+  C4: 8 genes x (200 kb x 62 500 ESTs ~600 bp, 3 % errors), gene g = seed 40 + g
   C5: 1 Mb x 2 000 000 ESTs of exactly 150 bp, 1 % errors
 """
 from dataclasses import dataclass, field
@@ -39,6 +40,8 @@ class Workload:
 CONFIGS = {
     "C2": dict(gen_len=50_000, n_est=1_000, est_len=500, est_sd=100, err=0.01, seed=2),
     "C3": dict(gen_len=200_000, n_est=100_000, est_len=600, est_sd=100, err=0.03, seed=3),
+    # C4 = 8 genes of the C3 shape (gene g: seed 40 + g), 62 500 ESTs each = 500 000 in all
+    "C4": dict(gen_len=200_000, n_est=62_500, est_len=600, est_sd=100, err=0.03, seed=40, genes=8),
     "C5": dict(gen_len=1_000_000, n_est=2_000_000, est_len=150, est_sd=0, err=0.01, seed=5),
 }
 

@@ -229,3 +229,59 @@ def test_bench_flow_with_two_ranks_on_one_gpu(exe, tmp_path):
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "est-shard x2" and d["scaling"] == "weak"
     assert d["config"]["ests_per_gpu"] == 6000 and d["value"] > 0
+
+
+def test_bench_launches_its_own_ranks(exe, tmp_path):
+    """`python bench.py --gpus 2` with no launcher around it: the parent starts two rank processes
+    itself (children, never an exec) and relays rank 0's line.  Two ranks share this box's one GPU,
+    so the exchange runs over gloo; on a node with >= 2 GPUs the same command uses RCCL."""
+    import json
+    import sys
+    import torch
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    if torch.cuda.device_count() < 2:
+        env["PINTRON_DIST_BACKEND"] = "gloo"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+           "--ests", "3000", "--no-cpu"]
+    out = subprocess.run(cmd, cwd=tmp_path, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["ests_per_gpu"] == 3000 and d["value"] > 0
+    # a launcher that disagrees with --gpus is an error, not a silent 1-rank run
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--no-cpu"],
+                         cwd=tmp_path, env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"),
+                         capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and "WORLD_SIZE" in bad.stderr
+
+
+def test_c4_two_gene_sample_vs_compiled_reference(exe, tmp_path):
+    """BASELINE.json configs[3] (8 genes x 200 kb, ESTs sharded gene-wise over the GPUs) on a
+    2-gene x 1 500-EST sample: every gene's files against the reference object code, and
+    `bench.py --workload C4` over the same genes (one rank, both genes resident)."""
+    import json
+    import sys
+    ref = os.path.join(ROOT, "oracle", "_ref", "est-fact-core")
+    if not os.path.exists(ref):
+        pytest.skip("oracle/_ref/est-fact-core not present")
+    from pintron_amd import synth
+    for g in range(2):
+        w = synth.make("C4", n_est=1500, seed=synth.CONFIGS["C4"]["seed"] + g)
+        ref_dir, my_dir = tmp_path / ("ref%d" % g), tmp_path / ("mine%d" % g)
+        for d in (ref_dir, my_dir):
+            synth.write_files(w, str(d))
+        subprocess.run([ref], cwd=ref_dir, check=True, stderr=subprocess.DEVNULL)
+        subprocess.run([exe], cwd=my_dir, check=True)
+        for f in FILES:
+            assert filecmp.cmp(my_dir / f, ref_dir / f, shallow=False), (g, f)
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "C4", "--ests", "1500",
+                          "--steps", "1", "--warmup", "0"], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["scaling"] == "strong" and d["config"]["ests_per_gpu"] == 8 * 1500 and d["n_gpus"] == 1
