@@ -101,6 +101,48 @@ int pgpu_pairing_plan_fetch(pgpu_ctx* ctx, pgpu_pairing_plan* plan, pgpu_pairing
 int pgpu_pairing_plan_destroy(pgpu_ctx* ctx, pgpu_pairing_plan* plan);
 
 /* ------------------------------------------------------------------------------------------ */
+/* maximal-embedding graphs -- for every pattern of a plan whose pairings have just been       */
+/* computed (pgpu_pairing_plan_run), the rest of build_meg (src/compute-est-fact.c:101-131):    */
+/* build_edge_set (src/max-emb-graph.c:650-676 with is_there_an_edge_strict :394-465,           */
+/* add_edges_from :533-553, add_edges_from_source :555-599, add_edges_to_sink :601-647),        */
+/* simplify_meg (src/meg-simplification.c:314,193-232,142-191), transitive_reduction            */
+/* (:333-632), compact_short_edges (:258-312), is_too_complex_for_compaction and                */
+/* is_too_complex (:68-139).  The pairings stay in HBM; what comes back is the finished graph.  */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct {
+  uint32_t min_factor_len;            /* the one the pairings were computed with            */
+  int32_t  min_intron_length, max_intron_length;
+  uint32_t max_pairings_in_MEG;
+  double   max_prefix_discarded_rate, max_suffix_discarded_rate, max_freq_shortest_pairing;
+  uint32_t trans_red, short_edge_comp;   /* booleans                                         */
+} pgpu_meg_params;
+
+#define PGPU_MEG_MAX_VERTICES 64      /* vertices ever created for one MEG (source and sink included) */
+#define PGPU_MEG_MAX_DEGREE   32      /* out- or in-degree of a vertex                                 */
+#define PGPU_MEG_TOO_COMPLEX  1u      /* too_complex of build_meg (:122-131): the caller retries        */
+#define PGPU_MEG_UNAVAILABLE  2u      /* beyond the limits above (or cyclic): the record is a bare
+                                         header and the caller builds this MEG from the pairings       */
+/* One record per pattern, 4-byte aligned, little endian:
+ *   u32 n_vertices, u32 n_edges, u32 flags, u32 0
+ *   n_vertices x (i32 p, t, l)     in the order of the reference's position lists = the numbering
+ *                                  meg_write prints (src/io-meg.c:161-170); [0] source, [last] sink
+ *   (n_vertices + 1) x u16         first edge of each vertex (CSR)
+ *   n_edges x u8                   target vertex, in the order of the reference's adjacency lists
+ * run_meg builds the records of all patterns (after pgpu_pairing_plan_run with the same
+ * min_factor_len); meg_bytes = total size; fetch_meg copies them and the n_pat + 1 byte offsets. */
+int pgpu_pairing_plan_run_meg(pgpu_ctx* ctx, pgpu_pairing_plan* plan, const pgpu_meg_params* params);
+uint64_t pgpu_pairing_plan_meg_bytes(const pgpu_pairing_plan* plan);
+int pgpu_pairing_plan_fetch_meg(pgpu_ctx* ctx, pgpu_pairing_plan* plan, void* out, size_t out_cap,
+                                uint64_t* rec_first);
+/* HIP-event time of the MEG kernels of the last run_meg (build + scan + emit) */
+double pgpu_pairing_plan_meg_ms(const pgpu_pairing_plan* plan);
+
+/* page-locked host memory for the buffers handed to the fetch calls (a pageable destination
+ * makes the runtime stage the copy); plain malloc'ed memory works too, slower */
+int pgpu_host_alloc(pgpu_ctx* ctx, size_t bytes, void** out);
+int pgpu_host_free(pgpu_ctx* ctx, void* p);
+
+/* ------------------------------------------------------------------------------------------ */
 /* batched dynamic programs                                                                   */
 /* ------------------------------------------------------------------------------------------ */
 enum pgpu_dp_kind {

@@ -341,7 +341,9 @@ extern "C" int pgpu_dp_plan_create_parts(pgpu_ctx* ctx, const pgpu_index* idx, c
         if (lb > 65535u || la >= (1u << 28)) continue;
         k.family = KF_LCF; k.R = 0; k.size = (uint64_t)la * lb; break;
       case PGPU_DP_BORDERS:
-        if (la > PGPU_MAX_ROWS_BORDERS || lb > PGPU_MAX_COLS) continue;
+        // only the first and the last t_win = min(len_p + max_errs, len_t) characters of t are swept
+        // (src/refine.c:117-121): t may be a whole intron of any length the index can hold
+        if (la > PGPU_MAX_ROWS_BORDERS || std::min<uint64_t>((uint64_t)la + in.p2, lb) > PGPU_MAX_COLS) continue;
         if (in.p0 > in.p1 || in.p1 > la) { pre.status = PGPU_EINVAL; continue; }
         // cells as the reference bounds them: two matrices of len_p x t_win, t_win = min(len_p + max_errs, len_t)
         // (src/refine.c:117-121); the gap of check_gap_errors is a whole intron, the window a few dozen columns

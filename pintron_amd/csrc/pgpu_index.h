@@ -18,3 +18,13 @@ bool pgpu_ctx_pool_acquire(pgpu_ctx* ctx, int pool);
 void pgpu_ctx_pool_release(pgpu_ctx* ctx, int pool);
 void* pgpu_ctx_pool_get(pgpu_ctx* ctx, int pool, int slot, size_t bytes);
 bool pgpu_ctx_timing(const pgpu_ctx* ctx);
+
+// pgpu_meg.hip: hand-written exclusive prefix sums and the per-pattern MEG kernels
+size_t pgpu_scan_tmp_bytes(size_t n);
+void pgpu_exclusive_scan_u32(const uint32_t* in, unsigned long long* out, size_t n, void* tmp, hipStream_t st);
+size_t pgpu_meg_scratch_bytes(size_t n_pat);
+void pgpu_meg_launch_build(const pgpu_pairing* pairs, const unsigned long long* pair_first, const unsigned long long* pat_off,
+                           uint32_t n_pat, const pgpu_meg_params* prm, void* scratch, void* info, uint32_t* rec_bytes,
+                           hipStream_t st);
+void pgpu_meg_launch_emit(uint32_t n_pat, const void* scratch, const void* info, const unsigned long long* rec_off,
+                          uint8_t* out, hipStream_t st);

@@ -16,11 +16,12 @@
 //   pair_count / pair_fill / pair_cross / pair_emit
 //                 per position: occurrences above the threshold, sort by t, filter (a);
 //                 filter (b) against the previous position; compaction into (p,t,l) triples
+#include <algorithm>
 #include <cstring>
 #include <new>
 #include <vector>
 
-#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_radix_sort.hpp>   // index construction only (one-off per gene)
 #include <rocprim/device/device_scan.hpp>
 
 #include "pgpu_index.h"
@@ -483,6 +484,17 @@ struct pgpu_pairing_plan {
   float ms[7] = {0};
   bool pooled = false;
   pgpu_ctx* owner = nullptr;
+  // MEG stage (pgpu_meg.hip)
+  void *d_meg_scratch = nullptr, *d_meg_info = nullptr;
+  uint32_t* d_meg_bytes = nullptr;
+  unsigned long long* d_meg_off = nullptr;
+  uint8_t* d_meg_out = nullptr;
+  size_t meg_cap = 0;
+  unsigned long long meg_total = 0;
+  hipEvent_t meg_ev[2] = {nullptr, nullptr};
+  float meg_ms = 0.f;
+  uint32_t last_L = 0;
+  bool have_pairs = false;
 };
 
 // device buffer for a pairing plan: from the context's pool when the plan holds it
@@ -501,8 +513,10 @@ static void pairing_plan_free(pgpu_pairing_plan* p) {
     hipFree(p->d_thr); hipFree(p->d_cnt); hipFree(p->d_cnt_a); hipFree(p->d_cnt_b);
     hipFree(p->d_cand_off); hipFree(p->d_out_off); hipFree(p->d_out_first); hipFree(p->d_cand);
     hipFree(p->d_keep); hipFree(p->d_out); hipFree(p->d_tmp);
+    hipFree(p->d_meg_scratch); hipFree(p->d_meg_info); hipFree(p->d_meg_bytes); hipFree(p->d_meg_off); hipFree(p->d_meg_out);
   }
   for (auto& e : p->ev) if (e) hipEventDestroy(e);
+  for (auto& e : p->meg_ev) if (e) hipEventDestroy(e);
   delete p;
 }
 
@@ -531,12 +545,8 @@ extern "C" int pgpu_pairing_plan_create(pgpu_ctx* ctx, const pgpu_index* idx, co
   NEED(p->d_cand_off = plan_alloc<unsigned long long>(p, 9, tp + 1));
   NEED(p->d_out_off = plan_alloc<unsigned long long>(p, 10, tp + 1));
   NEED(p->d_out_first = plan_alloc<unsigned long long>(p, 11, n_pat + 1));
-  {
-    size_t b = 0;
-    TRY_HIP(rocprim::exclusive_scan(nullptr, b, p->d_cnt, p->d_cand_off, 0ull, tp + 1, rocprim::plus<unsigned long long>(), st));
-    p->tmp_bytes = b;
-    NEED(p->d_tmp = plan_alloc<uint8_t>(p, 12, b ? b : 16));
-  }
+  p->tmp_bytes = pgpu_scan_tmp_bytes(std::max(tp, n_pat) + 1);
+  NEED(p->d_tmp = plan_alloc<uint8_t>(p, 12, p->tmp_bytes));
   if (pgpu_ctx_timing(ctx)) for (auto& e : p->ev) TRY_HIP(hipEventCreate(&e));
   if (tp) TRY_HIP(hipMemcpyAsync(p->d_pats, patterns, tp, hipMemcpyHostToDevice, st));
   TRY_HIP(hipMemcpyAsync(p->d_pat_off, pat_off, (n_pat + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
@@ -560,8 +570,8 @@ extern "C" int pgpu_pairing_plan_run(pgpu_ctx* ctx, pgpu_pairing_plan* p, const 
   const PairParams prm{params->min_factor_len, params->min_string_depth_rate};
   const dim3 pgrid((unsigned)(p->n_pat ? p->n_pat : 1)), pblk(64);
   p->n_cand = p->n_out = 0;
+  p->have_pairs = false;
   if (p->n_pat == 0) return PGPU_OK;
-  size_t b;
   if (p->ev[0]) TRY_HIP(hipEventRecord(p->ev[0], st));
   hipLaunchKernelGGL(pair_locate_kernel, pgrid, pblk, 0, st, ix->d_gen, n, ix->d_sa, ix->d_klo, ix->d_khi, p->d_pats, p->d_pat_off, prm, p->d_lo, p->d_hi, p->d_a);
   if (p->ev[1]) TRY_HIP(hipEventRecord(p->ev[1], st));
@@ -570,8 +580,7 @@ extern "C" int pgpu_pairing_plan_run(pgpu_ctx* ctx, pgpu_pairing_plan* p, const 
   if (p->ev[2]) TRY_HIP(hipEventRecord(p->ev[2], st));
   hipLaunchKernelGGL(pair_count_kernel, pgrid, pblk, 0, st, ix->d_gen, n, ix->d_sa, p->d_pats, p->d_pat_off, prm, p->d_lo, p->d_hi, p->d_thr, p->d_cnt);
   TRY_HIP(hipMemsetAsync(p->d_cnt + tp, 0, sizeof(uint32_t), st));
-  b = p->tmp_bytes;
-  TRY_HIP(rocprim::exclusive_scan(p->d_tmp, b, p->d_cnt, p->d_cand_off, 0ull, tp + 1, rocprim::plus<unsigned long long>(), st));
+  pgpu_exclusive_scan_u32(p->d_cnt, p->d_cand_off, tp + 1, p->d_tmp, st);
   if (p->ev[3]) TRY_HIP(hipEventRecord(p->ev[3], st));
   TRY_HIP(hipMemcpyAsync(&p->n_cand, p->d_cand_off + tp, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
   TRY_HIP(hipStreamSynchronize(st));
@@ -587,8 +596,7 @@ extern "C" int pgpu_pairing_plan_run(pgpu_ctx* ctx, pgpu_pairing_plan* p, const 
   if (p->ev[4]) TRY_HIP(hipEventRecord(p->ev[4], st));
   hipLaunchKernelGGL(pair_cross_kernel, pgrid, pblk, 0, st, p->d_pat_off, p->d_cand_off, p->d_cand, p->d_cnt_a, p->d_keep, p->d_cnt_b);
   TRY_HIP(hipMemsetAsync(p->d_cnt_b + tp, 0, sizeof(uint32_t), st));
-  b = p->tmp_bytes;
-  TRY_HIP(rocprim::exclusive_scan(p->d_tmp, b, p->d_cnt_b, p->d_out_off, 0ull, tp + 1, rocprim::plus<unsigned long long>(), st));
+  pgpu_exclusive_scan_u32(p->d_cnt_b, p->d_out_off, tp + 1, p->d_tmp, st);
   if (p->ev[5]) TRY_HIP(hipEventRecord(p->ev[5], st));
   TRY_HIP(hipMemcpyAsync(&p->n_out, p->d_out_off + tp, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
   TRY_HIP(hipStreamSynchronize(st));
@@ -604,8 +612,78 @@ extern "C" int pgpu_pairing_plan_run(pgpu_ctx* ctx, pgpu_pairing_plan* p, const 
   TRY_HIP(hipStreamSynchronize(st));
   TRY_HIP(hipGetLastError());
   if (p->ev[0]) for (int k = 0; k < 6; ++k) hipEventElapsedTime(&p->ms[k], p->ev[k], p->ev[k + 1]);
+  p->have_pairs = true; p->last_L = params->min_factor_len;
 done:
   return rc;
+}
+
+// MEG of every pattern from the pairings that pgpu_pairing_plan_run left in HBM
+extern "C" int pgpu_pairing_plan_run_meg(pgpu_ctx* ctx, pgpu_pairing_plan* p, const pgpu_meg_params* prm) {
+  if (!ctx || !p || !prm || prm->min_factor_len == 0) return PGPU_EINVAL;
+  if (pgpu_ctx_bind(ctx) != PGPU_OK) return PGPU_EDEVICE;
+  p->meg_total = 0; p->meg_ms = 0.f;
+  if (p->n_pat == 0) return PGPU_OK;
+  if (!p->have_pairs || p->last_L != prm->min_factor_len)
+    return pgpu_ctx_fail(ctx, PGPU_EINVAL, "run_meg needs the pairings of pgpu_pairing_plan_run with the same min_factor_len");
+  int rc = PGPU_OK;
+  hipStream_t st = pgpu_ctx_stream(ctx);
+  const uint32_t np = (uint32_t)p->n_pat;
+  if (!p->d_meg_scratch) {
+    NEED(p->d_meg_scratch = plan_alloc<uint8_t>(p, 16, pgpu_meg_scratch_bytes(np)));
+    NEED(p->d_meg_info = plan_alloc<uint8_t>(p, 17, (size_t)np * 16));
+    NEED(p->d_meg_bytes = plan_alloc<uint32_t>(p, 18, (size_t)np + 1));
+    NEED(p->d_meg_off = plan_alloc<unsigned long long>(p, 19, (size_t)np + 1));
+    if (pgpu_ctx_timing(ctx)) for (auto& e : p->meg_ev) TRY_HIP(hipEventCreate(&e));
+  }
+  if (p->meg_ev[0]) TRY_HIP(hipEventRecord(p->meg_ev[0], st));
+  pgpu_meg_launch_build(p->d_out, p->d_out_first, p->d_pat_off, np, prm, p->d_meg_scratch, p->d_meg_info, p->d_meg_bytes, st);
+  TRY_HIP(hipMemsetAsync(p->d_meg_bytes + np, 0, sizeof(uint32_t), st));
+  pgpu_exclusive_scan_u32(p->d_meg_bytes, p->d_meg_off, (size_t)np + 1, p->d_tmp, st);
+  TRY_HIP(hipMemcpyAsync(&p->meg_total, p->d_meg_off + np, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+  TRY_HIP(hipStreamSynchronize(st));
+  if (p->meg_total > p->meg_cap || !p->d_meg_out) {
+    if (!p->pooled) hipFree(p->d_meg_out);
+    p->d_meg_out = nullptr;
+    p->meg_cap = (size_t)(p->meg_total + p->meg_total / 8 + 4096);
+    NEED(p->d_meg_out = plan_alloc<uint8_t>(p, 20, p->meg_cap));
+  }
+  pgpu_meg_launch_emit(np, p->d_meg_scratch, p->d_meg_info, p->d_meg_off, p->d_meg_out, st);
+  if (p->meg_ev[1]) TRY_HIP(hipEventRecord(p->meg_ev[1], st));
+  TRY_HIP(hipStreamSynchronize(st));
+  TRY_HIP(hipGetLastError());
+  if (p->meg_ev[0]) hipEventElapsedTime(&p->meg_ms, p->meg_ev[0], p->meg_ev[1]);
+done:
+  return rc;
+}
+
+extern "C" uint64_t pgpu_pairing_plan_meg_bytes(const pgpu_pairing_plan* p) { return p ? p->meg_total : 0; }
+extern "C" double pgpu_pairing_plan_meg_ms(const pgpu_pairing_plan* p) { return p ? p->meg_ms : 0.0; }
+
+extern "C" int pgpu_pairing_plan_fetch_meg(pgpu_ctx* ctx, pgpu_pairing_plan* p, void* out, size_t out_cap, uint64_t* rec_first) {
+  if (!ctx || !p || !rec_first || (p->meg_total && !out)) return PGPU_EINVAL;
+  if (out_cap < p->meg_total) return pgpu_ctx_fail(ctx, PGPU_ENOSPC, "MEG buffer too small");
+  if (pgpu_ctx_bind(ctx) != PGPU_OK) return PGPU_EDEVICE;
+  int rc = PGPU_OK;
+  hipStream_t st = pgpu_ctx_stream(ctx);
+  if (p->n_pat == 0) { rec_first[0] = 0; return PGPU_OK; }
+  if (p->meg_total) TRY_HIP(hipMemcpyAsync(out, p->d_meg_out, (size_t)p->meg_total, hipMemcpyDeviceToHost, st));
+  TRY_HIP(hipMemcpyAsync(rec_first, p->d_meg_off, (p->n_pat + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+  TRY_HIP(hipStreamSynchronize(st));
+done:
+  return rc;
+}
+
+extern "C" int pgpu_host_alloc(pgpu_ctx* ctx, size_t bytes, void** out) {
+  if (!ctx || !out) return PGPU_EINVAL;
+  *out = nullptr;
+  if (pgpu_ctx_bind(ctx) != PGPU_OK) return PGPU_EDEVICE;
+  if (hipHostMalloc(out, bytes ? bytes : 16, hipHostMallocDefault) != hipSuccess) return pgpu_ctx_fail(ctx, PGPU_ENOMEM, "out of page-locked host memory");
+  return PGPU_OK;
+}
+extern "C" int pgpu_host_free(pgpu_ctx* ctx, void* q) {
+  if (!ctx) return PGPU_EINVAL;
+  if (q && hipHostFree(q) != hipSuccess) return pgpu_ctx_fail(ctx, PGPU_EDEVICE, "hipHostFree failed");
+  return PGPU_OK;
 }
 
 extern "C" uint64_t pgpu_pairing_plan_count(const pgpu_pairing_plan* p) { return p ? p->n_out : 0; }

@@ -51,6 +51,38 @@ ef_meg* ef_meg_from_pairings(const ef_triple* tr, size_t n_tr, size_t m) {
   return V;
 }
 
+/* MEG built on the device (libpintron_gpu.so: pgpu_meg.hip) -> the list structure the embedding
+ * enumeration and the writers walk.  Vertices come in position-list order with their adjacency
+ * lists in the reference's order; incidence lists are not needed past this point and stay empty. */
+ef_meg* ef_meg_from_record(const void* rec, size_t m) {
+  const uint32_t* head = (const uint32_t*)rec;
+  const uint32_t nv = head[0];
+  const int32_t* vt = (const int32_t*)((const char*)rec + 16);
+  const uint16_t* first = (const uint16_t*)((const char*)rec + 16 + 12 * (size_t)nv);
+  const uint8_t* tgt = (const uint8_t*)rec + 16 + 12 * (size_t)nv + 2 * ((size_t)nv + 1);
+  ef_meg* V = (ef_meg*)malloc(sizeof(ef_meg));
+  V->n = m + 2;
+  V->v = (ef_list**)malloc(V->n * sizeof(ef_list*) + (nv + 2) * sizeof(ef_list));
+  ef_list* heads = (ef_list*)(V->v + V->n);
+  for (size_t i = 0; i < V->n; ++i) V->v[i] = &empty_position;
+  V->act = (size_t*)malloc((nv + 2) * sizeof(size_t));
+  V->n_act = 0;
+  ef_pairing* small[64];
+  ef_pairing** vx = nv <= 64 ? small : (ef_pairing**)malloc(nv * sizeof(ef_pairing*));
+  size_t h = 0;
+  for (uint32_t k = 0; k < nv; ++k) {
+    const int p = vt[3 * k], t = vt[3 * k + 1], l = vt[3 * k + 2];
+    const size_t pos = p == EF_SOURCE_START ? 0 : (p == EF_SINK_START ? V->n - 1 : 1 + (size_t)p);
+    if (V->v[pos] == &empty_position) { V->v[pos] = &heads[h++]; efl_init(V->v[pos]); V->act[V->n_act++] = pos; }
+    vx[k] = pairing_new(p, t, l);
+    efl_push_back(V->v[pos], vx[k]);
+  }
+  for (uint32_t k = 0; k < nv; ++k)
+    for (uint32_t e = first[k]; e < first[k + 1]; ++e) efl_push_back(vx[k]->adjs, vx[tgt[e]]);
+  if (vx != small) free(vx);
+  return V;
+}
+
 void ef_meg_free(ef_meg* V) {
   if (!V) return;
   EF_MEG_FOR_POS(V, i, 0, V->n) efl_clear(V->v[i], pairing_free);
@@ -421,6 +453,18 @@ ef_meg* ef_build_meg(const ef_seq* est, ef_backend* be, const ef_config* shared,
   bool too_complex;
   do {
     cfg.min_factor_len += (unsigned)*inc;
+    /* the device may already hold the finished graph of this pattern at these parameters (built
+     * right behind the pairings); bit 0 of its flags is build_meg's too_complex, bit 1 says the
+     * graph was beyond the device's limits and has to be built here */
+    const uint32_t* rec = be->meg ? (const uint32_t*)be->meg(be->self, est->seq, m, &cfg) : NULL;
+    if (rec && !(rec[2] & 2u)) {
+      too_complex = (rec[2] & 1u) != 0;
+      cfg.min_factor_len -= (unsigned)*inc;
+      if (too_complex && cfg.min_factor_len + *inc + 1 + 2 < m + 2) { ++*inc; continue; }
+      too_complex = false;
+      V = ef_meg_from_record(rec, m);
+      continue;
+    }
     ef_triple* tr = NULL; size_t ntr = 0;
     if (be->pairings(be->self, est->seq, m, cfg.min_factor_len, cfg.min_string_depth_rate, &tr, &ntr) != 0) {
       fprintf(stderr, "* FATAL pairing backend failed\n");

@@ -190,6 +190,11 @@ typedef struct shared {
   int n_pre;                                  /* 0 = no prefetch */
   size_t pre_lo[PRE_CHUNKS + 1];
   pgpu_pairing* pre_tri[PRE_CHUNKS]; uint64_t* pre_first[PRE_CHUNKS];
+  /* ... or, with the MEG stage on the device (the default), the finished graphs instead of the
+   * pairings: records in page-locked buffers that live as long as the session */
+  bool use_meg;
+  pgpu_meg_params meg_prm;
+  unsigned char* pre_meg[PRE_CHUNKS]; size_t pre_meg_cap[PRE_CHUNKS]; uint64_t* pre_meg_first[PRE_CHUNKS];
   size_t ready_entries;                       /* entries below this have their pairings (under mu) */
   pthread_cond_t ready_cv;
   bool kernel_timing;
@@ -259,10 +264,10 @@ static int fiber_dp(void* self, const ef_dp_req* q, ef_dp_res* res) {
 static int fiber_pairings(void* self, const char* pattern, size_t m, unsigned L, double rate, ef_triple** out, size_t* n) {
   fiber* f = (fiber*)self;
   const shared* sh = f->w->sh;
-  if (sh->n_pre && L == sh->in->cfg.min_factor_len && rate == sh->in->cfg.min_string_depth_rate &&
+  int c = 0;
+  if (sh->n_pre) while (f->cur_entry >= sh->pre_lo[c + 1]) ++c;
+  if (sh->n_pre && sh->pre_tri[c] && L == sh->in->cfg.min_factor_len && rate == sh->in->cfg.min_string_depth_rate &&
       pattern == sh->in->list[f->cur_entry]->seq) {
-    int c = 0;
-    while (f->cur_entry >= sh->pre_lo[c + 1]) ++c;
     const size_t e = f->cur_entry - sh->pre_lo[c];
     const uint64_t a = sh->pre_first[c][e], b = sh->pre_first[c][e + 1];
     ef_triple* t = (ef_triple*)malloc((size_t)(b - a + 1) * sizeof(ef_triple));
@@ -275,6 +280,20 @@ static int fiber_pairings(void* self, const char* pattern, size_t m, unsigned L,
   if (EF_TSAN) tsan_to(f->w->tsan_sched);
   ctx_switch(&f->ctx, &f->w->sched);
   return f->rc;
+}
+
+/* the device-built MEG of the entry being factorized, at the configured parameters */
+static const void* fiber_meg(void* self, const char* pattern, size_t m, const ef_config* cfg) {
+  (void)m;
+  fiber* f = (fiber*)self;
+  const shared* sh = f->w->sh;
+  if (!sh->use_meg || !sh->n_pre || cfg->min_factor_len != sh->in->cfg.min_factor_len ||
+      cfg->min_string_depth_rate != sh->in->cfg.min_string_depth_rate || pattern != sh->in->list[f->cur_entry]->seq)
+    return NULL;
+  int c = 0;
+  while (f->cur_entry >= sh->pre_lo[c + 1]) ++c;
+  if (!sh->pre_meg[c]) return NULL;
+  return sh->pre_meg[c] + sh->pre_meg_first[c][f->cur_entry - sh->pre_lo[c]];
 }
 
 /* room for n bytes of output text in the worker's current chunk */
@@ -358,7 +377,7 @@ static bool start_fiber(worker* w, int li) {
   }
   else { f = (fiber*)calloc(1, sizeof(fiber)); f->stack = (char*)malloc(sh->stack_size); }
   f->w = w; f->unit = u; f->state = F_RUNNABLE; f->lane = li;
-  f->be.self = f; f->be.pairings = fiber_pairings; f->be.dp = fiber_dp; f->be.dp_many = fiber_dp_many;
+  f->be.self = f; f->be.pairings = fiber_pairings; f->be.dp = fiber_dp; f->be.dp_many = fiber_dp_many; f->be.meg = fiber_meg;
   /* the stacks are plain heap blocks (no guard page): a sentinel at the low end tells an
    * overflow apart from everything else when the fibre is done */
   memcpy(f->stack, FIBER_SENTINEL, sizeof FIBER_SENTINEL);
@@ -760,7 +779,7 @@ struct ef_session {
   shared sh;
   pgpu_pairing_plan* pplan[PRE_CHUNKS];   /* all prepared sequences (both strands), resident in HBM */
   pthread_t pre_thread;
-  double pre_kernel_ms[6], pre_t0, pre_wall;
+  double pre_kernel_ms[6], pre_meg_ms, pre_t0, pre_wall;
   size_t nthreads;
   double load_s, index_s;
 };
@@ -857,6 +876,15 @@ ef_session* ef_session_open(int argc, char** argv) {
   sh->stack_size = env_size("PINTRON_FIBER_STACK_KB", 256) * 1024;
   sh->kernel_timing = env_flag("PINTRON_KERNEL_TIMING");
   sh->gen_len = strlen(in->gen->seq);
+  {
+    const char* gm = getenv("PINTRON_GPU_MEG");            /* 0: the graphs are built on the host from the pairings */
+    sh->use_meg = !(gm && gm[0] == '0' && gm[1] == '\0');
+    const ef_config* c = &in->cfg;
+    const pgpu_meg_params mp = { c->min_factor_len, c->min_intron_length, c->max_intron_length, c->max_pairings_in_MEG,
+                                 c->max_prefix_discarded_rate, c->max_suffix_discarded_rate, c->max_freq_shortest_pairing,
+                                 c->trans_red ? 1u : 0u, c->short_edge_comp ? 1u : 0u };
+    sh->meg_prm = mp;
+  }
   sh->n_lanes = (int)env_size("PINTRON_LANES", 4);
   if (sh->n_lanes > MAX_LANES) sh->n_lanes = MAX_LANES;
   s->load_s = t_loaded - t_start;
@@ -883,7 +911,33 @@ static void* prefetch_main(void* arg) {
   pgpu_pairing_params prm = { s->in.cfg.min_factor_len, 0, s->in.cfg.min_string_depth_rate };
   for (int c = 0; c < sh->n_pre; ++c) {
     int prc = pgpu_pairing_plan_run(s->ctx0, s->pplan[c], &prm);
-    if (prc == PGPU_OK) {
+    bool have_meg = false;
+    if (prc == PGPU_OK && sh->use_meg) {
+      /* the graphs are built where the pairings lie; only the finished records cross PCIe */
+      const int mrc = pgpu_pairing_plan_run_meg(s->ctx0, s->pplan[c], &sh->meg_prm);
+      if (mrc == PGPU_ENOSYS) sh->use_meg = false;           /* a library without the MEG stage */
+      else if (mrc != PGPU_OK) prc = mrc;
+      else {
+        const size_t bytes = (size_t)pgpu_pairing_plan_meg_bytes(s->pplan[c]);
+        const size_t entries = sh->pre_lo[c + 1] - sh->pre_lo[c];
+        if (bytes > sh->pre_meg_cap[c] || !sh->pre_meg[c]) {
+          if (sh->pre_meg[c]) pgpu_host_free(s->ctx0, sh->pre_meg[c]);
+          sh->pre_meg[c] = NULL;
+          sh->pre_meg_cap[c] = bytes + bytes / 8 + 4096;
+          void* q = NULL;
+          if (pgpu_host_alloc(s->ctx0, sh->pre_meg_cap[c], &q) == PGPU_OK) sh->pre_meg[c] = (unsigned char*)q;
+        }
+        if (!sh->pre_meg_first[c]) {
+          void* q = NULL;
+          if (pgpu_host_alloc(s->ctx0, (entries + 1) * sizeof(uint64_t), &q) == PGPU_OK) sh->pre_meg_first[c] = (uint64_t*)q;
+        }
+        if (!sh->pre_meg[c] || !sh->pre_meg_first[c]) prc = PGPU_ENOMEM;
+        else prc = pgpu_pairing_plan_fetch_meg(s->ctx0, s->pplan[c], sh->pre_meg[c], sh->pre_meg_cap[c], sh->pre_meg_first[c]);
+        have_meg = prc == PGPU_OK;
+        s->pre_meg_ms += pgpu_pairing_plan_meg_ms(s->pplan[c]);
+      }
+    }
+    if (prc == PGPU_OK && !have_meg) {
       const size_t cnt = (size_t)pgpu_pairing_plan_count(s->pplan[c]);
       sh->pre_tri[c] = (pgpu_pairing*)malloc((cnt + 1) * sizeof(pgpu_pairing));
       sh->pre_first[c] = (uint64_t*)malloc((sh->pre_lo[c + 1] - sh->pre_lo[c] + 1) * sizeof(uint64_t));
@@ -908,6 +962,7 @@ int ef_session_step(ef_session* s, ef_sched_stats* stats_out) {
   for (int c = 0; c < PRE_CHUNKS; ++c) { free(sh->pre_tri[c]); free(sh->pre_first[c]); sh->pre_tri[c] = NULL; sh->pre_first[c] = NULL; }
   sh->next_unit = 0; sh->failed = 0; sh->ready_entries = 0;
   memset(s->pre_kernel_ms, 0, sizeof s->pre_kernel_ms);
+  s->pre_meg_ms = 0;
   s->pre_t0 = t0; s->pre_wall = 0;
   if (sh->n_pre) pthread_create(&s->pre_thread, NULL, prefetch_main, s);
   const double t1 = now_s();
@@ -960,6 +1015,16 @@ int ef_session_step(ef_session* s, ef_sched_stats* stats_out) {
         ks.algo_bytes = k == 0 ? positions * lg * 8ull : pairs * 12ull;
       }
       if (ks.ms > 0) kstat_add(&st, &ks);
+    }
+    if (s->pre_meg_ms > 0) {
+      ef_kernel_stat ks; memset(&ks, 0, sizeof ks);
+      snprintf(ks.name, sizeof ks.name, "meg_build+emit");
+      ks.ms = s->pre_meg_ms; ks.launches = (size_t)sh->n_pre; ks.jobs = s->in.n;
+      /* algorithmic bytes: the pairings read (12 B each) and the records written */
+      unsigned long long pairs = 0, rec = 0;
+      for (int c = 0; c < sh->n_pre; ++c) { pairs += pgpu_pairing_plan_count(s->pplan[c]); rec += pgpu_pairing_plan_meg_bytes(s->pplan[c]); }
+      ks.algo_bytes = pairs * 12ull + rec;
+      kstat_add(&st, &ks);
     }
   }
   st.load_s = s->load_s; st.index_s = s->index_s; st.prefetch_s = s->pre_wall; st.workers_s = now_s() - t1;
@@ -1043,6 +1108,8 @@ void ef_session_close(ef_session* s) {
   free(sh->units);
   for (int c = 0; c < PRE_CHUNKS; ++c) {
     free(sh->pre_tri[c]); free(sh->pre_first[c]);
+    if (sh->pre_meg[c]) pgpu_host_free(s->ctx0, sh->pre_meg[c]);
+    if (sh->pre_meg_first[c]) pgpu_host_free(s->ctx0, sh->pre_meg_first[c]);
     if (s->pplan[c]) pgpu_pairing_plan_destroy(s->ctx0, s->pplan[c]);
   }
   for (int k = 0; k < sh->svc.n_threads; ++k) pgpu_destroy(sh->svc.threads[k].ctx);

@@ -127,6 +127,8 @@ typedef struct { int32_t p, t, l; } ef_triple;
 /* vertex set from the pairing triples of one pattern (already filtered and ordered as
  * build_vertex_set leaves them, src/max-emb-graph.c:218-392) */
 ef_meg* ef_meg_from_pairings(const ef_triple* tr, size_t n_tr, size_t pattern_len);
+/* the same structure from a device-built MEG record (vertices in position-list order + CSR) */
+ef_meg* ef_meg_from_record(const void* rec, size_t pattern_len);
 void ef_meg_free(ef_meg* V);
 void ef_build_edge_set(ef_meg* V, const ef_config* cfg);               /* src/max-emb-graph.c:650 */
 void ef_simplify_meg(ef_meg* V, const ef_config* cfg);                 /* src/meg-simplification.c:314 */
@@ -233,6 +235,10 @@ typedef struct ef_backend {
   /* n dynamic programs that do not depend on each other, answered together (one suspension of the
    * EST instead of n); may be NULL, then ef_dp_many() asks one by one */
   int (*dp_many)(void* self, const ef_dp_req* reqs, ef_dp_res* res, size_t n);
+  /* the finished MEG of `pattern` under `cfg`, when the backend has already built it on the
+   * device behind the pairings (record layout: include/pintron_gpu.h, pgpu_pairing_plan_run_meg);
+   * NULL (or a NULL hook) = not available, the caller builds the graph from the pairings */
+  const void* (*meg)(void* self, const char* pattern, size_t m, const ef_config* cfg);
 } ef_backend;
 
 static inline int ef_dp_many(ef_backend* be, const ef_dp_req* reqs, ef_dp_res* res, size_t n) {

@@ -24,8 +24,15 @@ static int oracle_pairings(void* self, const char* pattern, size_t m, unsigned L
   return 0;
 }
 
+/* ESTFACT_CHECK_DIMS=1: the largest operands per DP kind, to stderr (what the device limits of
+ * include/pintron_gpu.h have to cover on real inputs) */
+static size_t dim_max[8][2];
 static int oracle_dp_impl(void* self, const ef_dp_req* q, ef_dp_res* r);
 static int oracle_dp(void* self, const ef_dp_req* q, ef_dp_res* r) {
+  if ((unsigned)q->kind < 8) {
+    if (q->la > dim_max[q->kind][0]) dim_max[q->kind][0] = q->la;
+    if (q->lb > dim_max[q->kind][1]) dim_max[q->kind][1] = q->lb;
+  }
   const double t0 = now_s();
   const int rc = oracle_dp_impl(self, q, r);
   backend_s += now_s() - t0;
@@ -80,6 +87,8 @@ static void close_oracle(ef_backend* be) { orc_index_destroy((orc_index*)be->sel
 int main(int argc, char** argv) {
   const double t0 = now_s();
   const int rc = ef_run(argc, argv, open_oracle, close_oracle);
+  if (getenv("ESTFACT_CHECK_DIMS"))
+    for (int k = 0; k < 8; ++k) if (dim_max[k][0] || dim_max[k][1]) fprintf(stderr, "dims: kind %d max a_len %zu max b_len %zu\n", k, dim_max[k][0], dim_max[k][1]);
   if (getenv("ESTFACT_CHECK_TIMING")) fprintf(stderr, "timing: total %.3f s, oracle backend %.3f s, host logic %.3f s\n", now_s() - t0, backend_s, now_s() - t0 - backend_s);
   return rc;
 }

@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include "../../include/pintron_gpu.h"
+#include "../../pintron_amd/host/estfact.h"     /* the host's own MEG routines build the stand-in's records */
 #include "../../oracle/dp_oracle.h"
 #include "../../oracle/pairing_oracle.h"
 
@@ -17,7 +18,8 @@ uint64_t orc_dp_batch(const pgpu_dp_job* jobs, size_t n, const char* arena, cons
 struct pgpu_ctx { char err[64]; };
 struct pgpu_index { orc_index* ix; char* gen; size_t len; };
 struct pgpu_dp_plan { pgpu_dp_job* jobs; size_t n; char* arena; const pgpu_index* idx; pgpu_dp_result* res; char* strs; size_t strs_bytes; };
-struct pgpu_pairing_plan { const pgpu_index* idx; char* pats; uint64_t* off; size_t n; int32_t* out; uint64_t* first; size_t cnt; };
+struct pgpu_pairing_plan { const pgpu_index* idx; char* pats; uint64_t* off; size_t n; int32_t* out; uint64_t* first; size_t cnt;
+                           unsigned char* meg; uint64_t* meg_first; size_t meg_bytes; };
 
 int pgpu_init(int device, pgpu_ctx** ctx) { (void)device; *ctx = (pgpu_ctx*)calloc(1, sizeof(pgpu_ctx)); return PGPU_OK; }
 int pgpu_destroy(pgpu_ctx* ctx) { free(ctx); return PGPU_OK; }
@@ -71,7 +73,84 @@ int pgpu_pairing_plan_fetch(pgpu_ctx* ctx, pgpu_pairing_plan* p, pgpu_pairing* o
   memcpy(first, p->first, (p->n + 1) * sizeof(uint64_t));
   return PGPU_OK;
 }
-int pgpu_pairing_plan_destroy(pgpu_ctx* ctx, pgpu_pairing_plan* p) { (void)ctx; free(p->pats); free(p->off); free(p->out); free(p->first); free(p); return PGPU_OK; }
+int pgpu_pairing_plan_destroy(pgpu_ctx* ctx, pgpu_pairing_plan* p) { (void)ctx; free(p->pats); free(p->off); free(p->out); free(p->first); free(p->meg); free(p->meg_first); free(p); return PGPU_OK; }
+
+/* MEG stage of the stand-in: the host's own (reference-checked) MEG code, serialised in the record
+ * layout of include/pintron_gpu.h.  PINTRON_FAKE_NO_MEG=1 answers PGPU_ENOSYS instead (a library
+ * without the stage); PINTRON_FAKE_MEG_LIMIT=<n> flags graphs with more vertices as unavailable. */
+int pgpu_pairing_plan_run_meg(pgpu_ctx* ctx, pgpu_pairing_plan* p, const pgpu_meg_params* mp) {
+  (void)ctx;
+  if (getenv("PINTRON_FAKE_NO_MEG")) return PGPU_ENOSYS;
+  if (getenv("PINTRON_FAKE_CACHE") && p->meg) return PGPU_OK;
+  const char* lim = getenv("PINTRON_FAKE_MEG_LIMIT");
+  const size_t max_v = lim ? (size_t)atol(lim) : PGPU_MEG_MAX_VERTICES;
+  ef_config cfg; memset(&cfg, 0, sizeof cfg);
+  cfg.min_factor_len = mp->min_factor_len; cfg.min_intron_length = mp->min_intron_length; cfg.max_intron_length = mp->max_intron_length;
+  cfg.max_pairings_in_MEG = mp->max_pairings_in_MEG; cfg.max_prefix_discarded_rate = mp->max_prefix_discarded_rate;
+  cfg.max_suffix_discarded_rate = mp->max_suffix_discarded_rate; cfg.max_freq_shortest_pairing = mp->max_freq_shortest_pairing;
+  cfg.trans_red = mp->trans_red != 0; cfg.short_edge_comp = mp->short_edge_comp != 0;
+  free(p->meg); free(p->meg_first);
+  size_t cap = 1 << 16, len = 0;
+  p->meg = (unsigned char*)malloc(cap);
+  p->meg_first = (uint64_t*)malloc((p->n + 1) * sizeof(uint64_t));
+  for (size_t i = 0; i < p->n; ++i) {
+    p->meg_first[i] = len;
+    const size_t m = (size_t)(p->off[i + 1] - p->off[i]);
+    ef_meg* V = ef_meg_from_pairings((const ef_triple*)(p->out + 3 * p->first[i]), (size_t)(p->first[i + 1] - p->first[i]), m);
+    ef_build_edge_set(V, &cfg);
+    ef_simplify_meg(V, &cfg);
+    if (cfg.trans_red) ef_transitive_reduction(V);
+    bool complex = ef_is_too_complex_for_compaction(V);
+    if (!complex && cfg.short_edge_comp) ef_compact_short_edges(V, &cfg);
+    complex = complex || ef_is_too_complex(V, &cfg);
+    size_t tp, te;
+    ef_meg_stats(V, &tp, &te);
+    const bool unavailable = tp > max_v || tp > 255 || te > 60000;
+    const size_t bytes = unavailable ? 16 : ((16 + 12 * tp + 2 * (tp + 1) + te + 3) & ~(size_t)3);
+    if (len + bytes > cap) { cap = (len + bytes) * 2; p->meg = (unsigned char*)realloc(p->meg, cap); }
+    unsigned char* rec = p->meg + len;
+    memset(rec, 0, bytes);
+    uint32_t* head = (uint32_t*)rec;
+    if (unavailable) head[2] = PGPU_MEG_UNAVAILABLE;
+    else {
+      head[0] = (uint32_t)tp; head[1] = (uint32_t)te; head[2] = complex ? PGPU_MEG_TOO_COMPLEX : 0;
+      int32_t* vt = (int32_t*)(rec + 16);
+      uint16_t* first = (uint16_t*)(rec + 16 + 12 * tp);
+      unsigned char* tgt = rec + 16 + 12 * tp + 2 * (tp + 1);
+      int k = 0;
+      EF_MEG_FOR_POS(V, pos, 0, V->n) {
+        ef_iter it = efl_begin(V->v[pos]);
+        while (efi_has_next(&it)) { ef_pairing* q = (ef_pairing*)efi_next(&it); q->id = k; vt[3 * k] = q->p; vt[3 * k + 1] = q->t; vt[3 * k + 2] = q->l; ++k; }
+      }
+      uint32_t e = 0; k = 0;
+      EF_MEG_FOR_POS(V, pos, 0, V->n) {
+        ef_iter it = efl_begin(V->v[pos]);
+        while (efi_has_next(&it)) {
+          ef_pairing* q = (ef_pairing*)efi_next(&it);
+          first[k++] = (uint16_t)e;
+          ef_iter a = efl_begin(q->adjs);
+          while (efi_has_next(&a)) tgt[e++] = (unsigned char)((ef_pairing*)efi_next(&a))->id;
+        }
+      }
+      first[k] = (uint16_t)e;
+    }
+    ef_meg_free(V);
+    len += bytes;
+  }
+  p->meg_first[p->n] = len; p->meg_bytes = len;
+  return PGPU_OK;
+}
+uint64_t pgpu_pairing_plan_meg_bytes(const pgpu_pairing_plan* p) { return p->meg_bytes; }
+double pgpu_pairing_plan_meg_ms(const pgpu_pairing_plan* p) { (void)p; return 0.0; }
+int pgpu_pairing_plan_fetch_meg(pgpu_ctx* ctx, pgpu_pairing_plan* p, void* out, size_t cap, uint64_t* first) {
+  (void)ctx;
+  if (cap < p->meg_bytes) return PGPU_ENOSPC;
+  memcpy(out, p->meg, p->meg_bytes);
+  memcpy(first, p->meg_first, (p->n + 1) * sizeof(uint64_t));
+  return PGPU_OK;
+}
+int pgpu_host_alloc(pgpu_ctx* ctx, size_t bytes, void** out) { (void)ctx; *out = malloc(bytes ? bytes : 16); return *out ? PGPU_OK : PGPU_ENOMEM; }
+int pgpu_host_free(pgpu_ctx* ctx, void* q) { (void)ctx; free(q); return PGPU_OK; }
 int pgpu_pairings(pgpu_ctx* ctx, const pgpu_index* idx, const char* patterns, const uint64_t* off, size_t n, const pgpu_pairing_params* prm,
                   pgpu_pairing* out, size_t cap, uint64_t* first, size_t* n_out) {
   pgpu_pairing_plan* p; pgpu_pairing_plan_create(ctx, idx, patterns, off, n, &p);

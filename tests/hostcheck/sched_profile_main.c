@@ -8,6 +8,9 @@
 #include <time.h>
 #include "../../pintron_amd/host/ef_sched.h"
 
+extern int moncontrol(int);   /* gprof builds: sample the cached passes only */
+#pragma weak moncontrol
+
 static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
 static double cpu_s(void) { struct timespec t; clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
 
@@ -19,6 +22,7 @@ int main(int argc, char** argv) {
   if (!s) return 1;
   for (int p = 0; p < passes; ++p) {
     ef_sched_stats st;
+    if (moncontrol) moncontrol(p > 0);
     const double t0 = now_s(), c0 = cpu_s();
     if (ef_session_step(s, &st) != 0) return 1;
     fprintf(stderr, "pass %d: %.3f s wall, %.3f s cpu, %zu ESTs, %zu DP jobs in %zu batches -> %.1f us cpu per EST\n",

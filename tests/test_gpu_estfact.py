@@ -25,7 +25,8 @@ def exe():
 
 @pytest.mark.parametrize("env", [{}, {"PINTRON_ESTFACT_MODE": "direct"}, {"PINTRON_THREADS": "2", "PINTRON_FIBERS": "5"},
                                  {"PINTRON_LANES": "1"}, {"PINTRON_LANES": "4", "PINTRON_SERVICES": "2", "PINTRON_FIBERS": "8"},
-                                 {"PINTRON_NO_PREFETCH": "1", "PINTRON_THREADS": "3"}])
+                                 {"PINTRON_NO_PREFETCH": "1", "PINTRON_THREADS": "3"},
+                                 {"PINTRON_GPU_MEG": "0"}])
 def test_ambn_golden(exe, tmp_path, env):
     for f in ("genomic.txt", "ests.txt"):
         shutil.copy(os.path.join(GOLD, f), tmp_path)

@@ -37,7 +37,13 @@ def run(exe, cwd, env=None):
                                        ("estfact_sched_check", {"PINTRON_THREADS": "4", "PINTRON_FIBERS": "7"}),
                                        ("estfact_sched_check", {"PINTRON_LANES": "1", "PINTRON_THREADS": "2"}),
                                        ("estfact_sched_check", {"PINTRON_LANES": "4", "PINTRON_SERVICES": "2", "PINTRON_FIBERS": "8"}),
-                                       ("estfact_sched_check", {"PINTRON_ESTFACT_MODE": "direct"})])
+                                       ("estfact_sched_check", {"PINTRON_ESTFACT_MODE": "direct"}),
+                                       # MEG stage of the C-ABI: graphs beyond the device limits come back
+                                       # "unavailable" and are built on the host; a library without the stage;
+                                       # the stage switched off
+                                       ("estfact_sched_check", {"PINTRON_FAKE_MEG_LIMIT": "6", "PINTRON_THREADS": "2"}),
+                                       ("estfact_sched_check", {"PINTRON_FAKE_NO_MEG": "1", "PINTRON_THREADS": "2"}),
+                                       ("estfact_sched_check", {"PINTRON_GPU_MEG": "0", "PINTRON_THREADS": "2"})])
 def test_ambn_outputs_match_reference(bins, tmp_path, which, env):
     for f in ("genomic.txt", "ests.txt"):
         shutil.copy(os.path.join(GOLD, f), tmp_path)

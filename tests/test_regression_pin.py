@@ -23,7 +23,8 @@ def check_case(case, exe, tmp_path, env=None):
     RL.stage_inputs(case, str(tmp_path))
     e = dict(os.environ)
     e.update(env or {})
-    subprocess.run([exe], cwd=tmp_path, env=e, check=True, stderr=subprocess.DEVNULL)
+    run = subprocess.run([exe], cwd=tmp_path, env=e, stderr=subprocess.PIPE, text=True, errors="replace")
+    assert run.returncode == 0, "est-fact failed (%d): %s" % (run.returncode, run.stderr[-1500:])
     raw = (tmp_path / "raw-multifasta-out.txt").read_bytes()
     assert raw == RL.expected_raw(case), "raw-multifasta-out.txt differs from the reference object code's"
     if not RL.have_stages():
