@@ -128,6 +128,10 @@ typedef struct {
  *                                  meg_write prints (src/io-meg.c:161-170); [0] source, [last] sink
  *   (n_vertices + 1) x u16         first edge of each vertex (CSR)
  *   n_edges x u8                   target vertex, in the order of the reference's adjacency lists
+ *   (pad to 4) u32 meg_text_len, u32 edges_text_len, then the two texts est-fact prints for this
+ *                                  graph: meg_write's "(p,t,l)" lines, "#adj#", "i-j" lines
+ *                                  (src/io-meg.c:146-190) and the lines of
+ *                                  add_intronic_edges_to_file (src/max-emb-graph.c:677-699)
  * run_meg builds the records of all patterns (after pgpu_pairing_plan_run with the same
  * min_factor_len); meg_bytes = total size; fetch_meg copies them and the n_pat + 1 byte offsets. */
 int pgpu_pairing_plan_run_meg(pgpu_ctx* ctx, pgpu_pairing_plan* plan, const pgpu_meg_params* params);

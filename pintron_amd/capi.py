@@ -47,6 +47,8 @@ EXPORTS = [
     "pgpu_pairing_plan_create", "pgpu_pairing_plan_run", "pgpu_pairing_plan_count",
     "pgpu_pairing_plan_positions", "pgpu_pairing_plan_kernel_ms", "pgpu_pairing_plan_fetch",
     "pgpu_pairing_plan_destroy",
+    "pgpu_pairing_plan_run_meg", "pgpu_pairing_plan_meg_bytes", "pgpu_pairing_plan_fetch_meg",
+    "pgpu_pairing_plan_meg_ms", "pgpu_host_alloc", "pgpu_host_free",
     "pgpu_dp_plan_create", "pgpu_dp_plan_create_parts", "pgpu_dp_plan_launch", "pgpu_dp_plan_sync",
     "pgpu_dp_plan_string_bytes", "pgpu_dp_plan_fetch", "pgpu_dp_plan_destroy",
     "pgpu_dp_plan_results_to_device",
@@ -80,6 +82,14 @@ def lib():
         L.pgpu_index_build.argtypes = [vp, C.c_char_p, sz, C.POINTER(vp)]
         L.pgpu_index_destroy.argtypes = [vp, vp]
         L.pgpu_index_suffix_array.argtypes = [vp, vp, C.POINTER(C.c_uint32), sz]
+        L.pgpu_pairing_plan_run_meg.argtypes = [vp, vp, vp]
+        L.pgpu_pairing_plan_meg_bytes.argtypes = [vp]
+        L.pgpu_pairing_plan_meg_bytes.restype = u64
+        L.pgpu_pairing_plan_meg_ms.argtypes = [vp]
+        L.pgpu_pairing_plan_meg_ms.restype = C.c_double
+        L.pgpu_pairing_plan_fetch_meg.argtypes = [vp, vp, vp, sz, C.POINTER(u64)]
+        L.pgpu_host_alloc.argtypes = [vp, sz, C.POINTER(vp)]
+        L.pgpu_host_free.argtypes = [vp, vp]
         L.pgpu_pairings.argtypes = [vp, vp, C.c_char_p, C.POINTER(u64), sz,
                                     C.POINTER(PairingParams), C.POINTER(Pairing), sz,
                                     C.POINTER(u64), C.POINTER(sz)]
@@ -163,8 +173,33 @@ class Index:
             self.h = C.c_void_p()
 
 
+class MegParams(C.Structure):       # pgpu_meg_params; defaults = src/options.ggo:94-370
+    _fields_ = [("min_factor_len", C.c_uint32), ("min_intron_length", C.c_int32), ("max_intron_length", C.c_int32),
+                ("max_pairings_in_MEG", C.c_uint32), ("max_prefix_discarded_rate", C.c_double),
+                ("max_suffix_discarded_rate", C.c_double), ("max_freq_shortest_pairing", C.c_double),
+                ("trans_red", C.c_uint32), ("short_edge_comp", C.c_uint32)]
+
+
+def parse_meg_record(rec: bytes):
+    """One record of pgpu_pairing_plan_fetch_meg -> dict(flags, vertices [(p,t,l)], adj [[targets]],
+    meg_text, edges_text); vertices/adj are empty for an unavailable record."""
+    import struct
+    nv, ne, flags, _ = struct.unpack_from("<4I", rec, 0)
+    if flags & 2:
+        return dict(flags=flags, vertices=[], adj=[], meg_text=b"", edges_text=b"")
+    verts = [struct.unpack_from("<3i", rec, 16 + 12 * k) for k in range(nv)]
+    first = struct.unpack_from("<%dH" % (nv + 1), rec, 16 + 12 * nv)
+    base = 16 + 12 * nv + 2 * (nv + 1)
+    adj = [list(rec[base + first[k]:base + first[k + 1]]) for k in range(nv)]
+    graph = (base + ne + 3) & ~3
+    ml, el = struct.unpack_from("<2I", rec, graph)
+    return dict(flags=flags, vertices=verts, adj=adj, meg_text=rec[graph + 8:graph + 8 + ml],
+                edges_text=rec[graph + 8 + ml:graph + 8 + ml + el])
+
+
 class PairingPlan:
-    """Patterns resident in HBM; run() = all pairing kernels; fetch() -> (triples[n,3], first[n_pat+1])."""
+    """Patterns resident in HBM; run() = all pairing kernels; fetch() -> (triples[n,3], first[n_pat+1]);
+    run_meg()/fetch_meg() = the MEG stage behind the pairings."""
     STAGES = ["locate", "chain", "count+scan", "fill", "cross+scan", "emit"]
 
     def __init__(self, ctx: Context, index: Index, patterns):
@@ -195,6 +230,26 @@ class PairingPlan:
             self.ctx.h, self.h, out.ctypes.data_as(C.POINTER(Pairing)), n,
             first.ctypes.data_as(C.POINTER(C.c_uint64))))
         return out[:n], first
+
+    def run_meg(self, min_factor_len=15, min_intron_length=40, max_intron_length=0, max_pairings_in_MEG=80,
+                max_prefix_discarded_rate=0.6, max_suffix_discarded_rate=0.6, max_freq_shortest_pairing=0.4,
+                trans_red=True, short_edge_comp=True):
+        prm = MegParams(min_factor_len, min_intron_length, max_intron_length, max_pairings_in_MEG,
+                        max_prefix_discarded_rate, max_suffix_discarded_rate, max_freq_shortest_pairing,
+                        int(trans_red), int(short_edge_comp))
+        self.ctx.check(self.ctx.L.pgpu_pairing_plan_run_meg(self.ctx.h, self.h, C.byref(prm)))
+        return self.ctx.L.pgpu_pairing_plan_meg_bytes(self.h)
+
+    def fetch_meg(self):
+        """list of raw records (bytes), one per pattern"""
+        import numpy as np
+        n = self.ctx.L.pgpu_pairing_plan_meg_bytes(self.h)
+        out = np.zeros(max(n, 1), dtype=np.uint8)
+        first = np.zeros(self.n_pat + 1, dtype=np.uint64)
+        self.ctx.check(self.ctx.L.pgpu_pairing_plan_fetch_meg(
+            self.ctx.h, self.h, out.ctypes.data_as(C.c_void_p), n, first.ctypes.data_as(C.POINTER(C.c_uint64))))
+        raw = out.tobytes()
+        return [raw[int(first[i]):int(first[i + 1])] for i in range(self.n_pat)]
 
     def close(self):
         if self.h:

@@ -335,7 +335,28 @@ struct Meg {
   }
 };
 
-// one thread = one pattern.  info[pat] = {n_vertices, n_edges, flags, record bytes}
+// ---- the text est-fact prints for a MEG (the device formats what it has built) -----------------
+__device__ __forceinline__ uint32_t dec_len(int32_t v) {               // strlen of printf("%d", v)
+  uint32_t u = v < 0 ? 0u - (uint32_t)v : (uint32_t)v, n = v < 0 ? 2u : 1u;
+  while (u >= 10u) { u /= 10u; ++n; }
+  return n;
+}
+__device__ __forceinline__ uint8_t* put_dec(uint8_t* w, int32_t v) {
+  uint32_t u = v < 0 ? 0u - (uint32_t)v : (uint32_t)v;
+  if (v < 0) *w++ = '-';
+  uint8_t tmp[10]; int k = 0;
+  do { tmp[k++] = (uint8_t)('0' + u % 10u); u /= 10u; } while (u);
+  while (k) *w++ = tmp[--k];
+  return w;
+}
+// the nine numbers of a meg-edges.txt line (add_intronic_edges_to_file, src/max-emb-graph.c:677-699)
+__device__ __forceinline__ void edge_fields(const MegScratch* S, int pv, int x, int32_t* v9) {
+  v9[0] = S->t[pv] + S->l[pv]; v9[1] = S->t[x]; v9[2] = S->p[pv] + S->l[pv]; v9[3] = S->p[x];
+  v9[4] = S->t[x] - S->t[pv] - S->l[pv]; v9[5] = S->p[x] - S->p[pv] - S->l[pv];
+  v9[6] = (S->t[x] - S->t[pv]) - (S->p[x] - S->p[pv]); v9[7] = S->l[pv]; v9[8] = S->l[x];
+}
+
+// one thread = one pattern.  info[pat] = {n_vertices, n_edges, flags, live vertices}
 __global__ __launch_bounds__(64)
 void meg_build_kernel(const pgpu_pairing* __restrict__ pairs, const unsigned long long* __restrict__ pair_first,
                       const unsigned long long* __restrict__ pat_off, uint32_t n_pat, pgpu_meg_params prm,
@@ -378,11 +399,31 @@ void meg_build_kernel(const pgpu_pairing* __restrict__ pairs, const unsigned lon
   // final numbering = position-list order (what meg_write prints, src/io-meg.c:161-170)
   for (int k = 0; k < M.no; ++k) M.S->idx_of[M.S->order[k]] = (uint8_t)k;
   info[pat] = make_uint4(tp, te, flags, (uint32_t)M.no);
-  const uint32_t bytes = 16 + 12 * tp + 2 * (tp + 1) + te;
-  rec_bytes[pat] = (bytes + 3u) & ~3u;
+  // text lengths: meg_write (src/io-meg.c:146-190) and add_intronic_edges_to_file
+  uint32_t meg_txt = 6, edge_txt = 0;                                   // "#adj#\n"
+  for (int k = 0; k < M.no; ++k) {
+    const int v = M.S->order[k];
+    meg_txt += 5 + dec_len(M.S->p[v]) + dec_len(M.S->t[v]) + dec_len(M.S->l[v]);      // "(%d,%d,%d)\n"
+    const bool inner = M.S->p[v] != SRC_START && M.S->p[v] != SINK_START;
+    for (int q = 0; q < M.S->nadj[v]; ++q) {
+      const int x = M.S->adj[v][q];
+      meg_txt += 2 + dec_len(k) + dec_len((int32_t)M.S->idx_of[x]);                    // "%d-%d\n"
+      if (inner && M.S->p[x] != SINK_START) {
+        int32_t v9[9];
+        edge_fields(M.S, v, x, v9);
+        edge_txt += 9;                                                                 // 8 blanks + newline
+        for (int f = 0; f < 9; ++f) edge_txt += dec_len(v9[f]);
+        if (v9[6] >= 50) edge_txt += 9;                                                // " intronic"
+      }
+    }
+  }
+  M.S->star[0] = ((unsigned long long)edge_txt << 32) | meg_txt;         // handed to the emit kernel
+  const uint32_t graph = (16 + 12 * tp + 2 * (tp + 1) + te + 3u) & ~3u;
+  rec_bytes[pat] = (graph + 8 + meg_txt + edge_txt + 3u) & ~3u;
 }
 
-// records, compacted: header (n_vertices, n_edges, flags, 0), vertices, CSR offsets (u16), targets (u8)
+// records, compacted: header (n_vertices, n_edges, flags, 0), vertices, CSR offsets (u16), targets
+// (u8), then the two texts
 __global__ __launch_bounds__(64)
 void meg_emit_kernel(uint32_t n_pat, const MegScratch* __restrict__ scratch, const uint4* __restrict__ info,
                      const unsigned long long* __restrict__ rec_off, uint8_t* __restrict__ out) {
@@ -406,6 +447,33 @@ void meg_emit_kernel(uint32_t n_pat, const MegScratch* __restrict__ scratch, con
     for (int q = 0; q < S->nadj[v]; ++q) tgt[e++] = S->idx_of[S->adj[v][q]];
   }
   first[no] = (uint16_t)e;
+  const uint32_t graph = (16 + 12 * h.x + 2 * (h.x + 1) + h.y + 3u) & ~3u;
+  const uint32_t meg_txt = (uint32_t)(S->star[0] & 0xFFFFFFFFull), edge_txt = (uint32_t)(S->star[0] >> 32);
+  uint32_t* tl = (uint32_t*)(rec + graph);
+  tl[0] = meg_txt; tl[1] = edge_txt;
+  uint8_t* w = rec + graph + 8;
+  for (int k = 0; k < no; ++k) {
+    const int v = S->order[k];
+    *w++ = '('; w = put_dec(w, S->p[v]); *w++ = ','; w = put_dec(w, S->t[v]); *w++ = ','; w = put_dec(w, S->l[v]); *w++ = ')'; *w++ = '\n';
+  }
+  *w++ = '#'; *w++ = 'a'; *w++ = 'd'; *w++ = 'j'; *w++ = '#'; *w++ = '\n';
+  for (int k = 0; k < no; ++k) {
+    const int v = S->order[k];
+    for (int q = 0; q < S->nadj[v]; ++q) { w = put_dec(w, k); *w++ = '-'; w = put_dec(w, (int32_t)S->idx_of[S->adj[v][q]]); *w++ = '\n'; }
+  }
+  for (int k = 0; k < no; ++k) {
+    const int v = S->order[k];
+    if (S->p[v] == SRC_START || S->p[v] == SINK_START) continue;
+    for (int q = 0; q < S->nadj[v]; ++q) {
+      const int x = S->adj[v][q];
+      if (S->p[x] == SINK_START) continue;
+      int32_t v9[9];
+      edge_fields(S, v, x, v9);
+      for (int f = 0; f < 9; ++f) { if (f) *w++ = ' '; w = put_dec(w, v9[f]); }
+      if (v9[6] >= 50) { const char* t = " intronic"; for (int c = 0; c < 9; ++c) *w++ = (uint8_t)t[c]; }
+      *w++ = '\n';
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -216,17 +216,28 @@ def run_sharded(directory, workdir, dist, rank, world, device, L=None, files=(0,
         shutil.copy(os.path.join(directory, "config.ini"), os.path.join(workdir, "config.ini"))
     with open(os.path.join(workdir, "ests.txt"), "wb") as f:
         f.write(b"".join(recs[lo:hi]))
-    texts = {}
+    texts = {k: b"" for k in files}
+    stats = {"ests": 0, "aligned": 0, "dp_jobs": 0}
+    error = None
     if hi > lo:
-        sess = Session(L, workdir)
-        st = sess.step()
-        for k in files:
-            texts[k] = sess.output(k)
-        stats = {"ests": hi - lo, "aligned": int(st.aligned), "dp_jobs": int(st.dp_jobs)}
-        sess.close()
-    else:
-        texts = {k: b"" for k in files}
-        stats = {"ests": 0, "aligned": 0, "dp_jobs": 0}
+        try:
+            sess = Session(L, workdir)
+            try:
+                st = sess.step()
+                for k in files:
+                    texts[k] = sess.output(k)
+                stats = {"ests": hi - lo, "aligned": int(st.aligned), "dp_jobs": int(st.dp_jobs)}
+            finally:
+                sess.close()
+        except Exception as e:      # noqa: BLE001 -- reported below, on every rank
+            error = e
+    # a rank that failed must not leave the others waiting in the gathers: agree first
+    import torch
+    ok = torch.tensor([0 if error else 1], dtype=torch.int32, device=device)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()) == 0:
+        raise RuntimeError("est-fact failed on rank %d: %s" % (rank, error) if error
+                           else "est-fact failed on another rank")
     for k in files:
         parts = gather_bytes(texts[k], dist, rank, world, device)
         if rank == 0:

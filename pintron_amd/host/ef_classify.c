@@ -5,6 +5,7 @@
  * unused here).  IEEE double arithmetic in the reference's operation order; the matrices below are
  * the reference's DATA (GetPWMfor* at :665-1100), each entry + 0.00001f as there. */
 #include <math.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <stdint.h>
 #include <string.h>
@@ -146,6 +147,45 @@ static double score5(const char* gen, int splice5, int k) {           /* GetScor
   return motif_score(win, k);
 }
 
+/* ---- per-gene tables ------------------------------------------------------------------------------
+ * bps_memo[E]   verdict of ExistsGoodBPS... for an intron that ends at E (exclusive) and is at least
+ *               30 long: the scan looks at the windows that start 30..14 bases before E only, all of
+ *               them inside the intron, so the verdict is a property of E.
+ * score5_tab    score5(gen, start, k) for the four 5' matrices k = 2..5 at every start.
+ * Both are filled with the very functions the per-intron path calls, over ranges of positions on a
+ * few threads. */
+typedef struct { ef_seq* gs; size_t lo, hi, n; } prep_range;
+static void* prepare_range(void* arg) {
+  prep_range* r = (prep_range*)arg;
+  const char* gen = r->gs->seq;
+  for (size_t e = r->lo; e < r->hi; ++e) {
+    if (e >= 30) r->gs->bps_memo[e] = good_bps(gen + (e - 30), 30, 14, 30) != -1 ? 2 : 1;
+    for (int k = 0; k < 4; ++k) r->gs->score5_tab[k][e] = score5(gen, (int)e, 2 + k);
+  }
+  return NULL;
+}
+
+void ef_classify_prepare(ef_seq* gs) {
+  load_all();
+  const size_t n = strlen(gs->seq);
+  if (!gs->bps_memo) gs->bps_memo = (unsigned char*)calloc(n + 2, 1);
+  for (int k = 0; k < 4; ++k) { free(gs->score5_tab[k]); gs->score5_tab[k] = (double*)malloc((n + 2) * sizeof(double)); }
+  gs->score5_len = n + 1;
+  enum { T = 8 };
+  prep_range rg[T]; pthread_t th[T]; bool started[T];
+  for (int t = 0; t < T; ++t) {
+    rg[t].gs = gs; rg[t].n = n; rg[t].lo = (n + 1) * (size_t)t / T; rg[t].hi = (n + 1) * (size_t)(t + 1) / T;
+    started[t] = n >= 4096 && pthread_create(&th[t], NULL, prepare_range, &rg[t]) == 0;
+    if (!started[t]) prepare_range(&rg[t]);
+  }
+  for (int t = 0; t < T; ++t) if (started[t]) pthread_join(th[t], NULL);
+}
+
+static inline double score5_at(const ef_seq* gs, int start, int k) {
+  if (gs->score5_tab[0] && start >= 0 && (size_t)start < gs->score5_len) return gs->score5_tab[k - 2][start];
+  return score5(gs->seq, start, k);
+}
+
 /* classify_genomic_intron_start_end (:95-229), class only.  The reference copies the intron
  * (real_substring); we read it in place: intron = gen[start .. start+il) */
 static int classify_uncached(const ef_seq* gs, int start, int end);
@@ -192,22 +232,22 @@ static int classify_uncached(const ef_seq* gs, int start, int end) {
   const bool ag = !strcmp(p3, "ag") || !strcmp(p3, "AG");
   if ((!strcmp(p5, "gt") || !strcmp(p5, "GT")) && ag) {
     pt_type = 0;
-    u12 = score5(gen, start, 2);
-    u2 = score5(gen, start, 4);
+    u12 = score5_at(gs, start, 2);
+    u2 = score5_at(gs, start, 4);
   } else if ((!strcmp(p5, "gc") || !strcmp(p5, "GC")) && ag) {
     pt_type = 0;
-    u2 = score5(gen, start, 5);
-    u12 = score5(gen, start, 2);
-    t = score5(gen, start, 3); if (t > u12) u12 = t;
+    u2 = score5_at(gs, start, 5);
+    u12 = score5_at(gs, start, 2);
+    t = score5_at(gs, start, 3); if (t > u12) u12 = t;
   } else if ((!strcmp(p5, "at") || !strcmp(p5, "AT")) && (!strcmp(p3, "ac") || !strcmp(p3, "AC"))) {
-    u12 = score5(gen, start, 3);
-    u2 = score5(gen, start, 4);
-    t = score5(gen, start, 5); if (t > u2) u2 = t;
+    u12 = score5_at(gs, start, 3);
+    u2 = score5_at(gs, start, 4);
+    t = score5_at(gs, start, 5); if (t > u2) u2 = t;
   } else {
-    u12 = score5(gen, start, 2);
-    t = score5(gen, start, 3); if (t > u12) u12 = t;
-    u2 = score5(gen, start, 4);
-    t = score5(gen, start, 5); if (t > u2) u2 = t;
+    u12 = score5_at(gs, start, 2);
+    t = score5_at(gs, start, 3); if (t > u12) u12 = t;
+    u2 = score5_at(gs, start, 4);
+    t = score5_at(gs, start, 5); if (t > u2) u2 = t;
   }
   int type = 2;
   if (bps != -1) type = u12 > u2 ? 0 : 1;

@@ -1,8 +1,8 @@
 /* compute_est_fact and the est-fact process flow.
  * Behaviour follows src/compute-est-fact.c:192-293 and src/main-est-fact.c:90-339 of the reference
  * (same files in cwd, same record formats, same order of ESTs and of the reverse-complement
- * siblings).  The wall-clock timeout of the reference (src/my_time.c:177-198) is not reproduced:
- * nothing here depends on time. */
+ * siblings).  The wall-clock timeout of the reference (src/my_time.c:177-198) is a deterministic
+ * work budget here (ef_fact.c); its retry branch is the reference's. */
 #include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
@@ -93,39 +93,50 @@ void ef_write_factorization_records(const ef_seq* gen, const ef_est* e, ef_sink*
 ef_est* ef_compute_est_fact(const ef_seq* gen, const ef_seq* est, ef_backend* be, const ef_config* cfg,
                             const ef_side_files* side) {
   size_t inc = 0, prev_tp = 0, prev_te = 0, tp, te;
-  ef_meg* V = NULL;
-  bool same;
+  ef_est* fe = NULL;
+  bool expired;
   do {
-    V = ef_build_meg(est, be, cfg, &inc);
-    ef_meg_stats(V, &tp, &te);
-    same = prev_tp > 2 && prev_te > 0 && (prev_tp <= tp || prev_te <= te);
-    if (same) { ++inc; ef_meg_free(V); }
-  } while (same);
-  ef_est* fe = ef_get_est_factorizations(est, V, cfg, gen, be);
-  ef_refine_est_factorizations(gen, fe, cfg, be);
-  ef_remove_factorizations_with_very_small_exons(fe->factorizations);
-  if (!efl_empty(fe->factorizations)) ef_remove_duplicated_factorizations(fe->factorizations);
-  if (side && side->fmeg) {                                   /* report_meg (:73-88) */
-    ef_sink_puts(side->fmeg, "\n\n***********\n\n");
-    ef_write_single_est_info(side->fmeg, est);
-    ef_meg_write(side->fmeg, V);
-    if (side->fmeg->f) fflush(side->fmeg->f);
-  }
-  if (!efl_empty(fe->factorizations) && side) {
-    if (side->fintronic) {
-      ef_sink_puts(side->fintronic, ">"); ef_sink_puts(side->fintronic, est->id); ef_sink_puts(side->fintronic, "\n");
-      ef_intronic_edges_write(side->fintronic, V);
+    ef_meg* V = NULL;
+    bool same;
+    do {
+      V = ef_build_meg(est, be, cfg, &inc);
+      ef_meg_stats(V, &tp, &te);
+      same = prev_tp > 2 && prev_te > 0 && (prev_tp <= tp || prev_te <= te);
+      if (same) { ++inc; ef_meg_free(V); }
+    } while (same);
+    prev_tp = tp; prev_te = te;
+    /* internal_get_EST_factorizations (:154-190); NULL = budget spent ("timeout expired") */
+    fe = ef_get_est_factorizations(est, V, cfg, gen, be);
+    expired = fe == NULL;
+    if (fe) {
+      ef_refine_est_factorizations(gen, fe, cfg, be);
+      ef_remove_factorizations_with_very_small_exons(fe->factorizations);
+      if (!efl_empty(fe->factorizations)) ef_remove_duplicated_factorizations(fe->factorizations);
     }
-    if (side->fpmeg) { ef_write_single_est_info(side->fpmeg, est); ef_meg_write(side->fpmeg, V); }
-    /* "<meg us> <composition us> <#factorizations>": the two timings are inherently not
-     * reproducible; written as 0 */
-    if (side->ftmeg) {
-      char line[48];
-      snprintf(line, sizeof line, "0 0 %zu\n", efl_size(fe->factorizations));
-      ef_sink_puts(side->ftmeg, line);
+    const bool aligned = fe && !efl_empty(fe->factorizations);
+    if ((!expired || aligned) && side && side->fmeg) {            /* report_meg (:73-88) */
+      ef_sink_puts(side->fmeg, "\n\n***********\n\n");
+      ef_write_single_est_info(side->fmeg, est);
+      ef_meg_write(side->fmeg, V);
+      if (side->fmeg->f) fflush(side->fmeg->f);
     }
-  }
-  ef_meg_free(V);
+    if (aligned && side) {
+      if (side->fintronic) {
+        ef_sink_puts(side->fintronic, ">"); ef_sink_puts(side->fintronic, est->id); ef_sink_puts(side->fintronic, "\n");
+        ef_intronic_edges_write(side->fintronic, V);
+      }
+      if (side->fpmeg) { ef_write_single_est_info(side->fpmeg, est); ef_meg_write(side->fpmeg, V); }
+      /* "<meg us> <composition us> <#factorizations>": the two timings are inherently not
+       * reproducible; written as 0 */
+      if (side->ftmeg) {
+        char line[48];
+        snprintf(line, sizeof line, "0 0 %zu\n", efl_size(fe->factorizations));
+        ef_sink_puts(side->ftmeg, line);
+      }
+    }
+    if (expired) ++inc;                                          /* :277-283: longer factors, again */
+    ef_meg_free(V);
+  } while (expired);
   return fe;
 }
 
@@ -165,6 +176,7 @@ int ef_load_genomic(int argc, char** argv, ef_inputs* in) {
   ef_parse_genomic_header(in->gen);
   if (ef_ntails_removal(in->gen) != 0) { fprintf(stderr, "* FATAL The sequence is only composed by Ns.\n"); return 1; }
   ef_seq_index_kmers(in->gen);
+  ef_classify_prepare(in->gen);
   return 0;
 }
 

@@ -182,9 +182,30 @@ static int maximality_relation(ef_list* add, ef_list* cmp) {
   return check ? 2 : 1;
 }
 
-/* get_subtree_embeddings (:597-762), memoised on the vertex */
-static ef_list* subtree_embeddings(ef_pairing* root, const ef_config* cfg, const char* GEN) {
+/* The reference bounds the enumeration with a wall-clock timeout (max_single_factorization_time,
+ * checked at :626-629 on entering a subtree that is not memoised yet and at :706-711 every 1024
+ * candidate embeddings); when it expires get_subtree_embeddings returns NULL and compute_est_fact
+ * retries with a longer minimum factor (src/compute-est-fact.c:250-286).  Nothing here may depend
+ * on time, so the same two places count WORK instead: one unit per subtree entered and per
+ * candidate embedding compared.  The budget is max_single_factorization_time x EF_WORK_PER_SECOND
+ * (what one host core gets through per second of this loop, rounded down to a power of ten);
+ * PINTRON_WORK_BUDGET=<units> overrides it (tests).  The largest use of a run is reported by
+ * ef_work_high_water(). */
+#define EF_WORK_PER_SECOND 1000000ull
+typedef struct { unsigned long long used, limit; } ef_work;
+static unsigned long long work_high_water;
+unsigned long long ef_work_high_water(void) { return __atomic_load_n(&work_high_water, __ATOMIC_RELAXED); }
+static unsigned long long work_limit(const ef_config* cfg) {
+  static unsigned long long forced = ~0ull;
+  if (forced == ~0ull) { const char* e = getenv("PINTRON_WORK_BUDGET"); forced = e && atoll(e) > 0 ? (unsigned long long)atoll(e) : 0ull; }
+  if (forced) return forced;
+  return cfg->max_single_factorization_time ? (unsigned long long)cfg->max_single_factorization_time * EF_WORK_PER_SECOND : ~0ull;
+}
+
+/* get_subtree_embeddings (:597-762), memoised on the vertex; NULL = the work budget is spent */
+static ef_list* subtree_embeddings(ef_pairing* root, const ef_config* cfg, const char* GEN, ef_work* wk) {
   if (root->emb_memo) return root->emb_memo;
+  if (++wk->used > wk->limit) return NULL;
   ef_list* out = efl_new();
   root->visited = true;
   if (efl_empty(root->adjs)) {
@@ -195,11 +216,13 @@ static ef_list* subtree_embeddings(ef_pairing* root, const ef_config* cfg, const
     ef_iter ai = efl_begin(root->adjs);
     while (efi_has_next(&ai)) {
       ef_pairing* adj = (ef_pairing*)efi_next(&ai);
-      ef_list* sub = subtree_embeddings(adj, cfg, GEN);
+      ef_list* sub = subtree_embeddings(adj, cfg, GEN, wk);
+      if (!sub) { efl_free(out, embedding_free); return NULL; }
       ef_iter si = efl_begin(sub);
       while (efi_has_next(&si)) {
         ef_list* add = update_embedding((ef_list*)efi_next(&si), root, GEN, cfg);
         if (!add) continue;
+        if (++wk->used > wk->limit) { embedding_free(add); efl_free(out, embedding_free); return NULL; }
         int is_max = 2;
         ef_iter ci = efl_begin(out);
         while (efi_has_next(&ci) && is_max >= 1) {
@@ -401,15 +424,9 @@ ef_list* ef_clean_external_exons(ef_list* fact, const char* gen, const char* est
 
 /* dustScoreByLeftAndRight / dustScore (src/exon-complexity.c:38-79): the substring is scanned in
  * place (real_substring stops at the terminator, so does the scan) */
-static int base_index(unsigned char c) {
-  switch (c) {
-    case 'A': case 'a': return 0;
-    case 'C': case 'c': return 1;
-    case 'G': case 'g': return 2;
-    case 'T': case 't': return 3;
-    default: return -1;
-  }
-}
+static const signed char base_index_tab[256] = {
+  ['A'] = 1, ['a'] = 1, ['C'] = 2, ['c'] = 2, ['G'] = 3, ['g'] = 3, ['T'] = 4, ['t'] = 4 };
+static inline int base_index(unsigned char c) { return base_index_tab[c] - 1; }    /* ACGT -> 0..3, else -1 */
 static double dust_score(const char* s, int start, int end) {
   int want = end - start + 1;
   if (start < 0) { want += start; start = 0; }          /* real_substring clamps a negative index */
@@ -800,6 +817,7 @@ ef_est* ef_get_est_factorizations(const ef_seq* est_info, ef_meg* V, const ef_co
   const char* EST = est_info->seq;
   const unsigned est_len = (unsigned)V->n - 2;
   ef_list* flist = efl_new();
+  ef_work wk = { 0, work_limit(cfg) };
   EF_MEG_FOR_POS(V, i, 0, V->n) {
     ef_iter it = efl_begin(V->v[i]);
     while (efi_has_next(&it)) { ef_pairing* p = (ef_pairing*)efi_next(&it); p->visited = false; p->emb_memo = NULL; }
@@ -809,7 +827,17 @@ ef_est* ef_get_est_factorizations(const ef_seq* est_info, ef_meg* V, const ef_co
     while (efi_has_next(&it)) {
       ef_pairing* root = (ef_pairing*)efi_next(&it);
       if (root->visited) continue;
-      ef_list* embs = subtree_embeddings(root, cfg, GEN);
+      ef_list* embs = subtree_embeddings(root, cfg, GEN, &wk);
+      if (!embs) {
+        /* budget spent (:190-193): nothing of this attempt is kept, the caller retries */
+        EF_MEG_FOR_POS(V, j, 0, V->n) {
+          ef_iter jt = efl_begin(V->v[j]);
+          while (efi_has_next(&jt)) { ef_pairing* q = (ef_pairing*)efi_next(&jt); if (q->emb_memo) { efl_free(q->emb_memo, embedding_free); q->emb_memo = NULL; } }
+        }
+        efl_free(flist, ef_factorization_free);
+        free(est);
+        return NULL;
+      }
       ef_list* cands = factorizations_from_embeddings(embs, cfg);
       ef_iter ci = efl_begin(cands);
       while (efi_has_next(&ci)) {
@@ -831,6 +859,10 @@ ef_est* ef_get_est_factorizations(const ef_seq* est_info, ef_meg* V, const ef_co
       }
       efl_free(cands, NULL);
     }
+  }
+  {
+    unsigned long long hw = __atomic_load_n(&work_high_water, __ATOMIC_RELAXED);
+    while (wk.used > hw && !__atomic_compare_exchange_n(&work_high_water, &hw, wk.used, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) { }
   }
   /* release the memoised embeddings */
   EF_MEG_FOR_POS(V, i, 0, V->n) {

@@ -50,6 +50,7 @@ void ef_seq_free(ef_seq* s) {
   if (!s) return;
   free(s->id); free(s->seq); free(s->original_seq); free(s->gb); free(s->chr);
   free(s->kmer_first); free(s->kmer_pos); free(s->bps_memo);
+  for (int k = 0; k < 4; ++k) free(s->score5_tab[k]);
   free(s);
 }
 

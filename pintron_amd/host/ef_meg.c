@@ -29,6 +29,7 @@ static ef_list empty_position = { { &empty_position.sent, &empty_position.sent, 
 ef_meg* ef_meg_from_pairings(const ef_triple* tr, size_t n_tr, size_t m) {
   ef_meg* V = (ef_meg*)malloc(sizeof(ef_meg));
   V->n = m + 2;
+  V->rec = NULL;
   /* one list per EST position, most of them empty: headers exist only for the positions that
    * hold a vertex (source, sink and the distinct p of the pairings) */
   V->v = (ef_list**)malloc(V->n * sizeof(ef_list*) + (n_tr + 2) * sizeof(ef_list));
@@ -62,6 +63,7 @@ ef_meg* ef_meg_from_record(const void* rec, size_t m) {
   const uint8_t* tgt = (const uint8_t*)rec + 16 + 12 * (size_t)nv + 2 * ((size_t)nv + 1);
   ef_meg* V = (ef_meg*)malloc(sizeof(ef_meg));
   V->n = m + 2;
+  V->rec = rec;
   V->v = (ef_list**)malloc(V->n * sizeof(ef_list*) + (nv + 2) * sizeof(ef_list));
   ef_list* heads = (ef_list*)(V->v + V->n);
   for (size_t i = 0; i < V->n; ++i) V->v[i] = &empty_position;
@@ -397,7 +399,22 @@ void ef_transitive_reduction(ef_meg* V) {
   free(scratch);
 }
 
+/* the two texts of a device-built record (layout: include/pintron_gpu.h) */
+static const char* record_texts(const void* rec, uint32_t* meg_len, uint32_t* edges_len) {
+  const uint32_t* head = (const uint32_t*)rec;
+  const size_t graph = (16 + 12 * (size_t)head[0] + 2 * ((size_t)head[0] + 1) + head[1] + 3) & ~(size_t)3;
+  const uint32_t* tl = (const uint32_t*)((const char*)rec + graph);
+  *meg_len = tl[0]; *edges_len = tl[1];
+  return (const char*)rec + graph + 8;
+}
+
 void ef_meg_write(ef_sink* f, ef_meg* V) {
+  if (V->rec) {
+    uint32_t ml, el;
+    const char* t = record_texts(V->rec, &ml, &el);
+    ef_sink_write(f, t, ml);
+    return;
+  }
   ef_wbuf w; efw_open(&w, f);
   int index = 0;
   EF_MEG_FOR_POS(V, i, 0, V->n) {
@@ -424,6 +441,12 @@ void ef_meg_write(ef_sink* f, ef_meg* V) {
 }
 
 void ef_intronic_edges_write(ef_sink* f, ef_meg* V) {
+  if (V->rec) {
+    uint32_t ml, el;
+    const char* t = record_texts(V->rec, &ml, &el);
+    ef_sink_write(f, t + ml, el);
+    return;
+  }
   ef_wbuf w; efw_open(&w, f);
   EF_MEG_FOR_POS(V, i, 0, V->n) {
     ef_iter it = efl_begin(V->v[i]);

@@ -30,6 +30,7 @@
 #include <string.h>
 #include <stdint.h>
 #include <ucontext.h>
+#include <sys/mman.h>
 
 /* ---- fibre context switch --------------------------------------------------------------------------
  * swapcontext() saves and restores the signal mask with a system call on every switch; an EST
@@ -113,7 +114,7 @@ struct worker;
 typedef struct fiber {
   ef_ctx ctx;
   void* tsan;                /* ThreadSanitizer's handle of this fibre (EF_TSAN builds) */
-  char* stack;
+  char* stack; bool guarded;
   struct worker* w;
   int state;
   size_t unit;
@@ -129,6 +130,24 @@ typedef struct fiber {
 } fiber;
 
 static const char FIBER_SENTINEL[16] = "pintron-fibre-s";
+
+/* Fibre stacks are their own mappings with an inaccessible page below the lowest address: a stack
+ * that overflows (the embedding enumeration recurses as deep as the MEG is long) faults on the
+ * guard page instead of writing over a neighbouring heap block.  When the mapping cannot be had
+ * (map count exhausted by a very large PINTRON_FIBERS) the stack is a heap block and only the
+ * sentinel at its low end tells. */
+#define EF_GUARD_BYTES 4096u
+static char* stack_alloc(size_t size, bool* guarded) {
+  void* m = mmap(NULL, size + EF_GUARD_BYTES, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_STACK, -1, 0);
+  if (m != MAP_FAILED && mprotect(m, EF_GUARD_BYTES, PROT_NONE) == 0) { *guarded = true; return (char*)m + EF_GUARD_BYTES; }
+  if (m != MAP_FAILED) munmap(m, size + EF_GUARD_BYTES);
+  *guarded = false;
+  return (char*)malloc(size);
+}
+static void stack_free(char* stack, size_t size, bool guarded) {
+  if (!stack) return;
+  if (guarded) munmap(stack - EF_GUARD_BYTES, size + EF_GUARD_BYTES); else free(stack);
+}
 
 /* one input EST: entry `first` of the prepared list, plus the sibling at first+1 if any */
 typedef struct {
@@ -368,18 +387,18 @@ static bool start_fiber(worker* w, int li) {
   if (u == (size_t)-1) return false;
   if (f) {                       /* recycled: keep the stack and the sink blocks */
     char* st = f->stack;
+    const bool gd = f->guarded;
     void* ts = f->tsan;
     ef_sink keep[EF_N_OUT];
     memcpy(keep, f->out, sizeof keep);
     memset(f, 0, sizeof(fiber));
-    f->stack = st; f->tsan = ts;
+    f->stack = st; f->guarded = gd; f->tsan = ts;
     memcpy(f->out, keep, sizeof keep);
   }
-  else { f = (fiber*)calloc(1, sizeof(fiber)); f->stack = (char*)malloc(sh->stack_size); }
+  else { f = (fiber*)calloc(1, sizeof(fiber)); f->stack = stack_alloc(sh->stack_size, &f->guarded); }
   f->w = w; f->unit = u; f->state = F_RUNNABLE; f->lane = li;
   f->be.self = f; f->be.pairings = fiber_pairings; f->be.dp = fiber_dp; f->be.dp_many = fiber_dp_many; f->be.meg = fiber_meg;
-  /* the stacks are plain heap blocks (no guard page): a sentinel at the low end tells an
-   * overflow apart from everything else when the fibre is done */
+  /* besides the guard page: a sentinel at the low end, checked when the fibre is done */
   memcpy(f->stack, FIBER_SENTINEL, sizeof FIBER_SENTINEL);
 #if EF_TSAN
   if (f->tsan) __tsan_destroy_fiber(f->tsan);
@@ -710,8 +729,11 @@ static size_t host_core_share(void) {
  * PINTRON_NUMA=0 leaves the affinity alone, PINTRON_NUMA_NODE=<n> names the node. */
 static cpu_set_t numa_original;            /* the affinity the process came with */
 static int numa_bound = -2;                /* node the calling thread is bound to; -2: untouched */
+static int open_sessions;                  /* the caller's affinity is given back when the last one closes */
 
 static int guess_gpu_numa_node(int dev) {
+  /* the dev-th render node is the dev-th HIP device only when no visibility mask renumbers them */
+  if (getenv("HIP_VISIBLE_DEVICES") || getenv("ROCR_VISIBLE_DEVICES") || getenv("CUDA_VISIBLE_DEVICES")) return -1;
   int minors[64], n = 0;
   DIR* d = opendir("/dev/dri");
   if (!d) return -1;
@@ -728,6 +750,13 @@ static int guess_gpu_numa_node(int dev) {
   if (fscanf(f, "%d", &node) != 1) node = -1;
   fclose(f);
   return node;
+}
+
+/* undo bind_to_numa_node on the calling thread (a library user -- bench.py, pintron_amd.multi -- goes
+ * on living after the session: its later threads and child processes must not stay pinned) */
+static void restore_affinity(void) {
+  if (numa_bound >= -1) sched_setaffinity(0, sizeof numa_original, &numa_original);
+  numa_bound = -2;
 }
 
 static void bind_to_numa_node(int node) {
@@ -806,8 +835,14 @@ ef_session* ef_session_open(int argc, char** argv) {
   mallopt(M_TOP_PAD, 16 << 20);
   bind_to_numa_node(guess_gpu_numa_node(ef_gpu_device_from_env()));   /* before the runtime starts its threads */
   ef_session* s = (ef_session*)calloc(1, sizeof(ef_session));
+  ++open_sessions;
+  pthread_mutex_init(&s->sh.mu, NULL);
+  pthread_cond_init(&s->sh.ready_cv, NULL);
+  pthread_mutex_init(&s->sh.svc.mu, NULL);
+  pthread_cond_init(&s->sh.svc.posted, NULL);
+  pthread_cond_init(&s->sh.svc.finished, NULL);
   int load_rc = ef_load_genomic(argc, argv, &s->in);
-  if (load_rc != 0) { free(s); return NULL; }
+  if (load_rc != 0) { ef_session_close(s); return NULL; }
   gpu_boot boot = { NULL, PGPU_EDEVICE, s->in.gen->seq, strlen(s->in.gen->seq), NULL, PGPU_EDEVICE };
   pthread_t boot_thread;
   const bool booting = pthread_create(&boot_thread, NULL, gpu_boot_main, &boot) == 0;
@@ -815,21 +850,20 @@ ef_session* ef_session_open(int argc, char** argv) {
   ef_classify_init();
   const double t_loaded = now_s();
   if (booting) pthread_join(boot_thread, NULL); else gpu_boot_main(&boot);
-  if (load_rc != 0) { if (boot.rc == PGPU_OK) pgpu_destroy(boot.ctx); free(s); return NULL; }
+  if (boot.rc == PGPU_OK) { s->ctx0 = boot.ctx; s->sh.idx = boot.idx_rc == PGPU_OK ? boot.idx : NULL; }
+  if (load_rc != 0) { ef_session_close(s); return NULL; }
   if (boot.rc != PGPU_OK) {
     fprintf(stderr, "* FATAL no usable MI355X (gfx950) device / libpintron_gpu.so: est-fact has no CPU fallback\n");
-    free(s); return NULL;
+    ef_session_close(s); return NULL;
   }
-  s->ctx0 = boot.ctx;
   bind_to_numa_node(pgpu_device_numa_node(s->ctx0));   /* the library's word on the first guess */
   ef_inputs* in = &s->in;
   shared* sh = &s->sh;
   sh->in = in;
   if (boot.idx_rc != PGPU_OK) {
     fprintf(stderr, "* FATAL pgpu_index_build: %s\n", pgpu_last_error(s->ctx0));
-    free(s); return NULL;
+    ef_session_close(s); return NULL;
   }
-  sh->idx = boot.idx;
   sh->units = (unit*)calloc(in->n + 1, sizeof(unit));
   for (size_t k = 0; k < in->n;) {
     unit* u = &sh->units[sh->n_units++];
@@ -855,18 +889,13 @@ ef_session* ef_session_open(int argc, char** argv) {
       off[hi - lo] = pos;
       const int prc = pgpu_pairing_plan_create(s->ctx0, sh->idx, blob, off, hi - lo, &s->pplan[cidx]);
       free(blob); free(off);
-      if (prc != PGPU_OK) { fprintf(stderr, "* FATAL pairing plan: %s\n", pgpu_last_error(s->ctx0)); free(s); return NULL; }
+      if (prc != PGPU_OK) { fprintf(stderr, "* FATAL pairing plan: %s\n", pgpu_last_error(s->ctx0)); ef_session_close(s); return NULL; }
     }
   }
-  pthread_mutex_init(&sh->mu, NULL);
-  pthread_cond_init(&sh->ready_cv, NULL);
-  pthread_mutex_init(&sh->svc.mu, NULL);
-  pthread_cond_init(&sh->svc.posted, NULL);
-  pthread_cond_init(&sh->svc.finished, NULL);
   sh->svc.n_threads = (int)env_size("PINTRON_SERVICES", 3);
   if (sh->svc.n_threads > MAX_SERVICES) sh->svc.n_threads = MAX_SERVICES;
   for (int k = 0; k < sh->svc.n_threads; ++k) {
-    if (pgpu_init(ef_gpu_device_from_env(), &sh->svc.threads[k].ctx) != PGPU_OK) { free(s); return NULL; }
+    if (pgpu_init(ef_gpu_device_from_env(), &sh->svc.threads[k].ctx) != PGPU_OK) { ef_session_close(s); return NULL; }
     if (env_flag("PINTRON_KERNEL_TIMING")) pgpu_set_timing(sh->svc.threads[k].ctx, 1);
   }
   /* the workers hide the GPU latency with lanes, not with oversubscription */
@@ -964,7 +993,11 @@ int ef_session_step(ef_session* s, ef_sched_stats* stats_out) {
   memset(s->pre_kernel_ms, 0, sizeof s->pre_kernel_ms);
   s->pre_meg_ms = 0;
   s->pre_t0 = t0; s->pre_wall = 0;
-  if (sh->n_pre) pthread_create(&s->pre_thread, NULL, prefetch_main, s);
+  bool pre_started = false;
+  if (sh->n_pre) {
+    pre_started = pthread_create(&s->pre_thread, NULL, prefetch_main, s) == 0;
+    if (!pre_started) prefetch_main(s);                       /* no thread to be had: in line */
+  }
   const double t1 = now_s();
   service* sv = &sh->svc;
   sv->stop = false; sv->head = sv->tail = NULL; sv->sh = sh;
@@ -972,19 +1005,23 @@ int ef_session_step(ef_session* s, ef_sched_stats* stats_out) {
     memset(&sv->threads[k].stats, 0, sizeof(ef_sched_stats));
     memset(sv->threads[k].phase_s, 0, sizeof sv->threads[k].phase_s);
     sv->threads[k].sv = sv;
-    pthread_create(&sv->threads[k].thread, NULL, service_main, &sv->threads[k]);
   }
+  int sv_started = 0;
+  while (sv_started < sv->n_threads && pthread_create(&sv->threads[sv_started].thread, NULL, service_main, &sv->threads[sv_started]) == 0) ++sv_started;
   worker* ws = (worker*)calloc(s->nthreads, sizeof(worker));
   pthread_t* th = (pthread_t*)malloc(s->nthreads * sizeof(pthread_t));
-  for (size_t t = 0; t < s->nthreads; ++t) { ws[t].sh = sh; pthread_create(&th[t], NULL, worker_main, &ws[t]); }
-  for (size_t t = 0; t < s->nthreads; ++t) pthread_join(th[t], NULL);
-  if (sh->n_pre) pthread_join(s->pre_thread, NULL);
+  size_t w_started = 0;
+  if (sv_started > 0)            /* a worker that cannot get a thread is simply not started: the others take its ESTs */
+    for (size_t t = 0; t < s->nthreads; ++t) { ws[w_started].sh = sh; if (pthread_create(&th[w_started], NULL, worker_main, &ws[w_started]) == 0) ++w_started; }
+  if (sv_started == 0 || w_started == 0) { fprintf(stderr, "* FATAL cannot start the service / worker threads\n"); sh->failed = 1; }
+  for (size_t t = 0; t < w_started; ++t) pthread_join(th[t], NULL);
+  if (pre_started) pthread_join(s->pre_thread, NULL);
   pthread_mutex_lock(&sv->mu); sv->stop = true; pthread_cond_broadcast(&sv->posted); pthread_mutex_unlock(&sv->mu);
-  for (int k = 0; k < sv->n_threads; ++k) pthread_join(sv->threads[k].thread, NULL);
+  for (int k = 0; k < sv_started; ++k) pthread_join(sv->threads[k].thread, NULL);
   ef_sched_stats st;
   memset(&st, 0, sizeof st);
   st.threads = s->nthreads;
-  for (int t = 0; t < sv->n_threads; ++t) {
+  for (int t = 0; t < sv_started; ++t) {
     const ef_sched_stats* ss = &sv->threads[t].stats;
     const double* ph = sv->threads[t].phase_s;
     if (getenv("PINTRON_VERBOSE"))
@@ -993,7 +1030,7 @@ int ef_session_step(ef_session* s, ef_sched_stats* stats_out) {
     st.dp_batches += ss->dp_batches; st.dp_jobs += ss->dp_jobs;
     for (int k = 0; k < ss->n_kernels; ++k) kstat_add(&st, &ss->kernels[k]);
   }
-  for (size_t t = 0; t < s->nthreads; ++t) {
+  for (size_t t = 0; t < w_started; ++t) {
     st.units += ws[t].stats.units;
     st.pairing_batches += ws[t].stats.pairing_batches; st.pairing_requests += ws[t].stats.pairing_requests;
     st.host_s += ws[t].stats.host_s; st.pairing_s += ws[t].stats.pairing_s; st.dp_s += ws[t].stats.dp_s;
@@ -1102,21 +1139,24 @@ void ef_session_close(ef_session* s) {
   while (sh->fiber_pool) {
     fiber* nx = sh->fiber_pool->pool_next;
     for (int k = 0; k < EF_N_OUT; ++k) free(sh->fiber_pool->out[k].mem);
-    free(sh->fiber_pool->stack); free(sh->fiber_pool);
+    stack_free(sh->fiber_pool->stack, sh->stack_size, sh->fiber_pool->guarded); free(sh->fiber_pool);
     sh->fiber_pool = nx;
   }
   free(sh->units);
-  for (int c = 0; c < PRE_CHUNKS; ++c) {
+  for (int c = 0; c < PRE_CHUNKS && s->ctx0; ++c) {
     free(sh->pre_tri[c]); free(sh->pre_first[c]);
     if (sh->pre_meg[c]) pgpu_host_free(s->ctx0, sh->pre_meg[c]);
     if (sh->pre_meg_first[c]) pgpu_host_free(s->ctx0, sh->pre_meg_first[c]);
     if (s->pplan[c]) pgpu_pairing_plan_destroy(s->ctx0, s->pplan[c]);
   }
-  for (int k = 0; k < sh->svc.n_threads; ++k) pgpu_destroy(sh->svc.threads[k].ctx);
-  pgpu_index_destroy(s->ctx0, sh->idx);
-  pgpu_destroy(s->ctx0);
+  for (int k = 0; k < MAX_SERVICES; ++k) if (sh->svc.threads[k].ctx) pgpu_destroy(sh->svc.threads[k].ctx);
+  if (s->ctx0 && sh->idx) pgpu_index_destroy(s->ctx0, sh->idx);
+  if (s->ctx0) pgpu_destroy(s->ctx0);
   ef_free_inputs(&s->in);
+  pthread_mutex_destroy(&sh->mu); pthread_cond_destroy(&sh->ready_cv);
+  pthread_mutex_destroy(&sh->svc.mu); pthread_cond_destroy(&sh->svc.posted); pthread_cond_destroy(&sh->svc.finished);
   free(s);
+  if (--open_sessions == 0) restore_affinity();
 }
 
 int ef_leave_without_cleanup = 0;

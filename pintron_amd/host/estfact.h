@@ -66,6 +66,10 @@ typedef struct {
   /* genomic only: branch-point verdict of classify-intron per intron END position, filled on
    * demand (0 = not computed yet, 1 = no branch point, 2 = branch point found) */
   unsigned char* bps_memo;
+  /* genomic only: MatInspector score of the four 5' splice-site matrices at every position
+   * (classify-intron's GetScoreOf5Prime*BySS), filled once by ef_classify_prepare */
+  double* score5_tab[4];
+  size_t score5_len;
 } ef_seq;
 
 /* read_multifasta (src/io-multifasta.c:133-164); returns number of records, -1 on I/O error */
@@ -109,6 +113,9 @@ typedef struct {
   /* the positions that ever held a vertex, ascending (a few dozen of the ~600): vertices are only
    * ever added at such a position, so visiting these in order = visiting all positions in order */
   size_t* act; size_t n_act;
+  /* the device-built record this graph was made from (its two texts are printed as they are),
+   * NULL for a graph built on the host */
+  const void* rec;
 } ef_meg;
 
 /* first index k with act[k] >= lo */
@@ -263,7 +270,9 @@ typedef struct {
 void ef_factorization_free(void* fact);
 void ef_est_free(ef_est* e);
 
-/* get_EST_factorizations (src/est-factorizations.c:126-594) */
+/* get_EST_factorizations (src/est-factorizations.c:126-594); NULL when the embedding enumeration
+ * ran out of its work budget (the reference's timeout, made deterministic: see ef_fact.c) */
+unsigned long long ef_work_high_water(void);
 ef_est* ef_get_est_factorizations(const ef_seq* est, ef_meg* V, const ef_config* cfg,
                                   const ef_seq* gen, ef_backend* be);
 /* refine_EST_factorizations & co (src/factorization-refinement.c) */
@@ -310,6 +319,10 @@ void ef_free_inputs(ef_inputs* in);
 int ef_open_outputs(ef_outputs* o);
 void ef_close_outputs(ef_outputs* o);
 void ef_classify_init(void);     /* loads the PWM tables once (call before threads start) */
+/* per-gene tables of the intron classifier: the branch-point verdict of every intron end and the
+ * 5' splice-site scores of every intron start depend on the genomic sequence alone, so they are
+ * computed once per gene (a few threads, milliseconds) instead of once per candidate intron */
+void ef_classify_prepare(ef_seq* gen);
 
 /* the whole est-fact process (src/main-est-fact.c:90-339); the caller supplies the backend */
 int ef_run(int argc, char** argv, ef_backend* (*open_backend)(const ef_seq* gen), void (*close_backend)(ef_backend*));

@@ -87,6 +87,7 @@ static void close_oracle(ef_backend* be) { orc_index_destroy((orc_index*)be->sel
 int main(int argc, char** argv) {
   const double t0 = now_s();
   const int rc = ef_run(argc, argv, open_oracle, close_oracle);
+  if (getenv("ESTFACT_CHECK_DIMS")) fprintf(stderr, "work: high water %llu units\n", ef_work_high_water());
   if (getenv("ESTFACT_CHECK_DIMS"))
     for (int k = 0; k < 8; ++k) if (dim_max[k][0] || dim_max[k][1]) fprintf(stderr, "dims: kind %d max a_len %zu max b_len %zu\n", k, dim_max[k][0], dim_max[k][1]);
   if (getenv("ESTFACT_CHECK_TIMING")) fprintf(stderr, "timing: total %.3f s, oracle backend %.3f s, host logic %.3f s\n", now_s() - t0, backend_s, now_s() - t0 - backend_s);

@@ -106,7 +106,10 @@ int pgpu_pairing_plan_run_meg(pgpu_ctx* ctx, pgpu_pairing_plan* p, const pgpu_me
     size_t tp, te;
     ef_meg_stats(V, &tp, &te);
     const bool unavailable = tp > max_v || tp > 255 || te > 60000;
-    const size_t bytes = unavailable ? 16 : ((16 + 12 * tp + 2 * (tp + 1) + te + 3) & ~(size_t)3);
+    const size_t graph = (16 + 12 * tp + 2 * (tp + 1) + te + 3) & ~(size_t)3;
+    ef_sink t1 = { NULL, NULL, 0, 0 }, t2 = { NULL, NULL, 0, 0 };
+    if (!unavailable) { ef_meg_write(&t1, V); ef_intronic_edges_write(&t2, V); }
+    const size_t bytes = unavailable ? 16 : ((graph + 8 + t1.len + t2.len + 3) & ~(size_t)3);
     if (len + bytes > cap) { cap = (len + bytes) * 2; p->meg = (unsigned char*)realloc(p->meg, cap); }
     unsigned char* rec = p->meg + len;
     memset(rec, 0, bytes);
@@ -133,7 +136,11 @@ int pgpu_pairing_plan_run_meg(pgpu_ctx* ctx, pgpu_pairing_plan* p, const pgpu_me
         }
       }
       first[k] = (uint16_t)e;
+      uint32_t* tl = (uint32_t*)(rec + graph);
+      tl[0] = (uint32_t)t1.len; tl[1] = (uint32_t)t2.len;
+      memcpy(rec + graph + 8, t1.mem, t1.len); memcpy(rec + graph + 8 + t1.len, t2.mem, t2.len);
     }
+    free(t1.mem); free(t2.mem);
     ef_meg_free(V);
     len += bytes;
   }

@@ -1,7 +1,11 @@
 /* TEST INFRASTRUCTURE (tests/): runs the host-side MEG construction of the est-fact program on
  * genomic.txt / ests.txt of the current directory with the CPU pairing ORACLE as the backend, and
  * writes megs-check.txt in the reference's megs.txt record format for EVERY entry of the EST
- * list (both strands).  The product binary never links this file nor the oracle. */
+ * list (both strands).  With MEG_CHECK_FIRST_ATTEMPT=1 it writes megs-first.txt instead: for every
+ * entry the graph of the FIRST attempt of build_meg (no retry with a longer factor), as
+ *   "@@seq <prepared sequence>\n@@complex <0|1>\n<meg_write text>@@edges\n<meg-edges text>@@end\n"
+ * which is what the device's MEG stage returns per pattern (tests/test_gpu_pairings.py).
+ * The product binary never links this file nor the oracle. */
 #include <stdlib.h>
 #include <string.h>
 
@@ -32,6 +36,11 @@ int main(int argc, char** argv) {
   const long n = ef_read_multifasta("ests.txt", &ests);
   if (n < 0) return 1;
   orc_index* ix = orc_index_create(gen->seq, strlen(gen->seq));
+  if (getenv("MEG_CHECK_FIRST_ATTEMPT")) {         /* the genomic sequence as the index sees it */
+    FILE* gp = fopen("genomic-prepared.txt", "w");
+    fputs(gen->seq, gp);
+    fclose(gp);
+  }
   ef_backend be = { ix, oracle_pairings };
   ef_sink sink = { fopen("megs-check.txt", "w"), NULL, 0, 0 };
   ef_sink* f = &sink;
@@ -43,6 +52,29 @@ int main(int argc, char** argv) {
     ef_seq* both[2] = { est, NULL };
     if (!est->fixed_strand) { both[1] = ef_copy_and_reverse(est); ef_polyAT_substitution(both[1]); }
     for (int k = 0; k < 2 && both[k]; ++k) {
+      if (getenv("MEG_CHECK_FIRST_ATTEMPT")) {
+        static ef_sink first;
+        if (!first.f) first.f = fopen("megs-first.txt", "w");
+        ef_triple* tr = NULL; size_t ntr = 0;
+        const size_t m = strlen(both[k]->seq);
+        oracle_pairings(ix, both[k]->seq, m, cfg.min_factor_len, cfg.min_string_depth_rate, &tr, &ntr);
+        ef_meg* V = ef_meg_from_pairings(tr, ntr, m);
+        free(tr);
+        ef_build_edge_set(V, &cfg);
+        ef_simplify_meg(V, &cfg);
+        if (cfg.trans_red) ef_transitive_reduction(V);
+        bool cx = ef_is_too_complex_for_compaction(V);
+        if (!cx && cfg.short_edge_comp) ef_compact_short_edges(V, &cfg);
+        cx = cx || ef_is_too_complex(V, &cfg);
+        ef_sink_puts(&first, "@@seq "); ef_sink_puts(&first, both[k]->seq);
+        ef_sink_puts(&first, cx ? "\n@@complex 1\n" : "\n@@complex 0\n");
+        ef_meg_write(&first, V);
+        ef_sink_puts(&first, "@@edges\n");
+        ef_intronic_edges_write(&first, V);
+        ef_sink_puts(&first, "@@end\n");
+        ef_meg_free(V);
+        continue;
+      }
       size_t inc = 0;
       ef_meg* V = ef_build_meg(both[k], &be, &cfg, &inc);
       ef_sink_puts(f, "\n\n***********\n\n");

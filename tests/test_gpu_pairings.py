@@ -86,3 +86,62 @@ def test_c3_shape_vs_oracle(gpu_ctx):
         tot += len(exp)
     assert tot > 10000
     oi.close()
+
+
+def _first_attempt_megs(tmp_path, genomic_fasta, ests_fasta):
+    """Host MEG code (checked against the reference's megs.txt in test_host_meg.py) + pairing oracle:
+    first-attempt graph of every prepared sequence."""
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    subprocess.run(["make", "-s", "-C", os.path.join(here, "hostcheck"), "meg_check"], check=True)
+    (tmp_path / "genomic.txt").write_text(genomic_fasta)
+    (tmp_path / "ests.txt").write_text(ests_fasta)
+    subprocess.run([os.path.join(here, "hostcheck", "meg_check")], cwd=tmp_path, check=True,
+                   env=dict(os.environ, MEG_CHECK_FIRST_ATTEMPT="1"), stderr=subprocess.DEVNULL)
+    out = []
+    for blk in (tmp_path / "megs-first.txt").read_text().split("@@end\n")[:-1]:
+        head, rest = blk.split("\n", 1)
+        cx, rest = rest.split("\n", 1)
+        meg, edges = rest.split("@@edges\n")
+        out.append(dict(seq=head[len("@@seq "):].encode(), complex=int(cx.split()[1]), meg=meg.encode(), edges=edges.encode()))
+    return out, (tmp_path / "genomic-prepared.txt").read_bytes()
+
+
+@pytest.mark.parametrize("source", ["c3", "ambn", "repeats"])
+def test_meg_stage_vs_host_meg_code(gpu_ctx, tmp_path, source):
+    """pgpu_pairing_plan_run_meg: for every prepared sequence (both strands) the finished graph --
+    vertices in position-list order, adjacency in list order, the too_complex verdict and the two
+    texts est-fact prints -- against the host MEG code over the pairing oracle."""
+    import pintron_amd.capi as capi
+    from pintron_amd import synth
+    if source == "c3":
+        w = synth.make("C3", n_est=400, seed=21)
+        gfa, efa = w.genomic_fasta(), w.ests_fasta()
+    elif source == "repeats":
+        gfa, efa = synth.make_region_start_repeats()
+    else:
+        gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ambn")
+        gfa, efa = open(os.path.join(gold, "genomic.txt")).read(), open(os.path.join(gold, "ests.txt")).read()
+    exp, genomic = _first_attempt_megs(tmp_path, gfa, efa)
+    assert len(exp) >= 40
+    idx = capi.Index(gpu_ctx, genomic)
+    plan = capi.PairingPlan(gpu_ctx, idx, [e["seq"] for e in exp])
+    plan.run(15, 0.2)
+    plan.run_meg()
+    recs = [capi.parse_meg_record(r) for r in plan.fetch_meg()]
+    plan.close()
+    idx.close()
+    n_unavailable = 0
+    for e, r in zip(exp, recs):
+        if r["flags"] & 2:
+            n_unavailable += 1
+            continue
+        assert (r["flags"] & 1) == e["complex"]
+        assert r["meg_text"] == e["meg"] and r["edges_text"] == e["edges"]
+        # the structured part says what the text says
+        lines = e["meg"].decode().split("#adj#\n")
+        verts = [tuple(int(x) for x in ln.strip("()").split(",")) for ln in lines[0].splitlines()]
+        assert [tuple(v) for v in r["vertices"]] == verts
+        edges = [tuple(int(x) for x in ln.split("-")) for ln in lines[1].splitlines()]
+        assert [(k, t) for k, a in enumerate(r["adj"]) for t in a] == edges
+    assert n_unavailable * 20 <= len(exp)

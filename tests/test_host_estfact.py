@@ -162,3 +162,32 @@ def test_cli_options_and_config_dump(bins, tmp_path):
     assert 'min-factor-length="18"' in dump and 'min-intron-length="60"' in dump and 'retain-externals="false"' in dump
     bad = subprocess.run([bins["estfact_check"], "--min-string-depth-rate", "1.5"], cwd=tmp_path, stderr=subprocess.DEVNULL)
     assert bad.returncode != 0
+
+
+def test_work_budget_replaces_the_timeout(bins, tmp_path):
+    """The reference's wall-clock limit on the embedding enumeration (max_single_factorization_time,
+    src/est-factorizations.c:626-629,706-711; retry with a longer factor, src/compute-est-fact.c:
+    277-283) is a deterministic work budget here.  A budget of a few units forces the retry branch on
+    ordinary ESTs: the run ends, and the sequential program, 1 and 4 scheduler threads agree byte for
+    byte.  With the default budget (900 s x 10^6 units) the largest enumeration of the run stays six
+    orders of magnitude below it and the output is the reference's."""
+    outs = []
+    for which, env in (("estfact_check", {}), ("estfact_sched_check", {"PINTRON_THREADS": "1"}),
+                       ("estfact_sched_check", {"PINTRON_THREADS": "4"})):
+        d = tmp_path / ("b_%d" % len(outs))
+        d.mkdir()
+        for f in ("genomic.txt", "ests.txt"):
+            shutil.copy(os.path.join(GOLD, f), d)
+        run(bins[which], d, dict(env, PINTRON_WORK_BUDGET="30"))
+        outs.append([(d / f).read_bytes() for f in FILES])
+    assert outs[0] == outs[1] == outs[2]
+    assert outs[0][0] != open(os.path.join(GOLD, "expected-raw-multifasta-out.txt"), "rb").read()   # the retries happened
+    d = tmp_path / "default"
+    d.mkdir()
+    for f in ("genomic.txt", "ests.txt"):
+        shutil.copy(os.path.join(GOLD, f), d)
+    e = dict(os.environ, ESTFACT_CHECK_DIMS="1")
+    r = subprocess.run([bins["estfact_check"]], cwd=d, env=e, check=True, stderr=subprocess.PIPE, text=True)
+    hw = int([ln for ln in r.stderr.splitlines() if ln.startswith("work: high water")][0].split()[3])
+    assert 0 < hw < 1000
+    assert filecmp.cmp(d / "raw-multifasta-out.txt", os.path.join(GOLD, "expected-raw-multifasta-out.txt"), shallow=False)
