@@ -147,6 +147,24 @@ int pgpu_host_alloc(pgpu_ctx* ctx, size_t bytes, void** out);
 int pgpu_host_free(pgpu_ctx* ctx, void* p);
 
 /* ------------------------------------------------------------------------------------------ */
+/* gather -- the single exchange of the EST-sharded run (one process per GPU):    */
+/* each rank hands in the bytes it produced (packed factorization records, or the text of an   */
+/* output file), rank 0 receives them in rank order = input order.  RCCL point-to-point over   */
+/* xGMI; the library loads RCCL on first use.  The reference has no counterpart: its est-fact  */
+/* is one process (src/main-est-fact.c:249-291 is the loop that is sharded here).              */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct pgpu_comm pgpu_comm;
+typedef struct { char bytes[128]; } pgpu_comm_id;     /* = ncclUniqueId */
+/* rank 0 makes the id and passes it to the other ranks by any means (est-fact: a file) */
+int pgpu_comm_unique_id(pgpu_ctx* ctx, pgpu_comm_id* id);
+int pgpu_comm_init(pgpu_ctx* ctx, int rank, int world, const pgpu_comm_id* id, pgpu_comm** comm);
+/* send/send_bytes: this rank's payload (host memory).  counts: `world` entries, filled on every
+ * rank.  recv/recv_cap: rank 0 only, receives sum(counts) bytes.  Collective: all ranks call it. */
+int pgpu_gather(pgpu_ctx* ctx, pgpu_comm* comm, const void* send, uint64_t send_bytes,
+                void* recv, uint64_t recv_cap, uint64_t* counts);
+int pgpu_comm_destroy(pgpu_ctx* ctx, pgpu_comm* comm);
+
+/* ------------------------------------------------------------------------------------------ */
 /* batched dynamic programs                                                                   */
 /* ------------------------------------------------------------------------------------------ */
 enum pgpu_dp_kind {

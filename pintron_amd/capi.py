@@ -49,6 +49,7 @@ EXPORTS = [
     "pgpu_pairing_plan_destroy",
     "pgpu_pairing_plan_run_meg", "pgpu_pairing_plan_meg_bytes", "pgpu_pairing_plan_fetch_meg",
     "pgpu_pairing_plan_meg_ms", "pgpu_host_alloc", "pgpu_host_free",
+    "pgpu_comm_unique_id", "pgpu_comm_init", "pgpu_gather", "pgpu_comm_destroy",
     "pgpu_dp_plan_create", "pgpu_dp_plan_create_parts", "pgpu_dp_plan_launch", "pgpu_dp_plan_sync",
     "pgpu_dp_plan_string_bytes", "pgpu_dp_plan_fetch", "pgpu_dp_plan_destroy",
     "pgpu_dp_plan_results_to_device",
@@ -90,6 +91,10 @@ def lib():
         L.pgpu_pairing_plan_fetch_meg.argtypes = [vp, vp, vp, sz, C.POINTER(u64)]
         L.pgpu_host_alloc.argtypes = [vp, sz, C.POINTER(vp)]
         L.pgpu_host_free.argtypes = [vp, vp]
+        L.pgpu_comm_unique_id.argtypes = [vp, vp]
+        L.pgpu_comm_init.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]
+        L.pgpu_gather.argtypes = [vp, vp, C.c_char_p, u64, vp, u64, C.POINTER(u64)]
+        L.pgpu_comm_destroy.argtypes = [vp, vp]
         L.pgpu_pairings.argtypes = [vp, vp, C.c_char_p, C.POINTER(u64), sz,
                                     C.POINTER(PairingParams), C.POINTER(Pairing), sz,
                                     C.POINTER(u64), C.POINTER(sz)]

@@ -180,11 +180,29 @@ int ef_load_genomic(int argc, char** argv, ef_inputs* in) {
   return 0;
 }
 
+/* EST-sharded runs (one process per GPU): rank r of w keeps a contiguous range of the input ESTs,
+ * balanced by sequence length; an EST and its reverse-complement sibling are one input record,
+ * so they stay together (src/main-est-fact.c:266-284 tries the sibling only when the EST fails) */
+int ef_shard_rank = 0, ef_shard_world = 1;
+
 /* second half: ests.txt and the preparation of every EST */
 int ef_load_ests(ef_inputs* in) {
   ef_seq** ests = NULL;
-  const long n_in = ef_read_multifasta("ests.txt", &ests);
+  long n_in = ef_read_multifasta("ests.txt", &ests);
   if (n_in < 0) { fprintf(stderr, "* FATAL File ests.txt not found! Terminating\n"); return 1; }
+  if (ef_shard_world > 1) {
+    unsigned long long total = 0, acc = 0;
+    for (long i = 0; i < n_in; ++i) total += strlen(ests[i]->seq);
+    long lo = 0, hi = n_in, i = 0;
+    for (int r = 1; r <= ef_shard_world; ++r) {          /* bound r: first i with acc * world >= total * r */
+      while (i < n_in && acc * (unsigned long long)ef_shard_world < total * (unsigned long long)r) { acc += strlen(ests[i]->seq); ++i; }
+      if (r == ef_shard_rank) lo = i;
+      if (r == ef_shard_rank + 1) { hi = r == ef_shard_world ? n_in : i; break; }
+    }
+    for (long k = 0; k < n_in; ++k) if (k < lo || k >= hi) ef_seq_free(ests[k]);
+    memmove(ests, ests + lo, (size_t)(hi - lo) * sizeof(ef_seq*));
+    n_in = hi - lo;
+  }
   /* preparation loop (src/main-est-fact.c:190-213): every EST is prepared on its own, so the
    * loop is split over a few threads; the list is then filled in input order */
   ef_seq** revs = (ef_seq**)calloc((size_t)n_in + 1, sizeof(ef_seq*));

@@ -1131,6 +1131,7 @@ char* ef_session_output(ef_session* s, int which, size_t* len) {
 char* ef_session_records(ef_session* s, size_t* len) { return ef_session_output(s, 0, len); }
 
 size_t ef_session_n_ests(const ef_session* s) { return s->sh.n_units; }
+struct pgpu_ctx* ef_session_context(ef_session* s) { return s->ctx0; }
 
 void ef_session_close(ef_session* s) {
   if (!s) return;

@@ -35,6 +35,14 @@ void ef_session_close(ef_session* s);
  * PINTRON_FIBERS (fibres per worker over all lanes, 1024), PINTRON_FIBER_STACK_KB (256),
  * PINTRON_SERVICES (GPU service threads, 3), PINTRON_GPU_DEVICE (0), PINTRON_NO_PREFETCH,
  * PINTRON_KERNEL_TIMING, PINTRON_VERBOSE */
+/* est-fact over several GPUs of one node from the C program itself (ef_multi.c): `--gpus=N` (or
+ * PINTRON_GPUS=N) starts one process per GPU; the ESTs of the gene are split in contiguous ranges,
+ * the text of the six files is gathered to rank 0 through pgpu_gather (RCCL) and written there.
+ * `--genes=FILE` (directories, one per line) runs many genes in one invocation, gene g on rank
+ * g mod N, each leaving its files in its own directory. */
+int ef_main_multi(int argc, char** argv);
+struct pgpu_ctx* ef_session_context(ef_session* s);
+
 /* set by a program that ends right after ef_run_batched: the session is not taken apart */
 extern int ef_leave_without_cleanup;
 int ef_run_batched(int argc, char** argv);

@@ -15,9 +15,9 @@ int main(int argc, char** argv) {
   const char* mode = getenv("PINTRON_ESTFACT_MODE");
   if (mode && !strcmp(mode, "direct")) return ef_run(argc, argv, ef_gpu_open, ef_gpu_close);
   /* PINTRON_CLEAN_EXIT keeps the orderly teardown (profilers that flush at exit need it) */
-  if (getenv("PINTRON_CLEAN_EXIT")) return ef_run_batched(argc, argv);
+  if (getenv("PINTRON_CLEAN_EXIT")) return ef_main_multi(argc, argv);
   ef_leave_without_cleanup = 1;
-  const int rc = ef_run_batched(argc, argv);
+  const int rc = ef_main_multi(argc, argv);      /* --gpus / --genes, else the plain batched run */
   fflush(NULL);
   _exit(rc);
 }

@@ -315,6 +315,7 @@ typedef struct { FILE* flog; ef_sink fout, fests, fmeg, fpmeg, ftmeg, fintronic;
 int ef_load_inputs(int argc, char** argv, ef_inputs* in);     /* = ef_load_genomic + ef_load_ests */
 int ef_load_genomic(int argc, char** argv, ef_inputs* in);
 int ef_load_ests(ef_inputs* in);
+extern int ef_shard_rank, ef_shard_world;   /* ef_load_ests keeps the rank's range of the input ESTs */
 void ef_free_inputs(ef_inputs* in);
 int ef_open_outputs(ef_outputs* o);
 void ef_close_outputs(ef_outputs* o);

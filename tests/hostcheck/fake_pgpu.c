@@ -156,6 +156,69 @@ int pgpu_pairing_plan_fetch_meg(pgpu_ctx* ctx, pgpu_pairing_plan* p, void* out, 
   memcpy(first, p->meg_first, (p->n + 1) * sizeof(uint64_t));
   return PGPU_OK;
 }
+/* gather of the stand-in: the ranks are processes on one host, the "wire" is a directory of files
+ * named after the communicator id (which rank 0 made and handed over exactly as with RCCL) */
+#include <stdio.h>
+#include <time.h>
+#include <unistd.h>
+struct pgpu_comm { char tag[64]; int rank, world; unsigned seq; };
+int pgpu_comm_unique_id(pgpu_ctx* ctx, pgpu_comm_id* id) {
+  (void)ctx;
+  memset(id, 0, sizeof *id);
+  snprintf(id->bytes, sizeof id->bytes, "%ld-%ld", (long)getpid(), (long)time(NULL));
+  return PGPU_OK;
+}
+int pgpu_comm_init(pgpu_ctx* ctx, int rank, int world, const pgpu_comm_id* id, pgpu_comm** out) {
+  (void)ctx;
+  pgpu_comm* c = (pgpu_comm*)calloc(1, sizeof *c);
+  snprintf(c->tag, sizeof c->tag, "%.60s", id->bytes); c->rank = rank; c->world = world;
+  *out = c; return PGPU_OK;
+}
+int pgpu_comm_destroy(pgpu_ctx* ctx, pgpu_comm* c) { (void)ctx; free(c); return PGPU_OK; }
+int pgpu_gather(pgpu_ctx* ctx, pgpu_comm* c, const void* send, uint64_t send_bytes, void* recv, uint64_t recv_cap, uint64_t* counts) {
+  (void)ctx;
+  const char* dir = getenv("TMPDIR") ? getenv("TMPDIR") : "/tmp";
+  char path[512], tmp[520];
+  const unsigned seq = c->seq++;
+  if (seq >= 2) {             /* every rank is past round seq-2 by now: its marker can go */
+    snprintf(path, sizeof path, "%s/pgpu-fake-%s-%u-seen-%d", dir, c->tag, seq - 2, c->rank);
+    unlink(path);
+  }
+  snprintf(path, sizeof path, "%s/pgpu-fake-%s-%u-%d", dir, c->tag, seq, c->rank);
+  snprintf(tmp, sizeof tmp, "%s.tmp", path);
+  FILE* f = fopen(tmp, "wb");
+  if (!f) return PGPU_EDEVICE;
+  if (send_bytes) fwrite(send, 1, send_bytes, f);
+  fclose(f);
+  rename(tmp, path);
+  uint64_t at = 0;
+  int rc = PGPU_OK;
+  for (int r = 0; r < c->world; ++r) {                  /* every rank reads every size; rank 0 the data too */
+    snprintf(path, sizeof path, "%s/pgpu-fake-%s-%u-%d", dir, c->tag, seq, r);
+    FILE* g = NULL;
+    for (int tries = 0; tries < 30000 && !g; ++tries) { g = fopen(path, "rb"); if (!g) { struct timespec ts = { 0, 2000000 }; nanosleep(&ts, NULL); } }
+    if (!g) return PGPU_EDEVICE;
+    fseek(g, 0, SEEK_END); counts[r] = (uint64_t)ftell(g); fseek(g, 0, SEEK_SET);
+    if (c->rank == 0 && rc == PGPU_OK) {
+      if (at + counts[r] > recv_cap) rc = PGPU_ENOSPC;
+      else if (counts[r] && fread((char*)recv + at, 1, counts[r], g) != counts[r]) rc = PGPU_EDEVICE;
+      at += counts[r];
+    }
+    fclose(g);
+  }
+  /* a second rendezvous so that nobody removes a file somebody has not read yet: each rank drops a
+   * "seen" marker, rank r removes its own payload once all markers are there */
+  snprintf(path, sizeof path, "%s/pgpu-fake-%s-%u-seen-%d", dir, c->tag, seq, c->rank);
+  f = fopen(path, "wb"); if (f) fclose(f);
+  for (int r = 0; r < c->world; ++r) {
+    snprintf(path, sizeof path, "%s/pgpu-fake-%s-%u-seen-%d", dir, c->tag, seq, r);
+    for (int tries = 0; tries < 30000 && access(path, F_OK) != 0; ++tries) { struct timespec ts = { 0, 2000000 }; nanosleep(&ts, NULL); }
+  }
+  snprintf(path, sizeof path, "%s/pgpu-fake-%s-%u-%d", dir, c->tag, seq, c->rank);
+  unlink(path);
+  return rc;
+}
+
 int pgpu_host_alloc(pgpu_ctx* ctx, size_t bytes, void** out) { (void)ctx; *out = malloc(bytes ? bytes : 16); return *out ? PGPU_OK : PGPU_ENOMEM; }
 int pgpu_host_free(pgpu_ctx* ctx, void* q) { (void)ctx; free(q); return PGPU_OK; }
 int pgpu_pairings(pgpu_ctx* ctx, const pgpu_index* idx, const char* patterns, const uint64_t* off, size_t n, const pgpu_pairing_params* prm,

@@ -286,3 +286,49 @@ def test_c4_two_gene_sample_vs_compiled_reference(exe, tmp_path):
     assert out.returncode == 0, out.stderr[-3000:]
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["scaling"] == "strong" and d["config"]["ests_per_gpu"] == 8 * 1500 and d["n_gpus"] == 1
+
+
+def test_gather_entry_point_on_rccl(gpu_ctx):
+    """pgpu_comm_* / pgpu_gather on the real backend with a communicator of one rank (this box has one
+    GPU): RCCL is loaded on demand, the sizes round and the payload round come back intact."""
+    import ctypes as C
+    L = gpu_ctx.L
+    ident = (C.c_char * 128)()
+    gpu_ctx.check(L.pgpu_comm_unique_id(gpu_ctx.h, ident))
+    comm = C.c_void_p()
+    gpu_ctx.check(L.pgpu_comm_init(gpu_ctx.h, 0, 1, ident, C.byref(comm)))
+    payload = bytes(range(256)) * 4000 + b"tail"
+    recv = C.create_string_buffer(len(payload))
+    counts = (C.c_uint64 * 1)()
+    for data in (payload, b"", payload[:17]):
+        gpu_ctx.check(L.pgpu_gather(gpu_ctx.h, comm, data, len(data), recv, len(payload), counts))
+        assert counts[0] == len(data) and recv.raw[:len(data)] == data
+    assert L.pgpu_gather(gpu_ctx.h, comm, payload, len(payload), recv, 10, counts) == -28      # PGPU_ENOSPC
+    gpu_ctx.check(L.pgpu_comm_destroy(gpu_ctx.h, comm))
+
+
+def test_c_program_many_genes_and_shards(exe, tmp_path):
+    """`est-fact --genes=FILE` (gene g on rank g mod N) on the GPU, and -- on a node with at least two
+    GPUs -- `est-fact --gpus=2`: the C program shards one gene over two ranks and rank 0 writes the
+    files of a single process (RCCL gather, pintron_amd/host/ef_multi.c)."""
+    import torch
+    from pintron_amd import synth
+    dirs = []
+    for g in range(2):
+        w = synth.make("C4", n_est=800, seed=synth.CONFIGS["C4"]["seed"] + g)
+        for tag in ("solo", "multi"):
+            synth.write_files(w, str(tmp_path / ("%s%d" % (tag, g))))
+        dirs.append(str(tmp_path / ("multi%d" % g)))
+        subprocess.run([exe], cwd=tmp_path / ("solo%d" % g), check=True)
+    (tmp_path / "genes.txt").write_text("\n".join(dirs) + "\n")
+    n = min(torch.cuda.device_count(), 2)
+    subprocess.run([exe, "--genes=" + str(tmp_path / "genes.txt"), "--gpus=%d" % n], cwd=tmp_path, check=True)
+    for g in range(2):
+        for f in FILES:
+            assert filecmp.cmp(tmp_path / ("solo%d" % g) / f, tmp_path / ("multi%d" % g) / f, shallow=False), (g, f)
+    if n >= 2:
+        shard = tmp_path / "shard"
+        synth.write_files(synth.make("C4", n_est=800, seed=synth.CONFIGS["C4"]["seed"]), str(shard))
+        subprocess.run([exe, "--gpus=2"], cwd=shard, check=True)
+        for f in FILES:
+            assert filecmp.cmp(shard / f, tmp_path / "solo0" / f, shallow=False), f

@@ -191,3 +191,43 @@ def test_work_budget_replaces_the_timeout(bins, tmp_path):
     hw = int([ln for ln in r.stderr.splitlines() if ln.startswith("work: high water")][0].split()[3])
     assert 0 < hw < 1000
     assert filecmp.cmp(d / "raw-multifasta-out.txt", os.path.join(GOLD, "expected-raw-multifasta-out.txt"), shallow=False)
+
+
+def test_c_program_shards_one_gene_over_ranks(bins, tmp_path):
+    """`est-fact --gpus=N` (pintron_amd/host/ef_multi.c): the program starts the other ranks itself,
+    each factorizes its range of the ESTs, rank 0 gathers the text of the six files through
+    pgpu_gather and writes what a single process writes.  Here over the CPU stand-in of the C-ABI,
+    whose gather goes through files; on the GPU box the same flow runs over RCCL."""
+    from pintron_amd import synth
+    w = synth.make("C2", n_est=240, seed=9)
+    one, many, envd = tmp_path / "one", tmp_path / "many", tmp_path / "env"
+    for d in (one, many, envd):
+        synth.write_files(w, str(d))
+    e = dict(os.environ, TMPDIR=str(tmp_path), PINTRON_THREADS="2")
+    subprocess.run([bins["estfact_sched_check"]], cwd=one, env=e, check=True, stderr=subprocess.DEVNULL)
+    subprocess.run([bins["estfact_sched_check"], "--gpus=3"], cwd=many, env=e, check=True, stderr=subprocess.DEVNULL)
+    subprocess.run([bins["estfact_sched_check"]], cwd=envd, env=dict(e, PINTRON_GPUS="2"), check=True, stderr=subprocess.DEVNULL)
+    for f in FILES:
+        assert filecmp.cmp(one / f, many / f, shallow=False), f
+        assert filecmp.cmp(one / f, envd / f, shallow=False), f
+    assert os.path.getsize(one / "raw-multifasta-out.txt") > 10000
+
+
+def test_c_program_runs_many_genes(bins, tmp_path):
+    """`est-fact --genes=FILE --gpus=N`: gene g on rank g mod N, every gene's files in its own
+    directory (BASELINE.json configs[3] in miniature)."""
+    from pintron_amd import synth
+    dirs = []
+    for g in range(3):
+        w = synth.make("C4", n_est=60, seed=synth.CONFIGS["C4"]["seed"] + g, gen_len=40_000)
+        for tag in ("solo", "multi"):
+            synth.write_files(w, str(tmp_path / ("%s%d" % (tag, g))))
+        dirs.append(str(tmp_path / ("multi%d" % g)))
+        subprocess.run([bins["estfact_sched_check"]], cwd=tmp_path / ("solo%d" % g), check=True, stderr=subprocess.DEVNULL,
+                       env=dict(os.environ, PINTRON_THREADS="2"))
+    (tmp_path / "genes.txt").write_text("# three genes\n" + "\n".join(dirs) + "\n")
+    subprocess.run([bins["estfact_sched_check"], "--genes=" + str(tmp_path / "genes.txt"), "--gpus=2"], cwd=tmp_path, check=True,
+                   stderr=subprocess.DEVNULL, env=dict(os.environ, PINTRON_THREADS="2", TMPDIR=str(tmp_path)))
+    for g in range(3):
+        for f in FILES:
+            assert filecmp.cmp(tmp_path / ("solo%d" % g) / f, tmp_path / ("multi%d" % g) / f, shallow=False), (g, f)
