@@ -57,6 +57,13 @@ int pgpu_device_numa_node(pgpu_ctx* ctx);
 /* ------------------------------------------------------------------------------------------ */
 int pgpu_index_build(pgpu_ctx* ctx, const char* genomic, size_t len, pgpu_index** idx);
 int pgpu_index_destroy(pgpu_ctx* ctx, pgpu_index* idx);
+/* The index depends on the genomic sequence alone, and a gene is processed many times (re-runs of
+ * the pipeline, parameter studies): save writes suffix array, LCP array and k-mer table to a file,
+ * load brings them back into HBM without the construction.  load returns PGPU_EINVAL when the file
+ * is missing, damaged or was made for another sequence (length + hash are checked) -- the caller
+ * then builds.   */
+int pgpu_index_save(pgpu_ctx* ctx, const pgpu_index* idx, const char* genomic, const char* path);
+int pgpu_index_load(pgpu_ctx* ctx, const char* path, const char* genomic, size_t len, pgpu_index** idx);
 /* copies the suffix array (len entries) back to the host; for tests and diagnostics */
 int pgpu_index_suffix_array(pgpu_ctx* ctx, const pgpu_index* idx, uint32_t* sa_out, size_t cap);
 

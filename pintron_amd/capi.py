@@ -43,7 +43,7 @@ assert C.sizeof(DpJob) == 48 and C.sizeof(DpResult) == 48
 # every symbol include/pintron_gpu.h declares
 EXPORTS = [
     "pgpu_init", "pgpu_destroy", "pgpu_last_error", "pgpu_abi_version", "pgpu_set_timing", "pgpu_device_numa_node",
-    "pgpu_index_build", "pgpu_index_destroy", "pgpu_index_suffix_array", "pgpu_pairings",
+    "pgpu_index_build", "pgpu_index_destroy", "pgpu_index_suffix_array", "pgpu_index_save", "pgpu_index_load", "pgpu_pairings",
     "pgpu_pairing_plan_create", "pgpu_pairing_plan_run", "pgpu_pairing_plan_count",
     "pgpu_pairing_plan_positions", "pgpu_pairing_plan_kernel_ms", "pgpu_pairing_plan_fetch",
     "pgpu_pairing_plan_destroy",
@@ -82,6 +82,8 @@ def lib():
         L.pgpu_last_error.restype = C.c_char_p
         L.pgpu_index_build.argtypes = [vp, C.c_char_p, sz, C.POINTER(vp)]
         L.pgpu_index_destroy.argtypes = [vp, vp]
+        L.pgpu_index_save.argtypes = [vp, vp, C.c_char_p, C.c_char_p]
+        L.pgpu_index_load.argtypes = [vp, C.c_char_p, C.c_char_p, sz, C.POINTER(vp)]
         L.pgpu_index_suffix_array.argtypes = [vp, vp, C.POINTER(C.c_uint32), sz]
         L.pgpu_pairing_plan_run_meg.argtypes = [vp, vp, vp]
         L.pgpu_pairing_plan_meg_bytes.argtypes = [vp]
@@ -159,11 +161,21 @@ class Context:
 
 
 class Index:
-    def __init__(self, ctx: Context, genomic: bytes):
+    def __init__(self, ctx: Context, genomic: bytes, load_from=None):
+        """Built on the device, or (load_from=<path>) read from a file written by save()."""
         self.ctx = ctx
         self.h = C.c_void_p()
         self.n = len(genomic)
-        ctx.check(ctx.L.pgpu_index_build(ctx.h, genomic, len(genomic), C.byref(self.h)))
+        self.genomic = genomic
+        if load_from is None:
+            ctx.check(ctx.L.pgpu_index_build(ctx.h, genomic, len(genomic), C.byref(self.h)))
+        else:
+            rc = ctx.L.pgpu_index_load(ctx.h, os.fsencode(load_from), genomic, len(genomic), C.byref(self.h))
+            if rc != PGPU_OK:
+                raise PgpuError(rc, "index file %s does not fit this sequence" % load_from)
+
+    def save(self, path):
+        self.ctx.check(self.ctx.L.pgpu_index_save(self.ctx.h, self.h, self.genomic, os.fsencode(path)))
 
     def suffix_array(self):
         import numpy as np

@@ -17,8 +17,10 @@
 //                 per position: occurrences above the threshold, sort by t, filter (a);
 //                 filter (b) against the previous position; compaction into (p,t,l) triples
 #include <algorithm>
+#include <cstdio>
 #include <cstring>
 #include <new>
+#include <string>
 #include <vector>
 
 #include <rocprim/device/device_radix_sort.hpp>   // index construction only (one-off per gene)
@@ -75,16 +77,22 @@ __global__ void sa_rerank_kernel(const uint32_t* __restrict__ sa, const uint32_t
   if (k < n) rank[sa[k]] = newrank_sorted[k];
 }
 
-__global__ void lcp_kernel(const uint8_t* __restrict__ T, const uint32_t* __restrict__ sa, uint32_t n,
-                           uint32_t* lcp) {
+// LCP of neighbouring suffixes from the rank arrays the prefix doubling went through: ranks[r] orders
+// the suffixes by their first 2^r characters (the end of the text sorting first), so two suffixes
+// share 2^r more characters exactly when their ranks[r] agree; descending r adds up the exact LCP
+// in ~log n steps per pair, however repetitive the sequence is (a character-by-character scan is
+// quadratic on a long exact repeat).
+__global__ void lcp_from_ranks_kernel(const uint32_t* const* __restrict__ ranks, int n_rounds,
+                                      const uint32_t* __restrict__ sa, uint32_t n, uint32_t* __restrict__ lcp) {
   const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k > n) return;
   if (k == 0 || k == n) { lcp[k] = 0; return; }
   const uint32_t a = sa[k - 1], b = sa[k];
-  uint32_t h = 0;
-  const uint32_t lim = n - (a > b ? a : b);
-  while (h < lim && T[a + h] == T[b + h]) ++h;
-  lcp[k] = h;
+  uint32_t l = 0;
+  for (int r = n_rounds - 1; r >= 0; --r) {
+    if (a + l < n && b + l < n && ranks[r][a + l] == ranks[r][b + l]) l += 1u << r;
+  }
+  lcp[k] = l;
 }
 
 __device__ __forceinline__ int kmer_base(uint32_t c) {
@@ -387,6 +395,8 @@ extern "C" int pgpu_index_build(pgpu_ctx* ctx, const char* genomic, size_t len, 
   const uint32_t n = (uint32_t)len;
   int rc = PGPU_OK;
   uint32_t *rank = nullptr, *sa2 = nullptr, *flags = nullptr, *newrank = nullptr;
+  std::vector<uint32_t*> round_ranks;        // rank arrays by 2^r-character prefixes, r = 0, 1, ...
+  const uint32_t** d_round_ptrs = nullptr;
   unsigned long long *keys = nullptr, *keys2 = nullptr;
   void* tmp = nullptr;
   size_t tmp_bytes = 0;
@@ -418,6 +428,12 @@ extern "C" int pgpu_index_build(pgpu_ctx* ctx, const char* genomic, size_t len, 
       b = tmp_bytes;
       TRY_HIP(rocprim::inclusive_scan(tmp, b, flags, newrank, n, rocprim::plus<uint32_t>(), st));
       hipLaunchKernelGGL(sa_rerank_kernel, grd, blk, 0, st, sa2, newrank, n, rank);
+      {                                        // this round ranked by the first max(1, 2h) characters
+        uint32_t* keep = nullptr;
+        TRY_HIP(dmalloc(&keep, n));
+        round_ranks.push_back(keep);
+        TRY_HIP(hipMemcpyAsync(keep, rank, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+      }
       TRY_HIP(hipMemcpyAsync(idx->d_sa, sa2, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
       uint32_t distinct = 0;
       TRY_HIP(hipMemcpyAsync(&distinct, newrank + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -426,7 +442,13 @@ extern "C" int pgpu_index_build(pgpu_ctx* ctx, const char* genomic, size_t len, 
       if (h >= n) { rc = pgpu_ctx_fail(ctx, PGPU_EDEVICE, "suffix array construction did not converge"); goto done; }
     }
   }
-  hipLaunchKernelGGL(lcp_kernel, grd, blk, 0, st, idx->d_gen, idx->d_sa, n, idx->d_lcp);
+  {
+    // round 0 ranked by 1 character (h == 0), round j >= 1 by 2^j characters: ranks[r] <-> 2^r
+    const int nr = (int)round_ranks.size();
+    TRY_HIP(hipMalloc((void**)&d_round_ptrs, (nr ? nr : 1) * sizeof(uint32_t*)));
+    if (nr) TRY_HIP(hipMemcpyAsync(d_round_ptrs, round_ranks.data(), nr * sizeof(uint32_t*), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(lcp_from_ranks_kernel, grd, blk, 0, st, (const uint32_t* const*)d_round_ptrs, nr, idx->d_sa, n, idx->d_lcp);
+  }
   TRY_HIP(dmalloc(&idx->d_klo, KTAB_ENTRIES));
   TRY_HIP(dmalloc(&idx->d_khi, KTAB_ENTRIES));
   TRY_HIP(hipMemsetAsync(idx->d_klo, 0, KTAB_ENTRIES * sizeof(uint32_t), st));
@@ -436,6 +458,81 @@ extern "C" int pgpu_index_build(pgpu_ctx* ctx, const char* genomic, size_t len, 
   TRY_HIP(hipGetLastError());
 done:
   hipFree(rank); hipFree(sa2); hipFree(flags); hipFree(newrank); hipFree(keys); hipFree(keys2); hipFree(tmp);
+  for (uint32_t* q : round_ranks) hipFree(q);
+  hipFree(d_round_ptrs);
+  if (rc != PGPU_OK) { hipFree(idx->d_gen); hipFree(idx->d_sa); hipFree(idx->d_lcp); hipFree(idx->d_klo); hipFree(idx->d_khi); delete idx; return rc; }
+  *out = idx;
+  return PGPU_OK;
+}
+
+// ---- the index on disk: a gene is usually processed many times (parameter studies, re-runs of the
+// pipeline), the index depends on the genomic sequence alone ------------------------------------
+namespace {
+struct IndexFileHeader { char magic[8]; uint32_t version, ktab; uint64_t len, hash; };
+const char INDEX_MAGIC[8] = { 'P', 'G', 'P', 'U', 'I', 'D', 'X', '1' };
+uint64_t fnv1a64(const void* p, size_t n) {
+  const unsigned char* b = (const unsigned char*)p;
+  uint64_t h = 1469598103934665603ull;
+  for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
+  return h;
+}
+}  // namespace
+
+extern "C" int pgpu_index_save(pgpu_ctx* ctx, const pgpu_index* idx, const char* genomic, const char* path) {
+  if (!ctx || !idx || !path || (idx->len && !genomic)) return PGPU_EINVAL;
+  if (pgpu_ctx_bind(ctx) != PGPU_OK) return PGPU_EDEVICE;
+  const size_t n = idx->len;
+  std::vector<uint32_t> host(2 * n + 1 + 2 * (size_t)KTAB_ENTRIES);
+  hipStream_t st = pgpu_ctx_stream(ctx);
+  if ((n && hipMemcpyAsync(host.data(), idx->d_sa, n * 4, hipMemcpyDeviceToHost, st) != hipSuccess) ||
+      hipMemcpyAsync(host.data() + n, idx->d_lcp, (n + 1) * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipMemcpyAsync(host.data() + 2 * n + 1, idx->d_klo, KTAB_ENTRIES * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipMemcpyAsync(host.data() + 2 * n + 1 + KTAB_ENTRIES, idx->d_khi, KTAB_ENTRIES * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipStreamSynchronize(st) != hipSuccess)
+    return pgpu_ctx_fail(ctx, PGPU_EDEVICE, "index download failed");
+  IndexFileHeader h;
+  memcpy(h.magic, INDEX_MAGIC, 8); h.version = 1; h.ktab = KTAB; h.len = n; h.hash = fnv1a64(genomic, n);
+  // written under a temporary name and renamed: a concurrent reader sees the whole file or none
+  std::string tmp = std::string(path) + ".tmp";
+  FILE* f = fopen(tmp.c_str(), "wb");
+  if (!f) return pgpu_ctx_fail(ctx, PGPU_EINVAL, "cannot create the index file");
+  const bool ok = fwrite(&h, sizeof h, 1, f) == 1 && fwrite(host.data(), 4, host.size(), f) == host.size();
+  if (fclose(f) != 0 || !ok || rename(tmp.c_str(), path) != 0) { remove(tmp.c_str()); return pgpu_ctx_fail(ctx, PGPU_EDEVICE, "writing the index file failed"); }
+  return PGPU_OK;
+}
+
+// PGPU_EINVAL when the file is missing, damaged or belongs to another sequence (the caller builds)
+extern "C" int pgpu_index_load(pgpu_ctx* ctx, const char* path, const char* genomic, size_t len, pgpu_index** out) {
+  if (!ctx || !path || !out || (len && !genomic)) return PGPU_EINVAL;
+  *out = nullptr;
+  if (pgpu_ctx_bind(ctx) != PGPU_OK) return PGPU_EDEVICE;
+  FILE* f = fopen(path, "rb");
+  if (!f) return PGPU_EINVAL;
+  IndexFileHeader h;
+  const size_t words = 2 * len + 1 + 2 * (size_t)KTAB_ENTRIES;
+  std::vector<uint32_t> host;
+  bool ok = fread(&h, sizeof h, 1, f) == 1 && memcmp(h.magic, INDEX_MAGIC, 8) == 0 && h.version == 1 && h.ktab == KTAB &&
+            h.len == len && h.hash == fnv1a64(genomic, len);
+  if (ok) { host.resize(words); ok = fread(host.data(), 4, words, f) == words && fgetc(f) == EOF; }
+  fclose(f);
+  if (!ok) return PGPU_EINVAL;
+  pgpu_index* idx = new (std::nothrow) pgpu_index();
+  if (!idx) return pgpu_ctx_fail(ctx, PGPU_ENOMEM, "out of host memory");
+  idx->len = len;
+  hipStream_t st = pgpu_ctx_stream(ctx);
+  const uint32_t n = (uint32_t)len;
+  int rc = PGPU_OK;
+  TRY_HIP(hipMalloc((void**)&idx->d_gen, len + 64));
+  TRY_HIP(hipMemsetAsync(idx->d_gen, 0, len + 64, st));
+  if (len) TRY_HIP(hipMemcpyAsync(idx->d_gen, genomic, len, hipMemcpyHostToDevice, st));
+  TRY_HIP(dmalloc(&idx->d_sa, n + 1)); TRY_HIP(dmalloc(&idx->d_lcp, n + 2));
+  TRY_HIP(dmalloc(&idx->d_klo, KTAB_ENTRIES)); TRY_HIP(dmalloc(&idx->d_khi, KTAB_ENTRIES));
+  if (n) TRY_HIP(hipMemcpyAsync(idx->d_sa, host.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+  TRY_HIP(hipMemcpyAsync(idx->d_lcp, host.data() + n, ((size_t)n + 1) * 4, hipMemcpyHostToDevice, st));
+  TRY_HIP(hipMemcpyAsync(idx->d_klo, host.data() + 2 * (size_t)n + 1, KTAB_ENTRIES * 4, hipMemcpyHostToDevice, st));
+  TRY_HIP(hipMemcpyAsync(idx->d_khi, host.data() + 2 * (size_t)n + 1 + KTAB_ENTRIES, KTAB_ENTRIES * 4, hipMemcpyHostToDevice, st));
+  TRY_HIP(hipStreamSynchronize(st));
+done:
   if (rc != PGPU_OK) { hipFree(idx->d_gen); hipFree(idx->d_sa); hipFree(idx->d_lcp); hipFree(idx->d_klo); hipFree(idx->d_khi); delete idx; return rc; }
   *out = idx;
   return PGPU_OK;

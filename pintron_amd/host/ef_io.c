@@ -3,6 +3,7 @@
  * function); the implementation is our own. */
 #define _GNU_SOURCE
 #include <ctype.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -103,26 +104,22 @@ static bool next_line(const char* buf, size_t size, size_t* pos, line_t* ln) {
 /* read_multifasta (src/io-multifasta.c:133-164) with getData (:94-130): a record starts at a line
  * beginning with '>', its sequence is the concatenation of the following non-empty lines up to
  * the next '>' line, the literal line "#\#" or the end of the file. */
-long ef_read_multifasta(const char* path, ef_seq*** out) {
-  FILE* f = fopen(path, "rb");
-  if (!f) return -1;
-  fseek(f, 0, SEEK_END);
-  const long sz = ftell(f);
-  fseek(f, 0, SEEK_SET);
-  char* buf = (char*)malloc((size_t)sz + 1);
-  if (fread(buf, 1, (size_t)sz, f) != (size_t)sz) { fclose(f); free(buf); return -1; }
-  fclose(f);
+/* the records of buf[0, sz), which starts at a record (or before the first one) */
+typedef struct { const char* buf; size_t sz; ef_seq** v; size_t n; } parse_range;
+static void* parse_records(void* arg) {
+  parse_range* r = (parse_range*)arg;
+  const char* buf = r->buf; const size_t sz = r->sz;
   size_t pos = 0, cap = 16, n = 0;
   ef_seq** v = (ef_seq**)malloc(cap * sizeof(ef_seq*));
   line_t ln;
-  bool have = next_line(buf, (size_t)sz, &pos, &ln);
+  bool have = next_line(buf, sz, &pos, &ln);
   while (have) {
     if (ln.len > 0 && ln.p[0] == '>') {
       ef_seq* s = seq_new();
       s->id = dup_range(ln.p + 1, ln.len - 1);
       size_t scap = 256, slen = 0;
       char* data = (char*)malloc(scap);
-      while ((have = next_line(buf, (size_t)sz, &pos, &ln))) {
+      while ((have = next_line(buf, sz, &pos, &ln))) {
         if (ln.len > 0 && ln.p[0] == '>') break;
         if (ln.len == 3 && memcmp(ln.p, "#\\#", 3) == 0) break;
         if (ln.len == 0) continue;
@@ -138,9 +135,51 @@ long ef_read_multifasta(const char* path, ef_seq*** out) {
       if (n == cap) { cap *= 2; v = (ef_seq**)realloc(v, cap * sizeof(ef_seq*)); }
       v[n++] = s;
     } else {
-      have = next_line(buf, (size_t)sz, &pos, &ln);
+      have = next_line(buf, sz, &pos, &ln);
     }
   }
+  r->v = v; r->n = n;
+  return NULL;
+}
+
+/* A record starts at every line that begins with '>', whatever came before it, so a large file is
+ * cut at such lines into a few ranges that are parsed side by side (a C5-sized ests.txt holds two
+ * million records: one thread spends most of its time in malloc) and joined in file order. */
+long ef_read_multifasta(const char* path, ef_seq*** out) {
+  FILE* f = fopen(path, "rb");
+  if (!f) return -1;
+  fseek(f, 0, SEEK_END);
+  const long sz = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  char* buf = (char*)malloc((size_t)sz + 1);
+  if (fread(buf, 1, (size_t)sz, f) != (size_t)sz) { fclose(f); free(buf); return -1; }
+  fclose(f);
+  buf[sz] = '\0';
+  enum { MAX_PARTS = 8 };
+  const int want = (sz >= (8 << 20) || getenv("PINTRON_PARSE_SPLIT")) ? MAX_PARTS : 1;   /* the variable: tests */
+  size_t cut[MAX_PARTS + 1];
+  int parts = 0;
+  cut[0] = 0;
+  for (int t = 1; t < want; ++t) {
+    size_t at = (size_t)sz * (size_t)t / (size_t)want;
+    if (at <= cut[parts]) continue;
+    const char* q = buf + at;                         /* the next "\n>" at or after `at` */
+    while ((q = (const char*)memchr(q, '\n', (size_t)(buf + sz - q))) != NULL && q + 1 < buf + sz && q[1] != '>') ++q;
+    if (!q || q + 1 >= buf + sz) break;
+    cut[++parts] = (size_t)(q + 1 - buf);
+  }
+  cut[++parts] = (size_t)sz;
+  parse_range rg[MAX_PARTS]; pthread_t th[MAX_PARTS]; bool started[MAX_PARTS];
+  for (int t = 0; t < parts; ++t) {
+    rg[t].buf = buf + cut[t]; rg[t].sz = cut[t + 1] - cut[t]; rg[t].v = NULL; rg[t].n = 0;
+    started[t] = parts > 1 && pthread_create(&th[t], NULL, parse_records, &rg[t]) == 0;
+    if (!started[t]) parse_records(&rg[t]);
+  }
+  size_t n = 0;
+  for (int t = 0; t < parts; ++t) { if (started[t]) pthread_join(th[t], NULL); n += rg[t].n; }
+  ef_seq** v = (ef_seq**)malloc((n + 1) * sizeof(ef_seq*));
+  size_t at = 0;
+  for (int t = 0; t < parts; ++t) { memcpy(v + at, rg[t].v, rg[t].n * sizeof(ef_seq*)); at += rg[t].n; free(rg[t].v); }
   free(buf);
   *out = v;
   return (long)n;

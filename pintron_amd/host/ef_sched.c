@@ -822,7 +822,20 @@ static void* gpu_boot_main(void* arg) {
   b->rc = pgpu_init(ef_gpu_device_from_env(), &b->ctx);
   if (b->rc == PGPU_OK) {
     if (env_flag("PINTRON_KERNEL_TIMING")) pgpu_set_timing(b->ctx, 1);
+    /* PINTRON_INDEX_CACHE=<directory>: the index of a sequence is kept there under its hash and
+     * loaded instead of built the next time the same genomic sequence comes by */
+    const char* cache = getenv("PINTRON_INDEX_CACHE");
+    char path[1200];
+    if (cache && cache[0]) {
+      unsigned long long h = 1469598103934665603ull;
+      for (size_t i = 0; i < b->gen_len; ++i) { h ^= (unsigned char)b->gen[i]; h *= 1099511628211ull; }
+      snprintf(path, sizeof path, "%s/pintron-index-%016llx-%zu.bin", cache, h, b->gen_len);
+      b->idx_rc = pgpu_index_load(b->ctx, path, b->gen, b->gen_len, &b->idx);
+      if (b->idx_rc == PGPU_OK) return NULL;
+    }
     b->idx_rc = pgpu_index_build(b->ctx, b->gen, b->gen_len, &b->idx);
+    if (b->idx_rc == PGPU_OK && cache && cache[0] && pgpu_index_save(b->ctx, b->idx, b->gen, path) != PGPU_OK)
+      fprintf(stderr, "* WARN the index could not be saved to %s\n", path);
   }
   return NULL;
 }

@@ -31,6 +31,8 @@ int pgpu_index_build(pgpu_ctx* ctx, const char* g, size_t len, pgpu_index** idx)
   x->ix = orc_index_create(g, len);
   *idx = x; return PGPU_OK;
 }
+int pgpu_index_save(pgpu_ctx* ctx, const pgpu_index* idx, const char* g, const char* path) { (void)ctx; (void)idx; (void)g; (void)path; return PGPU_ENOSYS; }
+int pgpu_index_load(pgpu_ctx* ctx, const char* path, const char* g, size_t len, pgpu_index** idx) { (void)ctx; (void)path; (void)g; (void)len; (void)idx; return PGPU_EINVAL; }
 int pgpu_index_destroy(pgpu_ctx* ctx, pgpu_index* idx) { (void)ctx; orc_index_destroy(idx->ix); free(idx->gen); free(idx); return PGPU_OK; }
 
 int pgpu_pairing_plan_create(pgpu_ctx* ctx, const pgpu_index* idx, const char* patterns, const uint64_t* off, size_t n, pgpu_pairing_plan** out) {

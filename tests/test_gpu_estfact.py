@@ -288,23 +288,39 @@ def test_c4_two_gene_sample_vs_compiled_reference(exe, tmp_path):
     assert d["scaling"] == "strong" and d["config"]["ests_per_gpu"] == 8 * 1500 and d["n_gpus"] == 1
 
 
-def test_gather_entry_point_on_rccl(gpu_ctx):
+GATHER_WORKER = r"""
+import ctypes as C, sys
+sys.path.insert(0, %(root)r)
+import pintron_amd.capi as capi
+ctx = capi.Context(0)
+L = ctx.L
+ident = (C.c_char * 128)()
+ctx.check(L.pgpu_comm_unique_id(ctx.h, ident))
+comm = C.c_void_p()
+ctx.check(L.pgpu_comm_init(ctx.h, 0, 1, ident, C.byref(comm)))
+payload = bytes(range(256)) * 4000 + b"tail"
+recv = C.create_string_buffer(len(payload))
+counts = (C.c_uint64 * 1)()
+for data in (payload, b"", payload[:17]):
+    ctx.check(L.pgpu_gather(ctx.h, comm, data, len(data), recv, len(payload), counts))
+    assert counts[0] == len(data) and recv.raw[:len(data)] == data
+assert L.pgpu_gather(ctx.h, comm, payload, len(payload), recv, 10, counts) == -28      # PGPU_ENOSPC
+ctx.check(L.pgpu_comm_destroy(ctx.h, comm))
+ctx.close()
+print("gather ok")
+"""
+
+
+def test_gather_entry_point_on_rccl(exe, tmp_path):
     """pgpu_comm_* / pgpu_gather on the real backend with a communicator of one rank (this box has one
-    GPU): RCCL is loaded on demand, the sizes round and the payload round come back intact."""
-    import ctypes as C
-    L = gpu_ctx.L
-    ident = (C.c_char * 128)()
-    gpu_ctx.check(L.pgpu_comm_unique_id(gpu_ctx.h, ident))
-    comm = C.c_void_p()
-    gpu_ctx.check(L.pgpu_comm_init(gpu_ctx.h, 0, 1, ident, C.byref(comm)))
-    payload = bytes(range(256)) * 4000 + b"tail"
-    recv = C.create_string_buffer(len(payload))
-    counts = (C.c_uint64 * 1)()
-    for data in (payload, b"", payload[:17]):
-        gpu_ctx.check(L.pgpu_gather(gpu_ctx.h, comm, data, len(data), recv, len(payload), counts))
-        assert counts[0] == len(data) and recv.raw[:len(data)] == data
-    assert L.pgpu_gather(gpu_ctx.h, comm, payload, len(payload), recv, 10, counts) == -28      # PGPU_ENOSPC
-    gpu_ctx.check(L.pgpu_comm_destroy(gpu_ctx.h, comm))
+    GPU): RCCL is loaded on demand, the sizes round and the payload round come back intact.  Own
+    process, without torch: the library loads the system's RCCL, and a process that already carries
+    torch's bundled HIP runtime and RCCL is not the place to map a second pair (the C program that
+    uses this entry point never has torch in it)."""
+    script = tmp_path / "gather_worker.py"
+    script.write_text(GATHER_WORKER % dict(root=ROOT))
+    out = subprocess.run([os.sys.executable, str(script)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "gather ok" in out.stdout, out.stderr[-2000:]
 
 
 def test_c_program_many_genes_and_shards(exe, tmp_path):

@@ -145,3 +145,54 @@ def test_meg_stage_vs_host_meg_code(gpu_ctx, tmp_path, source):
         edges = [tuple(int(x) for x in ln.split("-")) for ln in lines[1].splitlines()]
         assert [(k, t) for k, a in enumerate(r["adj"]) for t in a] == edges
     assert n_unavailable * 20 <= len(exp)
+
+
+def test_index_file_roundtrip(gpu_ctx, tmp_path):
+    """pgpu_index_save / pgpu_index_load: the index read back from disk gives the same suffix array
+    and the same pairings; a file made for another sequence is refused."""
+    import pintron_amd.capi as capi
+    from pintron_amd import synth
+    w = synth.make("C2", n_est=60, seed=8)
+    ests = list(w.est_seqs) + [PL.revcomp(e) for e in w.est_seqs]
+    built = capi.Index(gpu_ctx, w.genomic)
+    path = str(tmp_path / "gene.idx")
+    built.save(path)
+    loaded = capi.Index(gpu_ctx, w.genomic, load_from=path)
+    assert np.array_equal(built.suffix_array(), loaded.suffix_array())
+    out = []
+    for ix in (built, loaded):
+        plan = capi.PairingPlan(gpu_ctx, ix, ests)
+        plan.run(15, 0.2)
+        plan.run_meg()
+        out.append((plan.fetch()[0].tobytes(), plan.fetch_meg()))
+        plan.close()
+    assert out[0] == out[1] and len(out[0][0]) > 1000
+    other = bytes(w.genomic[:-1]) + (b"A" if w.genomic[-1:] != b"A" else b"C")
+    with pytest.raises(capi.PgpuError):
+        capi.Index(gpu_ctx, other, load_from=path)
+    with pytest.raises(capi.PgpuError):
+        capi.Index(gpu_ctx, w.genomic, load_from=str(tmp_path / "missing.idx"))
+    built.close()
+    loaded.close()
+
+
+def test_long_exact_repeat_in_the_genomic(gpu_ctx):
+    """A genomic sequence that contains a 30 kb exact duplicate: neighbouring suffixes share tens of
+    thousands of characters, which is where a character-by-character LCP scan goes quadratic.  The
+    index is built from the rank arrays of the doubling rounds (log n steps per pair) and the pairings
+    -- whose thresholds come from LCP-interval borders -- must still be the oracle's."""
+    import time
+    import pintron_amd.capi as capi
+    rng = random.Random(5)
+    unit = bytes(rng.choice(b"ACGT") for _ in range(30000))
+    flank = [bytes(rng.choice(b"ACGT") for _ in range(7000)) for _ in range(3)]
+    gen = flank[0] + unit + flank[1] + unit + flank[2]
+    ests = [gen[a:a + 400] for a in (6800, 7100, 20000, 36900, 43950, 44100, 60000, 73800)]
+    ests += [PL.revcomp(e) for e in ests]
+    t0 = time.time()
+    got = gpu_pairings(gpu_ctx, gen, ests)
+    assert time.time() - t0 < 20
+    oi = PL.OracleIndex(gen)
+    for e, g in zip(ests, got):
+        assert np.array_equal(g.reshape(-1, 3), oi.pairings(e)), len(e)
+    oi.close()

@@ -231,3 +231,23 @@ def test_c_program_runs_many_genes(bins, tmp_path):
     for g in range(3):
         for f in FILES:
             assert filecmp.cmp(tmp_path / ("solo%d" % g) / f, tmp_path / ("multi%d" % g) / f, shallow=False), (g, f)
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
+def test_split_parse_of_ests_file(bins, tmp_path):
+    """ests.txt is cut at record starts and parsed on several threads (files of 8 MB and more; forced
+    here): the records and their order are those of the sequential reader, on the edge-case inputs
+    (wrapped lines, odd headers, the '#\\#' terminator) and on a C2 sample."""
+    from pintron_amd import synth
+    g, e = synth.make_edge_cases()
+    w = synth.make("C2", n_est=200, seed=4)
+    for tag, gfa, efa in (("edge", g, e), ("c2", w.genomic_fasta(), w.ests_fasta())):
+        ref_dir, my_dir = tmp_path / (tag + "_ref"), tmp_path / (tag + "_mine")
+        for d in (ref_dir, my_dir):
+            d.mkdir()
+            (d / "genomic.txt").write_text(gfa)
+            (d / "ests.txt").write_text(efa)
+        subprocess.run([os.path.join(O.REF_DIR, "est-fact-core")], cwd=ref_dir, check=True, stderr=subprocess.DEVNULL)
+        run(bins["estfact_sched_check"], my_dir, {"PINTRON_THREADS": "2", "PINTRON_PARSE_SPLIT": "1"})
+        for f in FILES:
+            assert filecmp.cmp(my_dir / f, ref_dir / f, shallow=False), (tag, f)
