@@ -22,9 +22,24 @@
  * explicit node of depth max(lcp[lo], lcp[hi+1]); the locus itself is an explicit node iff the
  * first and last suffix of the interval differ at offset D.
  * Depths below L are not tracked exactly (they cannot influence a threshold or a pairing).
- * Known deviation, documented in DESIGN.md: the reference can emit the pairing with t == 0
- * several times at an upper tree level (second loop of fill_list_pairings has no t == 0 guard);
- * we emit it once.
+ *
+ * The occurrence t == 0 has no preceding character: the reference files it under EVERY symbol of the
+ * genomic alphabet (src/aug_suffix_tree.c:183-192) and fill_list_pairings reports it once per
+ * symbol slice it walks, except where a guard stops it (:195: only in the slice of key 0, or key 1
+ * when key 0 is the slice of the preceding symbol).  The guard sits in the loop over the entries
+ * BEFORE the block of the child already reported, not in the loop over the entries AFTER it
+ * (:203-211) -- and suffix 0 is always after: libstree adds children at the head of the child list
+ * (stree_src/lst_stree.c:87) and the branch towards suffix 0 is the oldest of every node on its
+ * path (it is the remainder of the edge that was split, :548-590), so it comes last in the
+ * depth-first order that fills the occurrence array.  Hence, with l0 = lcp(P[i..], T[0..]) >= thr_i:
+ *     copies of (i, 0, l0) = sum over keys k != key(P[i-1]) of
+ *                              1            when some occurrence t' > 0 that matches MORE than l0
+ *                                           characters and is not prev-excluded has key(T[t'-1]) == k
+ *                                           (the block's slice k is not empty: second loop),
+ *                              guard(k)     otherwise (first loop),
+ *     guard(k) = (k == 0 || (k == 1 && key(P[i-1]) == 0)); key(c) = rank of c among the distinct
+ *     characters of T, or their number when c does not occur in T (or i == 0).
+ * Pinned against the reference's own build_vertex_set in tests/test_pairings_oracle.py.
  */
 #define _GNU_SOURCE
 #include "pairing_oracle.h"
@@ -37,6 +52,8 @@ struct orc_index {
   size_t n;
   uint32_t* sa;
   uint32_t* lcp;        /* lcp[k] = lcp(suffix sa[k-1], suffix sa[k]); lcp[0] = lcp[n] = 0 */
+  unsigned char key[256];  /* preprocess_text (src/aug_suffix_tree.c:68-120): rank among T's distinct characters */
+  unsigned sigma;          /* their number = the key of characters that do not occur */
 };
 
 static int suffix_cmp(const void* a, const void* b, void* ctx) {
@@ -53,6 +70,12 @@ orc_index* orc_index_create(const char* genomic, size_t n) {
   char* t = (char*)malloc(n + 1);
   memcpy(t, genomic, n); t[n] = '\0';
   ix->T = t; ix->n = n;
+  {
+    char seen[256] = {0};
+    for (size_t i = 0; i < n; ++i) seen[(unsigned char)t[i]] = 1;
+    for (int c = 0; c < 256; ++c) if (seen[c]) ix->key[c] = (unsigned char)ix->sigma++;
+    for (int c = 0; c < 256; ++c) if (!seen[c]) ix->key[c] = (unsigned char)ix->sigma;
+  }
   ix->sa = (uint32_t*)malloc((n + 1) * sizeof(uint32_t));
   ix->lcp = (uint32_t*)calloc(n + 2, sizeof(uint32_t));
   for (size_t i = 0; i < n; ++i) ix->sa[i] = (uint32_t)i;
@@ -131,6 +154,26 @@ long orc_pairings(const orc_index* ix, const char* P, size_t m, uint32_t L, doub
         occ[nocc].t = (int32_t)t; occ[nocc].l = (int32_t)l; ++nocc;
         if (l > A) A = l;
       }
+    }
+    /* copies of the t == 0 occurrence (header comment): extra ones are appended, none may remain */
+    for (size_t z = 0; z < nocc; ++z) {
+      if (occ[z].t != 0) continue;
+      const int32_t l0 = occ[z].l;
+      const unsigned sk = i > 0 ? ix->key[(unsigned char)P[i - 1]] : ix->sigma;
+      unsigned present = 0;
+      for (size_t q = 0; q < nocc; ++q)
+        if (occ[q].t > 0 && occ[q].l > l0) present |= 1u << ix->key[(unsigned char)T[occ[q].t - 1]];
+      unsigned copies = 0;
+      for (unsigned k = 0; k < ix->sigma; ++k) {
+        if (k == sk) continue;
+        copies += ((present >> k) & 1u) ? 1u : ((k == 0 || (k == 1 && sk == 0)) ? 1u : 0u);
+      }
+      if (copies == 0) { occ[z] = occ[--nocc]; }
+      else if (copies > 1) {
+        occ = (occ_t*)realloc(occ, (nocc + copies) * sizeof(occ_t));
+        for (unsigned c = 1; c < copies; ++c) occ[nocc++] = occ[z];
+      }
+      break;
     }
     D = A > s ? A : s;
     if (D < L) {                                   /* below the tracked range: restart at the root */

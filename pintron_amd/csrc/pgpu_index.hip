@@ -41,6 +41,10 @@ struct pgpu_index {
   uint32_t* d_lcp = nullptr;      // n+1 entries; lcp[0] = lcp[n] = 0
   uint32_t* d_klo = nullptr;      // [code] -> first suffix-array index of the k-mer (klo == khi: absent)
   uint32_t* d_khi = nullptr;
+  // preprocess_text (src/aug_suffix_tree.c:68-120): key of a character = its rank among the distinct
+  // characters of the genomic sequence, `sigma` (their number) for characters that do not occur
+  uint8_t* d_key = nullptr;          // 256 entries
+  uint32_t sigma = 0;
   size_t len = 0;
 };
 
@@ -176,6 +180,31 @@ __device__ __forceinline__ uint32_t extend(const uint8_t* __restrict__ T, uint32
   return l;
 }
 
+// How many times the reference lists the occurrence t == 0 of position i (oracle/pairing_oracle.c
+// states and tests the rule; src/max-emb-graph.c:168-216, src/aug_suffix_tree.c:183-192): suffix 0
+// has no preceding character, sits in the slice of every symbol, and is reported once per slice walked
+// -- through the unguarded loop where the child already reported holds an occurrence preceded by
+// that symbol, through the guarded one (key 0, or key 1 next to the preceding symbol's key 0)
+// elsewhere.  *l0 = lcp(P[i..], T[0..]); the result only matters when l0 reaches the threshold.
+__device__ uint32_t zero_copies(const uint8_t* __restrict__ T, uint32_t n, const uint32_t* __restrict__ sa,
+                                const uint8_t* __restrict__ key, uint32_t sigma, const uint8_t* __restrict__ P,
+                                uint32_t m, uint32_t i, uint32_t L, uint32_t lo, uint32_t hi, uint32_t l0) {
+  unsigned long long present[4] = {0, 0, 0, 0};
+  for (uint32_t k = lo; k < hi; ++k) {
+    const uint32_t t = sa[k];
+    if (t == 0 || prev_excluded(T, t, P, i)) continue;
+    if (extend(T, n, t, P, m, i, L) > l0) { const uint32_t q = key[T[t - 1]]; present[q >> 6] |= 1ull << (q & 63u); }
+  }
+  const uint32_t sk = i > 0 ? key[P[i - 1]] : sigma;
+  uint32_t copies = 0;
+  for (uint32_t k = 0; k < sigma; ++k) {
+    if (k == sk) continue;
+    if ((present[k >> 6] >> (k & 63u)) & 1ull) ++copies;
+    else if (k == 0 || (k == 1 && sk == 0)) ++copies;
+  }
+  return copies;
+}
+
 // one wave per pattern, lanes stride over its positions
 __global__ __launch_bounds__(64)
 void pair_locate_kernel(const uint8_t* __restrict__ T, uint32_t n, const uint32_t* __restrict__ sa,
@@ -247,6 +276,7 @@ void pair_chain_kernel(const uint8_t* __restrict__ T, uint32_t n, const uint32_t
 // number of occurrences at or above the threshold (before the filters)
 __global__ __launch_bounds__(64)
 void pair_count_kernel(const uint8_t* __restrict__ T, uint32_t n, const uint32_t* __restrict__ sa,
+                       const uint8_t* __restrict__ key, uint32_t sigma,
                        const uint8_t* __restrict__ pats, const unsigned long long* __restrict__ pat_off,
                        PairParams prm, const uint32_t* __restrict__ lo_in, const uint32_t* __restrict__ hi_in,
                        const uint32_t* __restrict__ thr_in, uint32_t* __restrict__ cnt_out) {
@@ -261,7 +291,9 @@ void pair_count_kernel(const uint8_t* __restrict__ T, uint32_t n, const uint32_t
       for (uint32_t k = lo; k < hi; ++k) {
         const uint32_t t = sa[k];
         if (prev_excluded(T, t, P, i)) continue;
-        if (extend(T, n, t, P, m, i, prm.L) >= thr) ++c;
+        const uint32_t l = extend(T, n, t, P, m, i, prm.L);
+        if (l < thr) continue;
+        c += t == 0 ? zero_copies(T, n, sa, key, sigma, P, m, i, prm.L, lo, hi, l) : 1u;
       }
     }
     cnt_out[base + i] = c;
@@ -274,6 +306,7 @@ struct Cand { uint32_t t, l; };
 // (src/max-emb-graph.c:301-334) and move the survivors to the front of the position's slot
 __global__ __launch_bounds__(64)
 void pair_fill_kernel(const uint8_t* __restrict__ T, uint32_t n, const uint32_t* __restrict__ sa,
+                      const uint8_t* __restrict__ key, uint32_t sigma,
                       const uint8_t* __restrict__ pats, const unsigned long long* __restrict__ pat_off,
                       PairParams prm, const uint32_t* __restrict__ lo_in, const uint32_t* __restrict__ hi_in,
                       const uint32_t* __restrict__ thr_in, const unsigned long long* __restrict__ cand_off,
@@ -292,9 +325,13 @@ void pair_fill_kernel(const uint8_t* __restrict__ T, uint32_t n, const uint32_t*
         if (prev_excluded(T, t, P, i)) continue;
         const uint32_t l = extend(T, n, t, P, m, i, prm.L);
         if (l < thr) continue;
-        uint32_t q = c++;                                  // insertion sort by t (t is unique)
-        while (q > 0 && slot[q - 1].t > t) { slot[q] = slot[q - 1]; --q; }
-        slot[q].t = t; slot[q].l = l;
+        // insertion sort by t (distinct, except the copies of t == 0, which stay together in front)
+        const uint32_t copies = t == 0 ? zero_copies(T, n, sa, key, sigma, P, m, i, prm.L, lo, hi, l) : 1u;
+        for (uint32_t cpy = 0; cpy < copies; ++cpy) {
+          uint32_t q = c++;
+          while (q > 0 && slot[q - 1].t > t) { slot[q] = slot[q - 1]; --q; }
+          slot[q].t = t; slot[q].l = l;
+        }
       }
       // filter (a): PJ dies when an earlier PI (smaller t) covers it or is its twin shifted by one.
       // The reference tests against ALL earlier entries, dead ones included, so deaths are
@@ -376,6 +413,22 @@ template <class T> hipError_t dmalloc(T** p, size_t count) {
 // ---------------------------------------------------------------------------------------------
 // C-ABI: index
 // ---------------------------------------------------------------------------------------------
+// alphabet keys of the genomic sequence (host), uploaded with the index
+static hipError_t upload_keys(pgpu_index* idx, const char* genomic, size_t len, hipStream_t st) {
+  bool seen[256] = {false};
+  for (size_t i = 0; i < len; ++i) seen[(unsigned char)genomic[i]] = true;
+  uint8_t key[256];
+  uint32_t sigma = 0;
+  for (int c = 0; c < 256; ++c) if (seen[c]) key[c] = (uint8_t)sigma++;
+  for (int c = 0; c < 256; ++c) if (!seen[c]) key[c] = (uint8_t)(sigma > 255 ? 255 : sigma);
+  idx->sigma = sigma;
+  hipError_t e = hipMalloc((void**)&idx->d_key, 256);
+  if (e != hipSuccess) return e;
+  e = hipMemcpyAsync(idx->d_key, key, 256, hipMemcpyHostToDevice, st);
+  if (e != hipSuccess) return e;
+  return hipStreamSynchronize(st);           // `key` is a local
+}
+
 #define TRY_HIP(call)                                                                        \
   do {                                                                                       \
     hipError_t e_ = (call);                                                                  \
@@ -405,6 +458,7 @@ extern "C" int pgpu_index_build(pgpu_ctx* ctx, const char* genomic, size_t len, 
   TRY_HIP(hipMalloc((void**)&idx->d_gen, len + 64));
   TRY_HIP(hipMemsetAsync(idx->d_gen, 0, len + 64, st));
   if (len) TRY_HIP(hipMemcpyAsync(idx->d_gen, genomic, len, hipMemcpyHostToDevice, st));
+  TRY_HIP(upload_keys(idx, genomic, len, st));
   TRY_HIP(dmalloc(&idx->d_sa, n + 1));
   TRY_HIP(dmalloc(&idx->d_lcp, n + 2));
   if (n > 0) {
@@ -460,7 +514,7 @@ done:
   hipFree(rank); hipFree(sa2); hipFree(flags); hipFree(newrank); hipFree(keys); hipFree(keys2); hipFree(tmp);
   for (uint32_t* q : round_ranks) hipFree(q);
   hipFree(d_round_ptrs);
-  if (rc != PGPU_OK) { hipFree(idx->d_gen); hipFree(idx->d_sa); hipFree(idx->d_lcp); hipFree(idx->d_klo); hipFree(idx->d_khi); delete idx; return rc; }
+  if (rc != PGPU_OK) { hipFree(idx->d_gen); hipFree(idx->d_sa); hipFree(idx->d_lcp); hipFree(idx->d_klo); hipFree(idx->d_khi); hipFree(idx->d_key); delete idx; return rc; }
   *out = idx;
   return PGPU_OK;
 }
@@ -525,6 +579,7 @@ extern "C" int pgpu_index_load(pgpu_ctx* ctx, const char* path, const char* geno
   TRY_HIP(hipMalloc((void**)&idx->d_gen, len + 64));
   TRY_HIP(hipMemsetAsync(idx->d_gen, 0, len + 64, st));
   if (len) TRY_HIP(hipMemcpyAsync(idx->d_gen, genomic, len, hipMemcpyHostToDevice, st));
+  TRY_HIP(upload_keys(idx, genomic, len, st));
   TRY_HIP(dmalloc(&idx->d_sa, n + 1)); TRY_HIP(dmalloc(&idx->d_lcp, n + 2));
   TRY_HIP(dmalloc(&idx->d_klo, KTAB_ENTRIES)); TRY_HIP(dmalloc(&idx->d_khi, KTAB_ENTRIES));
   if (n) TRY_HIP(hipMemcpyAsync(idx->d_sa, host.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
@@ -533,7 +588,7 @@ extern "C" int pgpu_index_load(pgpu_ctx* ctx, const char* path, const char* geno
   TRY_HIP(hipMemcpyAsync(idx->d_khi, host.data() + 2 * (size_t)n + 1 + KTAB_ENTRIES, KTAB_ENTRIES * 4, hipMemcpyHostToDevice, st));
   TRY_HIP(hipStreamSynchronize(st));
 done:
-  if (rc != PGPU_OK) { hipFree(idx->d_gen); hipFree(idx->d_sa); hipFree(idx->d_lcp); hipFree(idx->d_klo); hipFree(idx->d_khi); delete idx; return rc; }
+  if (rc != PGPU_OK) { hipFree(idx->d_gen); hipFree(idx->d_sa); hipFree(idx->d_lcp); hipFree(idx->d_klo); hipFree(idx->d_khi); hipFree(idx->d_key); delete idx; return rc; }
   *out = idx;
   return PGPU_OK;
 }
@@ -542,7 +597,7 @@ extern "C" int pgpu_index_destroy(pgpu_ctx* ctx, pgpu_index* idx) {
   if (!ctx || !idx) return PGPU_EINVAL;
   if (pgpu_ctx_bind(ctx) != PGPU_OK) return PGPU_EDEVICE;
   hipStreamSynchronize(pgpu_ctx_stream(ctx));
-  hipFree(idx->d_gen); hipFree(idx->d_sa); hipFree(idx->d_lcp); hipFree(idx->d_klo); hipFree(idx->d_khi);
+  hipFree(idx->d_gen); hipFree(idx->d_sa); hipFree(idx->d_lcp); hipFree(idx->d_klo); hipFree(idx->d_khi); hipFree(idx->d_key);
   delete idx;
   return PGPU_OK;
 }
@@ -675,7 +730,7 @@ extern "C" int pgpu_pairing_plan_run(pgpu_ctx* ctx, pgpu_pairing_plan* p, const 
   hipLaunchKernelGGL(pair_chain_kernel, dim3((unsigned)((p->n_pat + 63) / 64)), pblk, 0, st, ix->d_gen, n, ix->d_sa, ix->d_lcp,
                      p->d_pats, p->d_pat_off, (uint32_t)p->n_pat, prm, p->d_lo, p->d_hi, p->d_a, p->d_thr);
   if (p->ev[2]) TRY_HIP(hipEventRecord(p->ev[2], st));
-  hipLaunchKernelGGL(pair_count_kernel, pgrid, pblk, 0, st, ix->d_gen, n, ix->d_sa, p->d_pats, p->d_pat_off, prm, p->d_lo, p->d_hi, p->d_thr, p->d_cnt);
+  hipLaunchKernelGGL(pair_count_kernel, pgrid, pblk, 0, st, ix->d_gen, n, ix->d_sa, ix->d_key, ix->sigma, p->d_pats, p->d_pat_off, prm, p->d_lo, p->d_hi, p->d_thr, p->d_cnt);
   TRY_HIP(hipMemsetAsync(p->d_cnt + tp, 0, sizeof(uint32_t), st));
   pgpu_exclusive_scan_u32(p->d_cnt, p->d_cand_off, tp + 1, p->d_tmp, st);
   if (p->ev[3]) TRY_HIP(hipEventRecord(p->ev[3], st));
@@ -688,7 +743,7 @@ extern "C" int pgpu_pairing_plan_run(pgpu_ctx* ctx, pgpu_pairing_plan* p, const 
     NEED(p->d_cand = plan_alloc<Cand>(p, 13, p->cand_cap));
     NEED(p->d_keep = plan_alloc<uint8_t>(p, 14, p->cand_cap));
   }
-  hipLaunchKernelGGL(pair_fill_kernel, pgrid, pblk, 0, st, ix->d_gen, n, ix->d_sa, p->d_pats, p->d_pat_off, prm, p->d_lo, p->d_hi, p->d_thr,
+  hipLaunchKernelGGL(pair_fill_kernel, pgrid, pblk, 0, st, ix->d_gen, n, ix->d_sa, ix->d_key, ix->sigma, p->d_pats, p->d_pat_off, prm, p->d_lo, p->d_hi, p->d_thr,
                      p->d_cand_off, p->d_cand, p->d_cnt_a);
   if (p->ev[4]) TRY_HIP(hipEventRecord(p->ev[4], st));
   hipLaunchKernelGGL(pair_cross_kernel, pgrid, pblk, 0, st, p->d_pat_off, p->d_cand_off, p->d_cand, p->d_cnt_a, p->d_keep, p->d_cnt_b);

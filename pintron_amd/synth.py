@@ -225,6 +225,47 @@ def make_region_start_repeats(seed=5):
     return w.genomic_fasta(), w.ests_fasta()
 
 
+def make_region_start_copies(seed=7):
+    """ESTs for which the reference lists the pairing with t == 0 more than once (the occurrence without
+    a preceding character sits in every symbol slice of the reference's suffix tree and is reported per
+    slice at an upper tree level, src/max-emb-graph.c:168-216): exon-like blocks elsewhere in the
+    region begin with a copy of the region's first 40-70 bases behind a varying character, and
+    transcripts start (after 0, 1 or 30 unrelated bases) on such a copy.  The repeated vertex goes
+    through MEG construction, simplification and the writers.  Returns (genomic, ests) FASTA texts."""
+    import random
+    w = make("C2", n_est=6, seed=seed)
+    G = bytearray(w.genomic)
+    rng = random.Random(seed)
+    spots = []
+    for k, pos in enumerate((2500, 6000, 11000, 16000, 21000, 26000, 31000, 36000)):
+        n = (40, 55, 70, 45, 60, 50, 65, 42)[k]
+        G[pos - 1] = b"ACGT"[k % 4]
+        G[pos:pos + n] = G[0:n]
+        spots.append((pos, n))
+    G = bytes(G)
+    w.genomic = G
+
+    def rc(s):
+        return s[::-1].translate(bytes.maketrans(b"ACGT", b"TGCA"))
+
+    def junk(n):
+        return bytes(rng.choice(b"ACGT") for _ in range(n))
+
+    e1s, e1e = w.exons[1]
+    seqs, heads = list(w.est_seqs), list(w.est_headers)
+    k = 0
+    for pos, n in spots:
+        for lead in (0, 1, 30):
+            for tail in (G[pos + n:pos + n + 120], G[pos + n:pos + n + 90] + G[e1s:e1e][:120]):
+                x = junk(lead) + G[pos:pos + n] + tail
+                for y in (x, rc(x)):
+                    seqs.append(y)
+                    heads.append(">/gb=TC%05d /clone_end=3'" % k)
+                    k += 1
+    w.est_seqs, w.est_headers = seqs, heads
+    return w.genomic_fasta(), w.ests_fasta()
+
+
 def make_edge_cases(seed=5):
     """Inputs around the corners of the input handling: N tails and internal N runs in the genomic
     sequence, negative-strand header, ESTs that are too short / all N / lower case / polyA only /

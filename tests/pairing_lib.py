@@ -130,3 +130,33 @@ def repeat_workload(seed, gen_len=30000):
         ests.append(gen[a:a + rng.randint(100, 700)])
     ests += [gen[:300], gen[5:200], b"ACAC" * 40, b"A" * 100, b"ACGTNNNNACGT" * 10, b"A", b""]
     return gen, ests
+
+
+def region_start_cases(seed, n_cases=60):
+    """Small genomic sequences whose first bases are repeated elsewhere behind another character, and
+    ESTs that match the repeat for longer than they match the region start: the occurrence t == 0 is
+    then reported at an upper level of the reference's suffix tree, once per symbol slice it walks
+    (oracle/pairing_oracle.c) -- about half of the cases hold the pairing (i, 0, l) twice.  Alphabets
+    of 2..5 symbols, the preceding EST character present, absent (i == 0) or foreign ('N').
+    Returns [(genomic, [est, ...]), ...]."""
+    rng = random.Random(seed)
+
+    def rs(n, al=b"ACGT"):
+        return bytes(rng.choice(al) for _ in range(n))
+
+    out = []
+    for _ in range(n_cases):
+        al = rng.choice([b"ACGT", b"ACGT", b"ACGT", b"ACGTN", b"AC", b"ACG"])
+        head, x = rs(60, al), rs(120, al)
+        rep = rng.choice([20, 40, 55])
+        gen = head + rs(rng.choice([5, 300]), al) + rs(1, al) + head[:rep] + x + rs(300, al)
+        if rng.random() < 0.3:
+            gen += head[:35] + rs(50, al)
+        ests = []
+        for lead in (0, 1, 30):
+            est = rs(lead, b"ACGTN") + head[:rep] + x[:rng.choice([60, 100])]
+            if rng.random() < 0.3 and len(est) > 60:
+                est = est[:50] + rs(1, al) + est[51:]
+            ests.append(est)
+        out.append((gen, ests))
+    return out

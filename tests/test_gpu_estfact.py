@@ -139,6 +139,26 @@ def test_region_start_pairings_vs_compiled_reference(exe, tmp_path):
     assert (my_dir / "raw-multifasta-out.txt").read_text().count(">/gb=T0") >= 30
 
 
+def test_region_start_copies_vs_compiled_reference(exe, tmp_path):
+    """ESTs whose t == 0 pairing the reference lists more than once (synth.make_region_start_copies):
+    the GPU pairing kernels must produce the copies and the GPU MEG stage must carry the repeated
+    vertex exactly as the reference's lists do."""
+    ref = os.path.join(ROOT, "oracle", "_ref", "est-fact-core")
+    if not os.path.exists(ref):
+        pytest.skip("oracle/_ref/est-fact-core not present")
+    from pintron_amd import synth
+    g, e = synth.make_region_start_copies()
+    ref_dir, my_dir = tmp_path / "ref", tmp_path / "mine"
+    for d in (ref_dir, my_dir):
+        d.mkdir()
+        (d / "genomic.txt").write_text(g)
+        (d / "ests.txt").write_text(e)
+    subprocess.run([ref], cwd=ref_dir, check=True, stderr=subprocess.DEVNULL)
+    subprocess.run([exe], cwd=my_dir, check=True)
+    for f in FILES:
+        assert filecmp.cmp(my_dir / f, ref_dir / f, shallow=False), f
+
+
 def test_long_transcripts_vs_compiled_reference(exe, tmp_path):
     """Full-length transcripts with a 5.6 kb exon: alignments, K-band distances and affix searches
     with more than 4096 rows (strips) inside the whole program."""

@@ -251,3 +251,29 @@ def test_split_parse_of_ests_file(bins, tmp_path):
         run(bins["estfact_sched_check"], my_dir, {"PINTRON_THREADS": "2", "PINTRON_PARSE_SPLIT": "1"})
         for f in FILES:
             assert filecmp.cmp(my_dir / f, ref_dir / f, shallow=False), (tag, f)
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
+def test_region_start_copies_match_compiled_reference(bins, tmp_path):
+    """ESTs for which the reference holds the t == 0 pairing more than once (synth.make_region_start_copies):
+    the repeated vertex through MEG construction, simplification, factorization and the writers,
+    sequential program and scheduler (device-style MEG records included), against the reference."""
+    from pintron_amd import synth
+    g, e = synth.make_region_start_copies()
+    ref_dir = tmp_path / "ref"
+    ref_dir.mkdir()
+    (ref_dir / "genomic.txt").write_text(g)
+    (ref_dir / "ests.txt").write_text(e)
+    subprocess.run([os.path.join(O.REF_DIR, "est-fact-core")], cwd=ref_dir, check=True, stderr=subprocess.DEVNULL)
+    megs = (ref_dir / "megs.txt").read_text()
+    blocks = [b.split("#adj#")[0].splitlines()[2:] for b in megs.split("***********")[1:]]
+    assert sum(1 for b in blocks if len(set(b)) != len(b)) >= 4, "the generator no longer produces repeated vertices"
+    for which, env in (("estfact_check", {}), ("estfact_sched_check", {"PINTRON_THREADS": "2"}),
+                       ("estfact_sched_check", {"PINTRON_THREADS": "2", "PINTRON_GPU_MEG": "0"})):
+        my_dir = tmp_path / ("mine_%s_%d" % (which, len(env)))
+        my_dir.mkdir()
+        (my_dir / "genomic.txt").write_text(g)
+        (my_dir / "ests.txt").write_text(e)
+        run(bins[which], my_dir, env)
+        for f in FILES:
+            assert filecmp.cmp(my_dir / f, ref_dir / f, shallow=False), (which, f)

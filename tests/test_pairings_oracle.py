@@ -57,3 +57,28 @@ def test_golden_pairings():
             n += 1
         oi.close()
     assert n > 300
+
+
+@needs_ref
+def test_region_start_copies_match_reference():
+    """The occurrence t == 0 reported at an upper level of the reference's tree comes out once per
+    symbol slice walked (src/max-emb-graph.c:168-216): the oracle's closed form against the
+    reference's own build_vertex_set on fresh random cases (the committed golden set holds others)."""
+    n_dup = n = 0
+    for gen, ests in PL.region_start_cases(101, n_cases=40):
+        oi, ri = PL.OracleIndex(gen), PL.RefIndex(gen)
+        for e in ests:
+            for L, rate in ((15, 0.2), (18, 0.1)):
+                a, b = oi.pairings(e, L, rate).tolist(), ri.pairings(e, L, rate).tolist()
+                assert a == b, (gen[:70], e[:70], L, rate)
+                n_dup += len(set(map(tuple, b))) != len(b)
+                n += 1
+        oi.close()
+    assert n_dup >= 20 and n >= 200
+
+
+def test_golden_set_holds_repeated_pairings():
+    with gzip.open(os.path.join(GOLD, "pairings.json.gz"), "rt") as f:
+        gold = json.load(f)
+    rep = sum(1 for s in gold["sets"] for c in s["cases"] if len(set(map(tuple, c["pairings"]))) != len(c["pairings"]))
+    assert rep >= 30

@@ -126,6 +126,18 @@ def main():
             if e:
                 cases.append(dict(est=e.decode(), L=L, rate=rate, pairings=ri.pairings(e, L, rate).tolist()))
     sets.append(dict(genomic=gen.decode(), cases=cases))
+    # the occurrence t == 0 at upper tree levels (copies of one pairing): tests/pairing_lib.py
+    n_dup = 0
+    for gen, ests in PL.region_start_cases(11):
+        ri = PL.RefIndex(gen)
+        cases = []
+        for e in ests:
+            for L, rate in ((15, 0.2), (18, 0.1)):
+                pr = ri.pairings(e, L, rate).tolist()
+                n_dup += len(set(map(tuple, pr))) != len(pr)
+                cases.append(dict(est=e.decode(), L=L, rate=rate, pairings=pr))
+        sets.append(dict(genomic=gen.decode(), cases=cases))
+    print("region-start cases with a repeated pairing:", n_dup)
     with gzip.open(os.path.join(GOLD, "pairings.json.gz"), "wt") as f:
         json.dump(dict(sets=sets), f)
     print("pairing cases:", sum(len(s["cases"]) for s in sets))
