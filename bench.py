@@ -156,6 +156,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--ests", type=int, default=N_EST_BATCH, help="ESTs per GPU per step (default: C3)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / parity leg")
+    ap.add_argument("--no-oneshot", action="store_true", help="skip the one-process start-to-files measurement")
     ap.add_argument("--workload", choices=("C3", "C4"), default="C3",
                     help="C3 (default, the metric's configuration): one 200 kb gene x --ests per GPU; "
                          "C4: 8 genes x 200 kb, --ests ESTs each (62 500 = BASELINE.json configs[3]), gene g on rank g mod N")
@@ -266,13 +267,36 @@ def main():
                        "dp_batches_per_step": int(sum(x.dp_batches for x in stats[-1])),
                        "parallelism": "est-shard x%d" % world},
             "dp_mcells_per_s": sum(k["cells"] for k in kernels.values()) * world / step_s / 1e6,
-            # md5 of rank 0's raw-multifasta-out text of the LAST TIMED step (tools/big_parity_check.py
-            # produces the same checksum from the reference CPU est-fact: tests/golden/bench_md5.json)
             "timed_output_md5": hashlib.md5(b"".join(sess.records() for sess in sessions)).hexdigest(),
             "phases_s": {"load_once": st.load_s, "index_once": st.index_s, "prefetch_pairings": st.prefetch_s,
                          "workers_wall": st.workers_s, "host_cpu_per_thread": st.host_s / st.threads,
                          "dp_batches_per_thread": st.dp_s / st.threads},
         }
+        # the text the LAST TIMED step left on rank 0 against the reference's checksum for the very same
+        # batch (tools/make_bench_md5.py ran the reference object code on it in the build container)
+        gold_path = os.path.join(ROOT, "tests", "golden", "bench_md5.json")
+        if args.workload == "C3" and os.path.exists(gold_path):
+            gold = json.load(open(gold_path)).get("C3:%d:seed%d" % (n_est, genes[0][1]))
+            if gold:
+                same = gold["raw-multifasta-out.txt"] == out["timed_output_md5"]
+                out["timed_output"] = {"ests": n_est, "md5": out["timed_output_md5"], "reference_md5": gold["raw-multifasta-out.txt"],
+                                       "identical_to_reference": same}
+                if not same:
+                    raise SystemExit("bench: the timed step's raw-multifasta-out differs from the reference's (md5 %s vs %s)"
+                                     % (out["timed_output_md5"], gold["raw-multifasta-out.txt"]))
+        if world == 1 and args.workload == "C3" and not args.no_oneshot:
+            # the way the pipeline driver uses est-fact (dist-scripts/pintron.py:878-884): one process per
+            # gene, process start -> the six files on disk.  Outside the timed steps; the resident
+            # sessions above keep their HBM.
+            exe = os.path.join(ROOT, "pintron_amd", "bin", "est-fact")
+            t_one = time.perf_counter()
+            rc_one = subprocess.run([exe], cwd=works[0], stderr=subprocess.DEVNULL).returncode
+            t_one = time.perf_counter() - t_one
+            if rc_one == 0:
+                raw = open(os.path.join(works[0], "raw-multifasta-out.txt"), "rb").read()
+                out["oneshot"] = {"seconds": t_one, "ESTs_per_s": n_est / t_one,
+                                  "what": "est-fact process start -> six files on disk, same %d-EST batch" % n_est,
+                                  "md5_equals_timed_step": hashlib.md5(raw).hexdigest() == out["timed_output_md5"]}
         if kernels:
             name, dom = max(kernels.items(), key=lambda kv: kv[1]["ms"])
             per_launch_ms = dom["ms"] / max(dom["launches"], 1)

@@ -225,8 +225,11 @@ typedef struct {
 /* limits (per job); larger jobs get status PGPU_ERANGE */
 #define PGPU_MAX_ROWS_LEV     65536u  /* ALIGN, AFFIX: a_len; ED, KBAND: min(a_len,b_len) (beyond 4096 rows
                                         one wave sweeps the matrix in strips of 4096 rows) */
-#define PGPU_MAX_ROWS_BORDERS 4096u  /* BORDERS: a_len */
-#define PGPU_MAX_ROWS_GAP     2048u  /* GAP: a_len */
+#define PGPU_MAX_ROWS_BORDERS 4096u  /* BORDERS: a_len of the fast kernels; up to PGPU_MAX_ROWS_LEV a slow
+                                        anti-diagonal kernel over HBM answers instead of refusing */
+#define PGPU_MAX_ROWS_GAP     2048u  /* GAP: a_len of the fast kernels; larger windows take the slow kernel */
+#define PGPU_MAX_GAP_SIDE    16000u  /* GAP: a_len and b_len */
+#define PGPU_MAX_GAP_CELLS (1ull << 27)   /* GAP: (a_len+1)*(b_len+1), one direction byte per cell */
 #define PGPU_MAX_COLS      1048576u
 
 /* A plan holds a batch of jobs resident in HBM: operands, sorted job table, workspaces, results.

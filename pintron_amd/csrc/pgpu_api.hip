@@ -325,8 +325,9 @@ extern "C" int pgpu_dp_plan_create_parts(pgpu_ctx* ctx, const pgpu_index* idx, c
         if (la > PGPU_MAX_ROWS_LEV || lb > PGPU_MAX_COLS) continue;
         k.family = KF_ALIGN; k.R = row_class(la); k.size = (uint64_t)la * lb; break;
       case PGPU_DP_GAP:
-        if (la > PGPU_MAX_ROWS_GAP || lb > 16000u || la > 16000u) continue;
-        k.family = KF_GAP; k.R = row_class(la); k.size = (uint64_t)la * lb; break;
+        if (lb > PGPU_MAX_GAP_SIDE || la > PGPU_MAX_GAP_SIDE || ((uint64_t)la + 1) * ((uint64_t)lb + 1) > PGPU_MAX_GAP_CELLS) continue;
+        // beyond 2048 rows: the anti-diagonal kernel over HBM (slow, but the reference computes these too)
+        k.family = KF_GAP; k.R = la > PGPU_MAX_ROWS_GAP ? ROW_CLASS_STRIPS : row_class(la); k.size = (uint64_t)la * lb; break;
       case PGPU_DP_ED:
         if (std::min(la, lb) > PGPU_MAX_ROWS_LEV || std::max(la, lb) > PGPU_MAX_COLS) continue;
         k.family = KF_ED; k.R = row_class(std::min(la, lb)); k.size = (uint64_t)la * lb; break;
@@ -343,7 +344,7 @@ extern "C" int pgpu_dp_plan_create_parts(pgpu_ctx* ctx, const pgpu_index* idx, c
       case PGPU_DP_BORDERS:
         // only the first and the last t_win = min(len_p + max_errs, len_t) characters of t are swept
         // (src/refine.c:117-121): t may be a whole intron of any length the index can hold
-        if (la > PGPU_MAX_ROWS_BORDERS || std::min<uint64_t>((uint64_t)la + in.p2, lb) > PGPU_MAX_COLS) continue;
+        if (la > PGPU_MAX_ROWS_LEV || std::min<uint64_t>((uint64_t)la + in.p2, lb) > PGPU_MAX_COLS) continue;
         if (in.p0 > in.p1 || in.p1 > la) { pre.status = PGPU_EINVAL; continue; }
         // cells as the reference bounds them: two matrices of len_p x t_win, t_win = min(len_p + max_errs, len_t)
         // (src/refine.c:117-121); the gap of check_gap_errors is a whole intron, the window a few dozen columns
@@ -383,7 +384,12 @@ extern "C" int pgpu_dp_plan_create_parts(pgpu_ctx* ctx, const pgpu_index* idx, c
   size_t ws = 0, strs = 0, nkeys = 0;
   for (auto& k : v) {
     const uint32_t la = k.j.la, lb = k.j.lb;
-    if (k.R == ROW_CLASS_STRIPS) {            // two boundary rows, then (ALIGN) the directions of every strip
+    if (k.R == ROW_CLASS_STRIPS && k.family == KF_GAP) {          // gap_slow_kernel: 9 rolling diagonals + 1 B per cell
+      k.j.ws_off = ws; ws += (size_t)9 * ((size_t)la + 1) * 4 + ((size_t)la + 1) * ((size_t)lb + 1);
+      k.j.str_off = strs; strs += 2 * ((size_t)la + lb + 1);
+    } else if (k.R == ROW_CLASS_STRIPS && k.family == KF_BORDERS) {   // borders_slow_kernel: 3 diagonals + 4 row-minima arrays
+      k.j.ws_off = ws; ws += (size_t)7 * ((size_t)la + 1) * 4;
+    } else if (k.R == ROW_CLASS_STRIPS) {     // two boundary rows, then (ALIGN) the directions of every strip
       const uint32_t nc = (k.family == KF_ED || k.family == KF_KBAND) ? std::max(la, lb) : lb;
       k.j.ws_off = ws; ws += 2 * strip_bnd_bytes(nc);
       if (k.family == KF_ALIGN) {
@@ -411,6 +417,7 @@ extern "C" int pgpu_dp_plan_create_parts(pgpu_ctx* ctx, const pgpu_index* idx, c
     // a launch group = a family; BORDERS and AFFIX split into (up to 64 rows: one wave per job),
     // (more rows: one job per workgroup) and, AFFIX only, (beyond 4096 rows: strips)
     auto variant = [](const Keyed& k) -> int {
+      if (k.family == KF_GAP) return k.R == ROW_CLASS_STRIPS ? (int)ROW_CLASS_STRIPS : 0;
       if (k.family != KF_BORDERS && k.family != KF_AFFIX) return 0;
       return k.R == 1 ? 1 : (k.R == ROW_CLASS_STRIPS ? (int)ROW_CLASS_STRIPS : 0);
     };
@@ -426,7 +433,7 @@ extern "C" int pgpu_dp_plan_create_parts(pgpu_ctx* ctx, const pgpu_index* idx, c
       // (BORDERS touches the first and the last t_win characters of t only)
       g.algo_bytes += la + (k.family == KF_BORDERS ? std::min<uint64_t>(lb, 2 * std::min<uint64_t>(la + k.j.p2, lb)) : lb);
       g.max_rows = std::max(g.max_rows, (uint32_t)la);
-      if (k.R >= (k.family == KF_GAP ? 8u : 32u)) ++g.n_big;
+      if (k.R >= (k.family == KF_GAP ? 8u : 32u)) ++g.n_big;       // (the slow GAP / BORDERS groups ignore it)
       if (k.family == KF_ALIGN) g.algo_bytes += la * lb + 3 * (la + lb);     // + directions read back, two strings
       if (k.family == KF_GAP) g.algo_bytes += 3 * la * lb + 3 * (la + lb);
       if (k.family == KF_BORDERS) g.algo_bytes += 2 * 8 * la;
@@ -444,6 +451,8 @@ extern "C" int pgpu_dp_plan_create_parts(pgpu_ctx* ctx, const pgpu_index* idx, c
     if (g.family == KF_BORDERS && g.R == 1) snprintf(nm, sizeof nm, "lev_wave<BORDERS,R=1>");
     else if (g.family == KF_AFFIX && g.R == 1) snprintf(nm, sizeof nm, "lev_wave<AFFIX,R=1>");
     else if (g.family == KF_AFFIX && g.R == (int)ROW_CLASS_STRIPS) snprintf(nm, sizeof nm, "lev_wave<AFFIX,strips>");
+    else if (g.family == KF_BORDERS && g.R == (int)ROW_CLASS_STRIPS) snprintf(nm, sizeof nm, "borders_slow");
+    else if (g.family == KF_GAP && g.R == (int)ROW_CLASS_STRIPS) snprintf(nm, sizeof nm, "gap_slow");
     else snprintf(nm, sizeof nm, "%s", fam[g.family]);
     g.name = nm;
     p->groups.push_back(g);
@@ -589,7 +598,10 @@ extern "C" int pgpu_dp_plan_launch(pgpu_ctx* ctx, pgpu_dp_plan* p) {
       switch (g.family) {
         case KF_ALIGN: case KF_ED: case KF_BORDERS: case KF_AFFIX: case KF_KBAND:
           launch_lev(g.family, g.R, g.max_rows, jobs, n, (int)g.n_big, p->d_results, p->d_ws, p->d_strs, st); break;
-        case KF_GAP: launch_gap(jobs, n, (int)g.n_big, p->d_results, p->d_ws, p->d_strs, st); break;
+        case KF_GAP:
+          if (g.R == (int)ROW_CLASS_STRIPS) launch_gap_slow(jobs, n, p->d_results, p->d_ws, p->d_strs, st);
+          else launch_gap(jobs, n, (int)g.n_big, p->d_results, p->d_ws, p->d_strs, st);
+          break;
         case KF_LCF:
           launch_lcf(jobs, n, g.max_chunks, g.max_l2, p->d_keys + key_of[gi], st);
           launch_lcf_finish(jobs, n, p->d_results, p->d_keys + key_of[gi], st);

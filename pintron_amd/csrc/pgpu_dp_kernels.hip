@@ -1208,6 +1208,151 @@ __global__ void lcf_finish_kernel(const DevJob* __restrict__ jobs, int njobs,
   res->v[2] = (int32_t)(0xFFFFu - (uint32_t)(key & 0xFFFFu));
 }
 
+// ---------------------------------------------------------------------------------------------
+// Jobs beyond the row limits of the register-resident kernels (GAP windows of more than 2048 EST
+// characters, BORDERS patterns of more than 4096): the reference computes them, slowly, so they
+// must not be refused.  One workgroup per job walks the anti-diagonals of the matrix with three
+// rolling diagonals per plane in the job's HBM workspace; cell (i, j) only needs diagonals d-1 and
+// d-2, thread q owns the rows i = q+1, q+1+256, ...  Nothing here is tuned: such jobs are rare
+// (long reads with a long unaligned stretch) and a slow answer beats an abort.
+// ---------------------------------------------------------------------------------------------
+constexpr int SLOW_BLOCK = 256;
+
+// ComputeGapAlignMatrix + TracebackGapAlignment (src/refine-intron.c:623-890), semantics as in
+// gap_wave_body / gap_traceback_wave.  Workspace: [9 x (n+1) int32 rolling diagonals][(n+1)*(m+1) bytes:
+// bits 0-1 L direction, bit 2 G "came from L", bits 3-4 R direction (3 = came from G)]
+__global__ __launch_bounds__(SLOW_BLOCK)
+void gap_slow_kernel(const DevJob* __restrict__ jobs, int njobs, DevResult* __restrict__ results,
+                     uint8_t* __restrict__ ws, uint8_t* __restrict__ strs) {
+  const DevJob job = jobs[blockIdx.x];
+  DevResult* res = &results[job.out_idx];
+  const uint32_t n = job.la, m = job.lb, cap = n + m + 1;
+  int32_t* diag = (int32_t*)(ws + job.ws_off);
+  uint8_t* dirs = ws + job.ws_off + (size_t)9 * (n + 1) * sizeof(int32_t);
+  const size_t w = (size_t)m + 1;
+  auto plane = [&](int which, uint32_t d) -> int32_t* { return diag + ((size_t)(which * 3 + (int)(d % 3u))) * (n + 1); };
+  for (uint32_t d = 2; d <= n + m; ++d) {
+    const int32_t *L1 = plane(0, d - 1), *L2 = plane(0, d - 2), *G1 = plane(1, d - 1), *R1 = plane(2, d - 1), *R2 = plane(2, d - 2);
+    int32_t *Lc = plane(0, d), *Gc = plane(1, d), *Rc = plane(2, d);
+    for (uint32_t i = threadIdx.x + 1; i <= n; i += SLOW_BLOCK) {
+      if (d <= i) break;
+      const uint32_t j = d - i;
+      if (j > m) continue;
+      // neighbours on the zero border (row 0 / column 0 of every plane) read as 0
+      const bool up_ok = i > 1, left_ok = j > 1;
+      const uint32_t ce = job.a[i - 1], cg = job.b[j - 1];
+      const int32_t sub = (ce == cg || is_n(ce) || is_n(cg)) ? 1 : -1;
+      const int32_t l_diag = (up_ok && left_ok) ? L2[i - 1] : 0, l_up = up_ok ? L1[i - 1] : 0, l_left = left_ok ? L1[i] : 0;
+      const int32_t g_left = left_ok ? G1[i] : 0;
+      const int32_t r_diag = (up_ok && left_ok) ? R2[i - 1] : 0, r_up = up_ok ? R1[i - 1] : 0, r_left = left_ok ? R1[i] : 0;
+      int32_t v = l_diag + sub; uint32_t dl = 0;
+      if (v < l_up - 1) { v = l_up - 1; dl = 1; }
+      if (v < l_left - 1) { v = l_left - 1; dl = 2; }
+      Lc[i] = v;
+      v = g_left; uint32_t dg = 0;
+      if (v < l_left) { v = l_left; dg = 1; }
+      Gc[i] = v;
+      v = r_diag + sub; uint32_t dr = 0;
+      const int32_t left = (i != n) ? r_left - 1 : r_left;            // free trailing gap (:756-759)
+      if (v < left) { v = left; dr = 2; }
+      if (v < g_left) { v = g_left; dr = 3; }
+      if (v < r_up - 1) { v = r_up - 1; dr = 1; }
+      Rc[i] = v;
+      dirs[(size_t)i * w + j] = (uint8_t)(dl | (dg << 2) | (dr << 3));
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x != 0) return;
+  uint8_t* ea = strs + job.str_off;
+  uint8_t* ga = ea + cap;
+  int32_t pl = 0;
+  if (n > 0 && m > 0) {
+    const uint32_t d = n + m;
+    const int32_t l = plane(0, d)[n], g = plane(1, d)[n], r = plane(2, d)[n];
+    if (r >= g) pl = (r >= l) ? 2 : 0; else pl = (g >= l) ? 1 : 0;   // :808-819
+  } else pl = 2;                                                   // all three are 0
+  int32_t factor_cut = 0, intron_start = 0, intron_end = 0, rev_start = -1, rev_end = -1;
+  uint32_t i = n, j = m, pos = cap - 1, k = 0;
+  ea[pos] = 0; ga[pos] = 0;
+  while (i > 0 && j > 0) {
+    const uint32_t b = dirs[(size_t)i * w + j];
+    const uint32_t dd = pl == 2 ? ((b >> 3) & 3u) : (pl == 1 ? (((b >> 2) & 1u) ? 3u : 2u) : (b & 3u));
+    --pos;
+    if (dd == 0)      { ea[pos] = job.a[--i]; ga[pos] = job.b[--j]; }
+    else if (dd == 1) { ea[pos] = job.a[--i]; ga[pos] = '-'; }
+    else {
+      if (dd == 3) {
+        if (pl == 2) { intron_end = (int32_t)j - 1; factor_cut = (int32_t)i; rev_end = (int32_t)k; }
+        else         { intron_start = (int32_t)j - 1; rev_start = (int32_t)k; }
+        --pl;
+      }
+      ea[pos] = '-'; ga[pos] = job.b[--j];
+    }
+    ++k;
+  }
+  while (i > 0) { --pos; ea[pos] = job.a[--i]; ga[pos] = '-'; ++k; }
+  while (j > 0) { --pos; ea[pos] = '-'; ga[pos] = job.b[--j]; ++k; }
+  res->status = 0;
+  res->v[0] = (int32_t)k; res->v[1] = factor_cut; res->v[2] = intron_start; res->v[3] = intron_end;
+  res->v[4] = rev_start >= 0 ? (int32_t)k - 1 - rev_start : 0;
+  res->v[5] = rev_end >= 0 ? (int32_t)k - 1 - rev_end : 0;
+  res->pad = 0;
+  res->str[0] = job.str_off + pos;
+  res->str[1] = job.str_off + cap + pos;
+}
+
+// general_refine_borders (src/refine.c:105-192) for patterns of more than 4096 characters.
+// Workspace: [3 x (len_p+1) uint32 rolling diagonals][pre, pre_pos, suf, suf_pos: 4 x (len_p+1) uint32]
+__global__ __launch_bounds__(SLOW_BLOCK)
+void borders_slow_kernel(const DevJob* __restrict__ jobs, int njobs, DevResult* __restrict__ results, uint8_t* __restrict__ ws) {
+  const DevJob job = jobs[blockIdx.x];
+  DevResult* res = &results[job.out_idx];
+  const uint32_t len_p = job.la, len_t = job.lb, max_errs = job.p2;
+  const uint32_t t_win = min(len_p + max_errs, len_t);
+  uint32_t* diag = (uint32_t*)(ws + job.ws_off);
+  uint32_t* mins = diag + (size_t)3 * (len_p + 1);
+  for (int sweep = 0; sweep < 2; ++sweep) {
+    uint32_t* mv = mins + (size_t)(2 * sweep) * (len_p + 1);
+    uint32_t* mp = mv + (len_p + 1);
+    const Operand rows{job.a, len_p, sweep == 1}, cols{job.b, len_t, sweep == 1};
+    for (uint32_t i = threadIdx.x; i <= len_p; i += SLOW_BLOCK) { mv[i] = i; mp[i] = 0; }     // column 0: M[i][0] = i
+    __syncthreads();
+    for (uint32_t d = 2; d <= len_p + t_win; ++d) {
+      const uint32_t *D1 = diag + (size_t)((d - 1) % 3u) * (len_p + 1), *D2 = diag + (size_t)((d - 2) % 3u) * (len_p + 1);
+      uint32_t* Dc = diag + (size_t)(d % 3u) * (len_p + 1);
+      for (uint32_t i = threadIdx.x + 1; i <= len_p; i += SLOW_BLOCK) {
+        if (d <= i) break;
+        const uint32_t j = d - i;
+        if (j > t_win) continue;
+        const uint32_t dg = i == 1 ? j - 1 : (j == 1 ? i - 1 : D2[i - 1]);
+        const uint32_t up = i == 1 ? j : D1[i - 1];
+        const uint32_t lf = j == 1 ? i : D1[i];
+        uint32_t v = dg + (rows.at(i - 1) == cols.at(j - 1) ? 0u : 1u);
+        if (v > up + 1) v = up + 1;
+        if (v > lf + 1) v = lf + 1;
+        Dc[i] = v;
+        if (mv[i] > v) { mv[i] = v; mp[i] = j; }            // strict: the first arg-min of the row (:133-159)
+      }
+      __syncthreads();
+    }
+  }
+  if (threadIdx.x != 0) return;
+  const uint32_t *pre = mins, *pre_pos = mins + (len_p + 1), *suf = mins + (size_t)2 * (len_p + 1), *suf_pos = mins + (size_t)3 * (len_p + 1);
+  const uint32_t avail = len_t + min(job.tail, 2u);
+  const uint32_t lo = job.p0, hi = job.p1 > job.p0 ? job.p1 : job.p0;
+  uint32_t bi = lo, bc = pre[lo] + suf[len_p - lo];
+  int bf = burset_adaptor(job.b, avail, pre_pos[lo], len_t - suf_pos[len_p - lo]);
+  for (uint32_t i = lo + 1; i <= hi; ++i) {
+    const int freq = burset_adaptor(job.b, avail, pre_pos[i], len_t - suf_pos[len_p - i]);
+    const uint32_t c = pre[i] + suf[len_p - i];
+    if (bc > c || (bc == c && freq > bf)) { bc = c; bf = freq; bi = i; }
+  }
+  res->status = 0;
+  res->v[0] = bc <= max_errs ? 1 : 0;
+  res->v[1] = (int32_t)bi; res->v[2] = (int32_t)pre_pos[bi];
+  res->v[3] = (int32_t)(len_t - suf_pos[len_p - bi]); res->v[4] = (int32_t)bc;
+}
+
 }  // namespace
 
 // R = 0: every row class of the family in one launch (ED, ALIGN, KBAND: the first n_big jobs are
@@ -1235,6 +1380,8 @@ void launch_lev(int family, int R, uint32_t max_rows, const DevJob* jobs, int nj
       if (R == 1) {
         const size_t lds = 4 * (64 + 1) * sizeof(uint32_t);
         hipLaunchKernelGGL((lev_wave_kernel<1, MODE_BORDERS>), dim3(njobs), dim3(64), lds, st, jobs, njobs, res, ws);
+      } else if (R == (int)ROW_CLASS_STRIPS) {
+        hipLaunchKernelGGL(borders_slow_kernel, dim3(njobs), dim3(SLOW_BLOCK), 0, st, jobs, njobs, res, ws);
       } else {
         const size_t lds = (2 * (COOP_W - 1) * 128 + 4 * ((size_t)max_rows + 1)) * sizeof(uint32_t);
         hipLaunchKernelGGL(borders_coop_any_kernel, dim3(njobs), dim3(512), lds, st, jobs, njobs, res);
@@ -1247,6 +1394,11 @@ void launch_lev(int family, int R, uint32_t max_rows, const DevJob* jobs, int nj
       break;
     default: break;
   }
+}
+
+void launch_gap_slow(const DevJob* jobs, int njobs, DevResult* res, uint8_t* ws, uint8_t* strs, hipStream_t st) {
+  if (njobs <= 0) return;
+  hipLaunchKernelGGL(gap_slow_kernel, dim3(njobs), dim3(SLOW_BLOCK), 0, st, jobs, njobs, res, ws, strs);
 }
 
 void launch_gap(const DevJob* jobs, int njobs, int n_big, DevResult* res, uint8_t* ws, uint8_t* strs, hipStream_t st) {

@@ -140,8 +140,11 @@ static void dump(const ef_config* c) {                 /* cmdline_parser_file_sa
   fclose(f);
 }
 
+extern unsigned long long ef_work_budget_override;     /* ef_fact.c */
+
 int ef_config_load(ef_config* c, int argc, char** argv) {
   ef_config_defaults(c);
+  { const char* e = getenv("PINTRON_WORK_BUDGET"); ef_work_budget_override = e && atoll(e) > 0 ? (unsigned long long)atoll(e) : 0ull; }
   bool given[32] = { false };
   for (int i = 1; i < argc; ++i) {
     const char* a = argv[i];

@@ -191,6 +191,7 @@ typedef struct service {
   bool stop;
   struct shared* sh;
   int n_threads;                         /* PINTRON_SERVICES: batches of different submitters overlap on the GPU */
+  long coalesce_us;                      /* PINTRON_COALESCE_US: wait that long for more requests before merging */
   service_thread threads[MAX_SERVICES];
 } service;
 
@@ -475,6 +476,14 @@ static void* service_main(void* arg) {
     const double t_idle = now_s();
     while (!sv->head && !sv->stop) pthread_cond_wait(&sv->posted, &sv->mu);
     me->phase_s[0] += now_s() - t_idle;
+    if (sv->coalesce_us > 0 && sv->head && !sv->stop) {
+      /* a short wait lets the lanes that are about to post join this batch: fewer, larger batches
+       * (every launch of a batch is latency-bound, so its cost hardly grows with the job count) */
+      pthread_mutex_unlock(&sv->mu);
+      struct timespec ts = { 0, sv->coalesce_us * 1000L };
+      nanosleep(&ts, NULL);
+      pthread_mutex_lock(&sv->mu);
+    }
     dp_request* list = sv->head;
     sv->head = sv->tail = NULL;
     const bool stop = sv->stop;
@@ -906,6 +915,7 @@ ef_session* ef_session_open(int argc, char** argv) {
     }
   }
   sh->svc.n_threads = (int)env_size("PINTRON_SERVICES", 3);
+  sh->svc.coalesce_us = getenv("PINTRON_COALESCE_US") ? atol(getenv("PINTRON_COALESCE_US")) : 0;
   if (sh->svc.n_threads > MAX_SERVICES) sh->svc.n_threads = MAX_SERVICES;
   for (int k = 0; k < sh->svc.n_threads; ++k) {
     if (pgpu_init(ef_gpu_device_from_env(), &sh->svc.threads[k].ctx) != PGPU_OK) { ef_session_close(s); return NULL; }
@@ -1055,14 +1065,18 @@ int ef_session_step(ef_session* s, ef_sched_stats* stats_out) {
       ef_kernel_stat ks; memset(&ks, 0, sizeof ks);
       snprintf(ks.name, sizeof ks.name, "%s", nm[k]);
       ks.ms = s->pre_kernel_ms[k]; ks.launches = (size_t)sh->n_pre; ks.jobs = s->in.n;
-      /* algorithmic bytes: two 4-byte suffix-array probes per bisection
-       * step and position for the descent; 12 bytes per pairing written */
+      /* algorithmic bytes of the table-guided search (restated for the 8-mer
+       * table): per position its pattern byte, one 2 x 4 B probe of the 4^8-entry table, two
+       * bisections over the run of that 8-mer (|T| / 4^8 suffixes on average: ceil(log2(run + 1))
+       * steps of one 4 B suffix-array probe each) and 3 x 4 B written (interval, longest match); plus
+       * one 4 B suffix-array read per occurrence reported.  12 bytes per pairing written by emit. */
       if (k == 0 || k == 5) {
         unsigned long long positions = 0, pairs = 0;
         for (int c = 0; c < sh->n_pre; ++c) { positions += pgpu_pairing_plan_positions(s->pplan[c]); pairs += pgpu_pairing_plan_count(s->pplan[c]); }
+        unsigned long long run = sh->gen_len / 65536ull + 1;
         unsigned lg = 0;
-        while ((1ull << lg) < sh->gen_len) ++lg;
-        ks.algo_bytes = k == 0 ? positions * lg * 8ull : pairs * 12ull;
+        while ((1ull << lg) < run + 1) ++lg;
+        ks.algo_bytes = k == 0 ? positions * (1ull + 8ull + 2ull * 4ull * lg + 12ull) + pairs * 4ull : pairs * 12ull;
       }
       if (ks.ms > 0) kstat_add(&st, &ks);
     }

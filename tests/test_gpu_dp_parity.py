@@ -86,16 +86,39 @@ def test_large_rows(gpu_ctx, O):
     cases.append(D.Case(D.BORDERS, a[:1100], b, p0=0, p1=1100, p2=60))
     cases.append(D.Case(D.GAP, a[:1500], b + D.rand_seq(rng, 300)))
     run_and_check(gpu_ctx, O, cases)
-    # over the limit: per-job ERANGE, the rest of the batch still runs
+    # beyond every limit (GAP: 16 000 per side): per-job ERANGE, the rest of the batch still runs
     jl = capi.JobList()
-    big = D.rand_seq(rng, 4097)
-    jl.add(capi.BORDERS, big, big[:-1] + b"A", p0=0, p1=4097, p2=3)
+    big = D.rand_seq(rng, 16001)
+    jl.add(capi.GAP, big[:100], big)
     jl.add(capi.ED, b"ACGT", b"ACGA")
-    jl.add(capi.GAP, big[:2049], big)
+    jl.add(capi.GAP, big, big[:100])
     out = capi.run_jobs(gpu_ctx, jl)
     assert out[0]["status"] == capi.PGPU_ERANGE
     assert out[1] == dict(status=0, score=1)
     assert out[2]["status"] == capi.PGPU_ERANGE
+
+
+def test_slow_kernels_beyond_the_fast_row_limits(gpu_ctx, O):
+    """GAP windows of more than 2048 EST characters and BORDERS patterns of more than 4096 used to be
+    refused (PGPU_ERANGE, est-fact stopped); the reference computes them, so an anti-diagonal kernel
+    over HBM now answers them -- slowly, bit-exactly.  Sizes just past the limits and well beyond,
+    ragged shapes, empty and one-character operands through the same launch group."""
+    rng = random.Random(44)
+    cases = []
+    for n, m in ((2049, 2300), (2500, 300), (3000, 3200), (4000, 9000)):
+        a, b = D.pair(rng, max(n, m), 0.04, 0.002)
+        a = a[:n]
+        cut = n // 2
+        g = b[:cut] + b"GT" + D.rand_seq(rng, max(0, m - n)) + b"AG" + b[cut:n]
+        cases.append(D.Case(D.GAP, a, g[:m] if len(g) > m else g))
+    for n, extra, errs in ((4097, 50, 40), (5000, 900, 120), (9000, 3000, 200)):
+        a, b = D.pair(rng, n, 0.02, 0.001)
+        a = a[:n]
+        cut = rng.randint(0, n)
+        t = D.mutate(rng, a[:cut], 0.02) + b"GT" + D.rand_seq(rng, extra) + b"AG" + D.mutate(rng, a[cut:], 0.02)
+        cases.append(D.Case(D.BORDERS, a, t, p0=0, p1=n, p2=errs))
+        cases.append(D.Case(D.BORDERS, a, t, p0=n // 3, p1=2 * n // 3, p2=errs, b_tail=b"GT"))
+    run_and_check(gpu_ctx, O, cases)
 
 
 def test_strips_beyond_4096_rows(gpu_ctx, O):

@@ -28,7 +28,7 @@ flags = ["gcc", "-std=gnu99", "-O1", "-g", "-fsanitize=address,undefined", "-fno
 seq = os.path.join(OUT, "estfact_check_asan")
 sched = os.path.join(OUT, "estfact_sched_asan")
 subprocess.run(flags + ["-o", seq, os.path.join(T, "estfact_check_main.c")] + host + orc + ["-lm"], check=True, cwd=T)
-subprocess.run(flags + ["-o", sched, os.path.join(H, "est_fact_main.c"), os.path.join(H, "ef_gpu_backend.c"),
+subprocess.run(flags + ["-o", sched, os.path.join(H, "est_fact_main.c"), os.path.join(H, "ef_multi.c"), os.path.join(H, "ef_gpu_backend.c"),
                         os.path.join(H, "ef_sched.c")] + host + [os.path.join(T, "fake_pgpu.c")] + orc + ["-lm"],
                check=True, cwd=T)
 

@@ -25,12 +25,12 @@ host = [os.path.join(H, f) for f in ("ef_io.c", "ef_meg.c", "ef_config.c", "ef_f
 orc = [os.path.join(O, f) for f in ("pairing_oracle.c", "dp_oracle.c", "dp_oracle_batch.c")]
 exe = os.path.join(OUT, "estfact_sched_tsan")
 subprocess.run(["gcc", "-std=gnu99", "-O1", "-g", "-fsanitize=thread", "-fno-omit-frame-pointer", "-pthread", "-o", exe,
-                os.path.join(H, "est_fact_main.c"), os.path.join(H, "ef_gpu_backend.c"), os.path.join(H, "ef_sched.c")]
+                os.path.join(H, "est_fact_main.c"), os.path.join(H, "ef_multi.c"), os.path.join(H, "ef_gpu_backend.c"), os.path.join(H, "ef_sched.c")]
                + host + [os.path.join(T, "fake_pgpu.c")] + orc + ["-lm"], check=True, cwd=T)
 subprocess.run(["make", "-s", "-C", T, "estfact_sched_check"], check=True)
 plain = os.path.join(T, "estfact_sched_check")
 
-cases = {"edge": synth.make_edge_cases()}
+cases = {"edge": synth.make_edge_cases(), "long": synth.make_long_transcripts(), "copies": synth.make_region_start_copies()}
 for cfg, n in (("C2", 200), ("C3", 300)):
     w = synth.make(cfg, n_est=n)
     cases[cfg.lower()] = (w.genomic_fasta(), w.ests_fasta())
