@@ -140,7 +140,7 @@ static void dump(const ef_config* c) {                 /* cmdline_parser_file_sa
   fclose(f);
 }
 
-extern unsigned long long ef_work_budget_override;     /* ef_fact.c */
+unsigned long long ef_work_budget_override;     /* PINTRON_WORK_BUDGET, read once here (single-threaded); used by ef_fact.c */
 
 int ef_config_load(ef_config* c, int argc, char** argv) {
   ef_config_defaults(c);

@@ -195,7 +195,7 @@ static int maximality_relation(ef_list* add, ef_list* cmp) {
 typedef struct { unsigned long long used, limit; } ef_work;
 static unsigned long long work_high_water;
 unsigned long long ef_work_high_water(void) { return __atomic_load_n(&work_high_water, __ATOMIC_RELAXED); }
-unsigned long long ef_work_budget_override;      /* PINTRON_WORK_BUDGET, read once by ef_config_load */
+extern unsigned long long ef_work_budget_override;      /* PINTRON_WORK_BUDGET, read once by ef_config_load (ef_config.c) */
 static unsigned long long work_limit(const ef_config* cfg) {
   if (ef_work_budget_override) return ef_work_budget_override;
   return cfg->max_single_factorization_time ? (unsigned long long)cfg->max_single_factorization_time * EF_WORK_PER_SECOND : ~0ull;
