@@ -38,6 +38,7 @@ struct pgpu_ctx {
   hipEvent_t ev_aux[NAUX] = {nullptr};
   bool fanout = true;        // spread groups over the auxiliary streams (PGPU_FANOUT=0 disables)
   int n_aux = NAUX;          // how many of them are used (PGPU_STREAMS=1..8)
+  bool merged = true;        // every wave-per-job family of a batch in ONE launch (PGPU_MERGED=0: a launch per family)
   bool packed = true;        // four streams, kernel families packed by expected duration (PGPU_PACK=0: round-robin over n_aux)
   // waiting: the calling thread must not burn a host core that other EST fibres could use (the
   // default HIP wait spins).  It naps and polls the event: measured on C3, naps of 50-200 us beat
@@ -174,6 +175,7 @@ extern "C" int pgpu_init(int device, pgpu_ctx** out) {
   { const char* f = getenv("PGPU_FANOUT"); ctx->fanout = !(f && f[0] == '0'); }
   { const char* f = getenv("PGPU_WAIT"); if (f) ctx->wait_poll_us = atol(f); }
   { const char* f = getenv("PGPU_PACK"); if (f && atoi(f) == 0) ctx->packed = false; }
+  { const char* f = getenv("PGPU_MERGED"); if (f && atoi(f) == 0) ctx->merged = false; }
   { const char* f = getenv("PGPU_STREAMS"); const int v = f ? atoi(f) : 0; if (v >= 1 && v <= pgpu_ctx::NAUX) { ctx->n_aux = v; ctx->packed = false; } }
   *out = ctx;
   return PGPU_OK;
@@ -211,7 +213,9 @@ struct Group {
   uint32_t n_big = 0;          // leading jobs of the large row classes (ED, ALIGN, KBAND: above 16 rows per lane; GAP: above 4)
   uint32_t max_rows = 0;       // largest a_len of the group (LDS of the one-job-per-workgroup BORDERS kernel)
   bool traceback = false;      // this group is the traceback pass of (family)
+  bool in_merged = false;      // its common row classes run inside the plan's merged launch; what is left here is the BIG part
   uint64_t cells = 0, algo_bytes = 0;
+  uint64_t cells_big = 0, algo_big = 0;     // share of the first n_big jobs
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   float ms = 0.f;
   std::string name;
@@ -249,6 +253,9 @@ struct pgpu_dp_plan {
   uint8_t* d_base = nullptr;
   uint8_t* h_up = nullptr; uint8_t* h_down = nullptr;
   size_t up_bytes = 0, off_results = 0, down_bytes = 0;
+  // merged launch (wave_jobs_kernel): segments = the common row classes of the wave-per-job families
+  int n_segs = 0, seg_family[6] = {0}, seg_start[6] = {0}, seg_count[6] = {0};
+  int merged_group = -1;       // index of the pseudo group that carries its timing and accounting
 };
 
 static void plan_free(pgpu_dp_plan* p) {
@@ -427,16 +434,17 @@ extern "C" int pgpu_dp_plan_create_parts(pgpu_ctx* ctx, const pgpu_index* idx, c
            (g.family != KF_LCF || j - i < 65535)) {
       const Keyed& k = v[j];
       const uint64_t la = k.j.la, lb = k.j.lb;
-      g.cells += (k.family == KF_GAP ? 3 : (k.family == KF_BORDERS ? 2 : 1)) * cells_of(k);
+      const uint64_t job_cells = (k.family == KF_GAP ? 3 : (k.family == KF_BORDERS ? 2 : 1)) * cells_of(k);
       // algorithmic HBM bytes: operands once; 1 B/cell of directions for
       // ALIGN, 3 B/cell for GAP; 8 B per row when row minima are produced
       // (BORDERS touches the first and the last t_win characters of t only)
-      g.algo_bytes += la + (k.family == KF_BORDERS ? std::min<uint64_t>(lb, 2 * std::min<uint64_t>(la + k.j.p2, lb)) : lb);
+      uint64_t job_bytes = la + (k.family == KF_BORDERS ? std::min<uint64_t>(lb, 2 * std::min<uint64_t>(la + k.j.p2, lb)) : lb);
+      if (k.family == KF_ALIGN) job_bytes += la * lb + 3 * (la + lb);     // + directions read back, two strings
+      if (k.family == KF_GAP) job_bytes += 3 * la * lb + 3 * (la + lb);
+      if (k.family == KF_BORDERS) job_bytes += 2 * 8 * la;
+      g.cells += job_cells; g.algo_bytes += job_bytes;
       g.max_rows = std::max(g.max_rows, (uint32_t)la);
-      if (k.R >= (k.family == KF_GAP ? 8u : 32u)) ++g.n_big;       // (the slow GAP / BORDERS groups ignore it)
-      if (k.family == KF_ALIGN) g.algo_bytes += la * lb + 3 * (la + lb);     // + directions read back, two strings
-      if (k.family == KF_GAP) g.algo_bytes += 3 * la * lb + 3 * (la + lb);
-      if (k.family == KF_BORDERS) g.algo_bytes += 2 * 8 * la;
+      if (k.R >= (k.family == KF_GAP ? 8u : 32u)) { ++g.n_big; g.cells_big += job_cells; g.algo_big += job_bytes; }   // (the slow GAP / BORDERS groups ignore it)
       if (k.family == KF_LCF) {
         const uint32_t ch = (uint32_t)((la + lb + 254) / 256);   // ceil((la+lb-1)/256) diagonals
         g.max_chunks = std::max(g.max_chunks, ch);
@@ -461,6 +469,27 @@ extern "C" int pgpu_dp_plan_create_parts(pgpu_ctx* ctx, const pgpu_index* idx, c
   for (auto& g : p->groups) {
     p->cells[g.kind] += g.cells;
     p->algo_bytes[g.kind] += g.algo_bytes;
+  }
+  if (ctx->merged) {
+    // the common row classes of the wave-per-job families run in one launch (wave_jobs_kernel); the
+    // groups keep their BIG part (first n_big jobs).  Long-running families first.
+    static const int order_fam[6] = { KF_ALIGN, KF_GAP, KF_KBAND, KF_BORDERS, KF_AFFIX, KF_ED };
+    Group m{};
+    m.family = KF_COUNT; m.kind = PGPU_DP_ALIGN; m.name = "wave_jobs";
+    for (int f : order_fam)
+      for (auto& g : p->groups) {
+        if (g.family != f || g.traceback) continue;
+        const bool wave_family = (f == KF_BORDERS || f == KF_AFFIX) ? g.R == 1 : g.R == 0;
+        if (!wave_family || p->n_segs >= 6) continue;
+        const size_t big = (f == KF_BORDERS || f == KF_AFFIX) ? 0 : g.n_big;
+        if (g.count <= big) continue;
+        p->seg_family[p->n_segs] = f; p->seg_start[p->n_segs] = (int)(g.first + big); p->seg_count[p->n_segs] = (int)(g.count - big);
+        ++p->n_segs;
+        m.count += g.count - big; m.cells += g.cells - (big ? g.cells_big : 0); m.algo_bytes += g.algo_bytes - (big ? g.algo_big : 0);
+        g.in_merged = true;
+        g.count = big; g.cells = big ? g.cells_big : 0; g.algo_bytes = big ? g.algo_big : 0;
+      }
+    if (p->n_segs) { p->merged_group = (int)p->groups.size(); p->groups.push_back(m); }
   }
   if (ctx->timing) {
     const size_t need = 2 * p->groups.size();
@@ -553,12 +582,14 @@ extern "C" int pgpu_dp_plan_launch(pgpu_ctx* ctx, pgpu_dp_plan* p) {
     for (size_t gi = 0; gi < p->groups.size(); ++gi) {
       const Group& g = p->groups[gi];
       if (g.traceback) continue;
-      order.push_back(gi);
       if (g.family == KF_LCF) { key_of[gi] = kb; kb += g.count; }
+      if (g.in_merged && g.count == 0) continue;           // nothing left outside the merged launch
+      order.push_back(gi);
     }
     auto weight = [&](size_t gi) -> long {
       const Group& g = p->groups[gi];
       switch (g.family) {
+        case KF_COUNT: return 9000;                        // the merged launch: behind the one-job-per-workgroup poles
         case KF_BORDERS: case KF_AFFIX: return g.R == 1 ? 150 : 10000 + (long)g.max_rows;
         case KF_ALIGN: return 5000;
         case KF_GAP: return 4000;
@@ -588,7 +619,7 @@ extern "C" int pgpu_dp_plan_launch(pgpu_ctx* ctx, pgpu_dp_plan* p) {
           case KF_AFFIX:   lane_of = one_wave ? 1 : 0; break;
           case KF_BORDERS: lane_of = one_wave ? 0 : 1; break;
           case KF_ED:      lane_of = 1; break;
-          case KF_ALIGN: case KF_KBAND: lane_of = 2; break;
+          case KF_ALIGN: case KF_KBAND: case KF_COUNT: lane_of = 2; break;
           default: lane_of = 3; break;           // GAP, LCF
         }
         used_mask |= 1u << lane_of;
@@ -596,6 +627,8 @@ extern "C" int pgpu_dp_plan_launch(pgpu_ctx* ctx, pgpu_dp_plan* p) {
       hipStream_t st = ctx->fanout ? ctx->aux[lane_of] : ctx->stream;
       if (g.ev0) HIP_TRY(ctx, hipEventRecord(g.ev0, st));
       switch (g.family) {
+        case KF_COUNT:
+          launch_wave_jobs(p->d_jobs, p->n_segs, p->seg_family, p->seg_start, p->seg_count, p->d_results, p->d_ws, p->d_strs, st); break;
         case KF_ALIGN: case KF_ED: case KF_BORDERS: case KF_AFFIX: case KF_KBAND:
           launch_lev(g.family, g.R, g.max_rows, jobs, n, (int)g.n_big, p->d_results, p->d_ws, p->d_strs, st); break;
         case KF_GAP:

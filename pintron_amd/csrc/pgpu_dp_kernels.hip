@@ -339,7 +339,7 @@ __device__ __noinline__ void kband_band_sweep(const uint8_t* __restrict__ lng, c
 
 template <int R, int MODE, bool STRIPS = false>
 __device__ __forceinline__ void lev_wave_body(const DevJob& job, DevResult* res, uint8_t* __restrict__ ws,
-                                              const uint32_t lane) {
+                                              const uint32_t lane, uint32_t* wave_lds = nullptr) {
   uint32_t cur[R], minv[R], minpos[R];
   AffixBest best{0, 0, 0, 0, 0};
 
@@ -404,7 +404,10 @@ __device__ __forceinline__ void lev_wave_body(const DevJob& job, DevResult* res,
     store_row_value<R>(cur, lane, n, &res->v[0]);
     if (lane == 0) { res->status = 0; res->v[5] = 0; }
   } else if constexpr (MODE == MODE_BORDERS) {
-    extern __shared__ uint32_t lds[];    // pre[], pre_pos[], suf[], suf_pos[], each len_p+1
+    // pre[], pre_pos[], suf[], suf_pos[], each len_p+1: the wave's own LDS region when the caller
+    // hands one in (several jobs per workgroup), else the workgroup's dynamic LDS
+    extern __shared__ uint32_t lds_dyn[];
+    uint32_t* lds = wave_lds ? wave_lds : lds_dyn;
     const uint32_t len_p = job.la, len_t = job.lb, max_errs = job.p2;
     const uint32_t t_win = min(len_p + max_errs, len_t);
     uint32_t* pre = lds; uint32_t* pre_pos = pre + (len_p + 1);
@@ -428,7 +431,11 @@ __device__ __forceinline__ void lev_wave_body(const DevJob& job, DevResult* res,
       }
     }
     if (lane == 0) { pre[0] = 0; pre_pos[0] = 0; suf[0] = 0; suf_pos[0] = 0; }
-    __syncthreads();
+    // one wave produced the four arrays and one wave reads them: a wave-level hand-over (a workgroup
+    // barrier would couple this wave to the unrelated jobs of its neighbours)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // cut scan of src/refine.c:161-178: the first i in [lo, hi] with the smallest total, ties by the
     // larger Burset frequency.  The lanes take i = lo + lane, lo + lane + 64, ... (each reads its four
     // genomic characters at once instead of lane 0 walking <= len_p+1 dependent loads) and then agree.
@@ -1120,6 +1127,57 @@ __device__ __forceinline__ void gap_traceback_wave(const DevJob& job, DevResult*
 }
 
 // ---------------------------------------------------------------------------------------------
+// ONE launch for every wave-per-job family of a batch.  A merged batch used to cost eleven launches
+// dealt onto four hardware queues, and the kernels of a queue run one after the other: the batch
+// took the SUM of its families' long poles per queue.  Here every wave of the grid looks its job up
+// in a short segment table (family, first job, count; long-running families first) and runs that
+// family's body: alignments with their tracebacks, gap alignments with theirs, banded and plain edit
+// distances and the single-wave BORDERS / AFFIX jobs overlap inside one dispatch, and the batch costs
+// its longest job.  The rare large row classes (BIG instances, a few hundred registers per lane) and
+// the one-job-per-workgroup kernels keep launches of their own.
+// ---------------------------------------------------------------------------------------------
+struct WaveSegs { int n; int start[6]; int count[6]; int family[6]; };
+
+__global__ __launch_bounds__(256)
+void wave_jobs_kernel(const DevJob* __restrict__ jobs, const WaveSegs segs, DevResult* __restrict__ results,
+                      uint8_t* __restrict__ ws, uint8_t* __restrict__ strs) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_win[4][TB_WIN_BYTES];
+  __shared__ uint8_t s_path[4][TB_PATH];
+  __shared__ uint32_t s_borders[4][4 * 65];
+  const uint32_t lane = threadIdx.x & 63u;
+  const int wave = (int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  int w = blockIdx.x * 4 + wave, fam = -1, idx = 0;
+  for (int sgi = 0; sgi < segs.n; ++sgi) {
+    if (w < segs.count[sgi]) { fam = segs.family[sgi]; idx = segs.start[sgi] + w; break; }
+    w -= segs.count[sgi];
+  }
+  if (fam < 0) return;
+  const DevJob job = jobs[idx];
+  DevResult* res = &results[job.out_idx];
+  switch (fam) {
+    case KF_ALIGN:
+      lev_any_dispatch<MODE_ALIGN, false>(job, res, ws, lane);
+      own_stores_visible();
+      align_traceback_wave(job, res, ws, strs, lane, s_win[wave], s_path[wave]);
+      break;
+    case KF_GAP:
+      switch (job.r_class) {
+        case 1:  gap_wave_body<1>(job, res, ws, lane); break;
+        case 2:  gap_wave_body<2>(job, res, ws, lane); break;
+        default: gap_wave_body<4>(job, res, ws, lane); break;
+      }
+      own_stores_visible();
+      gap_traceback_wave(job, res, ws, strs, lane, s_win[wave], s_path[wave]);
+      break;
+    case KF_KBAND:   lev_any_dispatch<MODE_KBAND, false>(job, res, ws, lane); break;
+    case KF_ED:      lev_any_dispatch<MODE_ED, false>(job, res, ws, lane); break;
+    case KF_BORDERS: lev_wave_body<1, MODE_BORDERS>(job, res, ws, lane, s_borders[wave]); break;
+    case KF_AFFIX:   lev_wave_body<1, MODE_AFFIX>(job, res, ws, lane); break;
+    default: break;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Longest common factor with N wildcard: find_longest_common_factor_dp
 // (src/factorization-refinement.c:255-316).  curr[i2+1] = match ? prev[i2]+1 : 0 only couples
 // cells of one diagonal, so the l1+l2-1 diagonals are independent: one thread per diagonal,
@@ -1394,6 +1452,21 @@ void launch_lev(int family, int R, uint32_t max_rows, const DevJob* jobs, int nj
       break;
     default: break;
   }
+}
+
+// segments: (family, first job, count) of the jobs the merged kernel runs, long poles first
+void launch_wave_jobs(const DevJob* jobs, int n_segs, const int* family, const int* start, const int* count,
+                      DevResult* res, uint8_t* ws, uint8_t* strs, hipStream_t st) {
+  WaveSegs sg;
+  sg.n = 0;
+  int total = 0;
+  for (int k = 0; k < n_segs && sg.n < 6; ++k) {
+    if (count[k] <= 0) continue;
+    sg.family[sg.n] = family[k]; sg.start[sg.n] = start[k]; sg.count[sg.n] = count[k]; ++sg.n;
+    total += count[k];
+  }
+  if (total == 0) return;
+  hipLaunchKernelGGL(wave_jobs_kernel, dim3((total + 3) / 4), dim3(256), 0, st, jobs, sg, res, ws, strs);
 }
 
 void launch_gap_slow(const DevJob* jobs, int njobs, DevResult* res, uint8_t* ws, uint8_t* strs, hipStream_t st) {

@@ -31,6 +31,8 @@ void launch_lev(int mode_family, int R, uint32_t max_rows, const DevJob* jobs, i
                 uint8_t* ws, uint8_t* strs, hipStream_t st);     // ALIGN: matrix + traceback
 void launch_gap(const DevJob* jobs, int njobs, int n_big, DevResult* res, uint8_t* ws, uint8_t* strs, hipStream_t st);   // + traceback
 void launch_gap_slow(const DevJob* jobs, int njobs, DevResult* res, uint8_t* ws, uint8_t* strs, hipStream_t st);   // beyond 2048 rows
+void launch_wave_jobs(const DevJob* jobs, int n_segs, const int* family, const int* start, const int* count,
+                      DevResult* res, uint8_t* ws, uint8_t* strs, hipStream_t st);   // every wave-per-job family in one launch
 void launch_lcf(const DevJob* jobs, int njobs, uint32_t max_chunks, uint32_t max_l2,
                 unsigned long long* keys, hipStream_t st);
 void launch_lcf_finish(const DevJob* jobs, int njobs, DevResult* res,

@@ -524,7 +524,7 @@ static void* service_main(void* arg) {
       const int ng = pgpu_dp_plan_n_groups(plan);
       for (int g = 0; g < ng; ++g) {
         pgpu_group_info gi;
-        if (pgpu_dp_plan_group_info(plan, g, &gi) != PGPU_OK) continue;
+        if (pgpu_dp_plan_group_info(plan, g, &gi) != PGPU_OK || gi.jobs == 0) continue;   /* nothing launched for it */
         ef_kernel_stat ks; memset(&ks, 0, sizeof ks);
         snprintf(ks.name, sizeof ks.name, "%s", gi.name);
         ks.ms = gi.ms; ks.launches = 1; ks.jobs = gi.jobs; ks.cells = gi.cells; ks.algo_bytes = gi.algo_bytes;
