@@ -213,6 +213,7 @@ struct Group {
   uint32_t n_big = 0;          // leading jobs of the large row classes (ED, ALIGN, KBAND: above 16 rows per lane; GAP: above 4)
   uint32_t max_rows = 0;       // largest a_len of the group (LDS of the one-job-per-workgroup BORDERS kernel)
   bool traceback = false;      // this group is the traceback pass of (family)
+  bool launched = false;       // its events were recorded by the last launch
   bool in_merged = false;      // its common row classes run inside the plan's merged launch; what is left here is the BIG part
   uint64_t cells = 0, algo_bytes = 0;
   uint64_t cells_big = 0, algo_big = 0;     // share of the first n_big jobs
@@ -626,6 +627,7 @@ extern "C" int pgpu_dp_plan_launch(pgpu_ctx* ctx, pgpu_dp_plan* p) {
       }
       hipStream_t st = ctx->fanout ? ctx->aux[lane_of] : ctx->stream;
       if (g.ev0) HIP_TRY(ctx, hipEventRecord(g.ev0, st));
+      g.launched = true;
       switch (g.family) {
         case KF_COUNT:
           launch_wave_jobs(p->d_jobs, p->n_segs, p->seg_family, p->seg_start, p->seg_count, p->d_results, p->d_ws, p->d_strs, st); break;
@@ -669,6 +671,7 @@ extern "C" int pgpu_dp_plan_sync(pgpu_ctx* ctx, pgpu_dp_plan* p) {
     for (int k = 0; k < PGPU_DP_NKINDS; ++k) { p->ms[k] = 0; p->launches[k] = 0; }
     for (auto& g : p->groups) {
       float ms = 0.f;
+      if (!g.launched) continue;            // everything of this group ran inside the merged launch
       if (g.ev0 && g.ev1 && hipEventElapsedTime(&ms, g.ev0, g.ev1) == hipSuccess) g.ms = ms;
       p->ms[g.kind] += g.ms;
       p->launches[g.kind] += 1;
