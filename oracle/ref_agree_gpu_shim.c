@@ -21,6 +21,9 @@
 #include "util.h"
 
 #include "../include/pintron_gpu.h"
+#ifdef AGREE_SELF_CHECK      /* debugging build: every device answer is compared with the CPU oracle */
+#include "dp_oracle.h"
+#endif
 
 static pgpu_ctx* ctx;
 static unsigned long n_calls[3];          /* ALIGN, ED, GAP answered by the device */
@@ -57,6 +60,27 @@ static pgpu_dp_result run_one(uint32_t kind, const char* a, size_t la, const cha
     exit(1);
   }
   free(arena);
+#ifdef AGREE_SELF_CHECK
+  {
+    char* o = (char*)calloc(2 * (la + lb + 2), 1);
+    int bad = 0;
+    if (kind == PGPU_DP_ALIGN) {
+      int32_t dim; const int32_t sc = (int32_t)orc_align(a, la, b, lb, o, o + la + lb + 2, &dim);
+      bad = sc != res.v[0] || dim != res.v[1] || memcmp(o, str + res.str[0], (size_t)dim) || memcmp(o + la + lb + 2, str + res.str[1], (size_t)dim);
+      if (bad) fprintf(stderr, "SELF-CHECK ALIGN differs: score %d/%d dim %d/%d\n a=%.*s\n b=%.*s\n", sc, res.v[0], dim, res.v[1], (int)la, a, (int)lb, b);
+    } else if (kind == PGPU_DP_GAP) {
+      orc_gap_result g; orc_gap_align(a, la, b, lb, o, o + la + lb + 2, &g);
+      bad = g.dim != res.v[0] || g.factor_cut != res.v[1] || g.intron_start != res.v[2] || g.intron_end != res.v[3] ||
+            g.intron_start_on_align != res.v[4] || g.intron_end_on_align != res.v[5] || memcmp(o, str + res.str[0], (size_t)g.dim) || memcmp(o + la + lb + 2, str + res.str[1], (size_t)g.dim);
+      if (bad) fprintf(stderr, "SELF-CHECK GAP differs: dim %d/%d cut %d/%d is %d/%d ie %d/%d\n a=%.*s\n b=%.*s\n", g.dim, res.v[0], g.factor_cut, res.v[1], g.intron_start, res.v[2], g.intron_end, res.v[3], (int)la, a, (int)lb, b);
+    } else {
+      const int32_t d = (int32_t)orc_edit_distance(a, la, b, lb);
+      bad = d != res.v[0];
+      if (bad) fprintf(stderr, "SELF-CHECK ED differs: %d/%d\n a=%.*s\n b=%.*s\n", d, res.v[0], (int)la, a, (int)lb, b);
+    }
+    free(o);
+  }
+#endif
   if (strings) *strings = str;
   return res;
 }
@@ -67,6 +91,7 @@ plist __wrap_compute_alignment(char* EST_seq, char* genomic_seq, bool only_one_a
   char* str = NULL;
   const pgpu_dp_result r = run_one(PGPU_DP_ALIGN, EST_seq, n, genomic_seq, m, &str);
   ++n_calls[0];
+  if (getenv("PINTRON_AGREE_DEBUG")) fprintf(stderr, "DBG A %d %d %zu %zu\n", r.v[0], r.v[1], n, m);
   palignment al = alignment_create(n + m + 1);
   al->score = r.v[0];
   al->alignment_dim = r.v[1];
@@ -82,6 +107,7 @@ plist __wrap_compute_alignment(char* EST_seq, char* genomic_seq, bool only_one_a
 unsigned int* __wrap_edit_distance(char* s1, size_t l1, char* s2, size_t l2) {
   const pgpu_dp_result r = run_one(PGPU_DP_ED, s1, l1, s2, l2, NULL);
   ++n_calls[1];
+  if (getenv("PINTRON_AGREE_DEBUG")) fprintf(stderr, "DBG E %d %zu %zu\n", r.v[0], l1, l2);
   unsigned int* M = (unsigned int*)calloc((l1 + 1) * (l2 + 1), sizeof(unsigned int));
   M[(l1 + 1) * (l2 + 1) - 1] = (unsigned int)r.v[0];
   return M;
@@ -93,6 +119,7 @@ plist __wrap_compute_gap_alignment(char* EST_seq, char* genomic_seq, bool only_o
   char* str = NULL;
   const pgpu_dp_result r = run_one(PGPU_DP_GAP, EST_seq, n, genomic_seq, m, &str);
   ++n_calls[2];
+  if (getenv("PINTRON_AGREE_DEBUG")) fprintf(stderr, "DBG G %d %d %d %d %zu %zu\n", r.v[0], r.v[1], r.v[2], r.v[3], n, m);
   pgap_alignment g = gap_alignment_create(n + m + 10);
   g->gap_alignment_dim = r.v[0]; g->factor_cut = r.v[1]; g->intron_start = r.v[2]; g->intron_end = r.v[3];
   g->intron_start_on_align = r.v[4]; g->intron_end_on_align = r.v[5];

@@ -29,6 +29,12 @@ REFDIR = os.path.join(ROOT, "oracle", "_ref")
 MINFACT = os.path.join(REFDIR, "min-factorization-ref")
 AGREE = os.path.join(REFDIR, "intron-agreement-ref")
 FIELDS = ("donor_start", "donor_end", "acceptor_start", "acceptor_end")
+# The reference's intron-agreement reads heap memory it never wrote: with glibc's MALLOC_PERTURB_ at 85 or
+# 165 the unmodified program dies with SIGSEGV after its "intron-agreement-end" log line, at 0 and 255 it
+# does not.  What it reads therefore depends on what the process allocated before (a GPU runtime in the
+# same process is enough to change it).  MALLOC_PERTURB_=255 makes malloc hand out zero-filled blocks, the
+# state a fresh heap has, so every run of the stage -- reference or bound to the device -- sees the same bytes.
+STAGE_ENV = dict(os.environ, MALLOC_PERTURB_="255")
 
 
 def have_stages():
@@ -64,7 +70,7 @@ def run_stages(workdir):
     with open(os.path.join(workdir, "raw-multifasta-out.txt"), "rb") as fin, \
             open(os.path.join(workdir, "out-agree.txt"), "wb") as fout:
         subprocess.run([MINFACT], cwd=workdir, stdin=fin, stdout=fout, stderr=subprocess.DEVNULL, check=True)
-    subprocess.run([AGREE], cwd=workdir, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+    subprocess.run([AGREE], cwd=workdir, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True, env=STAGE_ENV)
 
 
 def introns_table(workdir):

@@ -3,7 +3,8 @@ stage 3 re-aligns the exon borders around every intron with compute_alignment, e
 compute_gap_alignment (src/agree-introns.c:629,695,762,837; src/main-intron-agreement.c:857,864).
 oracle/_ref/intron-agreement-gpu is the reference's own intron-agreement with those three entry points
 answered by libpintron_gpu.so (oracle/ref_agree_gpu_shim.c): its two output files
-must equal those of the unmodified intron-agreement, on est-fact output produced by the HIP path."""
+must equal those of the unmodified intron-agreement, on est-fact output produced by the HIP path.  Both
+programs run on zero-filled malloc blocks (regression_lib.STAGE_ENV says why)."""
 import os
 import shutil
 import subprocess
@@ -34,7 +35,7 @@ def test_intron_agreement_with_device_alignments(tmp_path, case):
         d = tmp_path / tag
         shutil.copytree(work, d)
         r = subprocess.run([exe], cwd=d, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, errors="replace",
-                           env=dict(os.environ, PINTRON_VERBOSE="1"))
+                           env=dict(RL.STAGE_ENV, PINTRON_VERBOSE="1"))
         assert r.returncode == 0, r.stderr[-1500:]
         outs[tag] = [(d / f).read_bytes() for f in ("predicted-introns.txt", "out-after-intron-agree.txt")]
         if tag == "gpu":
