@@ -29,12 +29,16 @@ REFDIR = os.path.join(ROOT, "oracle", "_ref")
 MINFACT = os.path.join(REFDIR, "min-factorization-ref")
 AGREE = os.path.join(REFDIR, "intron-agreement-ref")
 FIELDS = ("donor_start", "donor_end", "acceptor_start", "acceptor_end")
-# The reference's intron-agreement reads heap memory it never wrote: with glibc's MALLOC_PERTURB_ at 85 or
-# 165 the unmodified program dies with SIGSEGV after its "intron-agreement-end" log line, at 0 and 255 it
-# does not.  What it reads therefore depends on what the process allocated before (a GPU runtime in the
-# same process is enough to change it).  MALLOC_PERTURB_=255 makes malloc hand out zero-filled blocks, the
-# state a fresh heap has, so every run of the stage -- reference or bound to the device -- sees the same bytes.
-STAGE_ENV = dict(os.environ, MALLOC_PERTURB_="255")
+# The reference's intron-agreement reads heap memory it never wrote: read_multifasta's EST_info_create
+# (src/types.c:133) mallocs the genomic's record, nothing sets its pref_N_length, and
+# write_multifasta_output (src/io-multifasta.c:223-230) adds it to a pointer and prints it --
+# MemorySanitizer on the unmodified sources reports exactly that, and with glibc's MALLOC_PERTURB_ at 85
+# or 165 the unmodified program dies with SIGSEGV after its "intron-agreement-end" log line.  In a fresh
+# heap the block happens to be zero; once something else allocated and freed before main (a GPU runtime
+# linked into the process is enough) it is not.  perturb=255 makes malloc hand out zero-filled blocks and
+# tcache_count=0 closes the one path (the thread cache) on which glibc returns a recycled block unfilled,
+# so every run of the stage -- reference or bound to the device -- sees the state a fresh heap has.
+STAGE_ENV = dict(os.environ, MALLOC_PERTURB_="255", GLIBC_TUNABLES="glibc.malloc.tcache_count=0")
 
 
 def have_stages():
