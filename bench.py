@@ -83,7 +83,7 @@ def rocprof_symbol(group_name):
         return "lev_wave_kernel<1, %d, false>" % modes[m.group(1)]
     if group_name == "lev_wave<AFFIX,strips>":
         return "lev_wave_kernel<64, 3, true>"
-    return {"wave_jobs": "wave_jobs_kernel", "gap_wave": "gap_any_kernel<false>", "borders_coop": "borders_coop_any_kernel", "affix_coop": "affix_coop_any_kernel",
+    return {"dp_batch": "dp_batch_kernel", "wave_jobs": "wave_jobs_kernel", "gap_wave": "gap_any_kernel<false>", "borders_coop": "borders_coop_any_kernel", "affix_coop": "affix_coop_any_kernel",
             "lcf": "lcf_kernel", "align_traceback": "align_traceback_wave_kernel",
             "gap_traceback": "gap_traceback_wave_kernel"}.get(group_name, group_name.split("+")[0] + "_kernel")
 

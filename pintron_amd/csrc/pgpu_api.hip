@@ -38,14 +38,16 @@ struct pgpu_ctx {
   hipEvent_t ev_aux[NAUX] = {nullptr};
   bool fanout = true;        // spread groups over the auxiliary streams (PGPU_FANOUT=0 disables)
   int n_aux = NAUX;          // how many of them are used (PGPU_STREAMS=1..8)
-  bool merged = true;        // every wave-per-job family of a batch in ONE launch (PGPU_MERGED=0: a launch per family)
+  int merged = 2;            // 2: the latency-bound part of a batch (one-job-per-workgroup sweeps + every wave-per-job
+                             //    family) in ONE launch beside the LCF launch; 1: the wave-per-job families in one
+                             //    launch, the sweeps in theirs; 0: a launch per family (PGPU_MERGED)
   bool packed = true;        // four streams, kernel families packed by expected duration (PGPU_PACK=0: round-robin over n_aux)
   // waiting: the calling thread must not burn a host core that other EST fibres could use (the
   // default HIP wait spins).  It naps and polls the event: measured on C3, naps of 50-200 us beat
   // a blocking-sync event by 5-7 % whole-program (the interrupt path costs more host time than
   // the naps cost latency).  PGPU_WAIT=<us> sets the nap, 0 = blocking-sync event, -1 = spin.
   hipEvent_t ev_done = nullptr;
-  long wait_poll_us = 100;
+  long wait_poll_us = 20;
   // pinned staging for the device->host result copies (pageable copies block and spin inside HIP)
   void* pin[2] = {nullptr, nullptr};
   size_t pin_cap[2] = {0, 0};
@@ -175,7 +177,7 @@ extern "C" int pgpu_init(int device, pgpu_ctx** out) {
   { const char* f = getenv("PGPU_FANOUT"); ctx->fanout = !(f && f[0] == '0'); }
   { const char* f = getenv("PGPU_WAIT"); if (f) ctx->wait_poll_us = atol(f); }
   { const char* f = getenv("PGPU_PACK"); if (f && atoi(f) == 0) ctx->packed = false; }
-  { const char* f = getenv("PGPU_MERGED"); if (f && atoi(f) == 0) ctx->merged = false; }
+  { const char* f = getenv("PGPU_MERGED"); if (f && atoi(f) >= 0 && atoi(f) <= 2) ctx->merged = atoi(f); }
   { const char* f = getenv("PGPU_STREAMS"); const int v = f ? atoi(f) : 0; if (v >= 1 && v <= pgpu_ctx::NAUX) { ctx->n_aux = v; ctx->packed = false; } }
   *out = ctx;
   return PGPU_OK;
@@ -257,6 +259,15 @@ struct pgpu_dp_plan {
   // merged launch (wave_jobs_kernel): segments = the common row classes of the wave-per-job families
   int n_segs = 0, seg_family[6] = {0}, seg_start[6] = {0}, seg_count[6] = {0};
   int merged_group = -1;       // index of the pseudo group that carries its timing and accounting
+  // ... and, with the batch kernel, the one-job-per-workgroup BORDERS / AFFIX jobs
+  bool batch = false;
+  int bc_start = 0, bc_count = 0, ac_start = 0, ac_count = 0;
+  uint32_t bc_max_rows = 0;
+  // LCF: the kernel leaves one 64-bit key per job directly in front of the results; they come back in the
+  // same copy and sync turns them into results (lcf_out[k] = caller index of the job of key k)
+  std::vector<uint32_t> lcf_out;
+  size_t off_keys = 0;
+  bool lcf_decoded = false;
 };
 
 static void plan_free(pgpu_dp_plan* p) {
@@ -412,6 +423,7 @@ extern "C" int pgpu_dp_plan_create_parts(pgpu_ctx* ctx, const pgpu_index* idx, c
       k.j.str_off = strs; strs += 2 * ((size_t)la + lb + 1);
     } else if (k.family == KF_LCF) {
       ++nkeys;
+      p->lcf_out.push_back(k.j.out_idx);
     }
     ws = (ws + 15) & ~(size_t)15;
   }
@@ -490,7 +502,24 @@ extern "C" int pgpu_dp_plan_create_parts(pgpu_ctx* ctx, const pgpu_index* idx, c
         g.in_merged = true;
         g.count = big; g.cells = big ? g.cells_big : 0; g.algo_bytes = big ? g.algo_big : 0;
       }
-    if (p->n_segs) { p->merged_group = (int)p->groups.size(); p->groups.push_back(m); }
+    if (ctx->merged >= 2) {
+      // the one-job-per-workgroup sweeps join it (dp_batch_kernel) unless the largest BORDERS pattern
+      // needs more LDS than the roles may share
+      for (auto& g : p->groups) {
+        if (g.traceback || g.R != 0 || g.count == 0 || g.count > 0x3fffffffu) continue;
+        if (g.family == KF_BORDERS && dp_batch_lds_bytes(true, 1, g.max_rows, 1) <= 64 * 1024) {
+          p->bc_start = (int)g.first; p->bc_count = (int)g.count; p->bc_max_rows = g.max_rows;
+        } else if (g.family == KF_AFFIX) {
+          p->ac_start = (int)g.first; p->ac_count = (int)g.count;
+        } else continue;
+        m.count += g.count; m.cells += g.cells; m.algo_bytes += g.algo_bytes;
+        g.in_merged = true; g.count = 0; g.cells = 0; g.algo_bytes = 0;
+        p->batch = true;
+      }
+      if (p->n_segs) p->batch = true;
+      if (p->batch) m.name = "dp_batch";
+    }
+    if (p->n_segs || p->batch) { p->merged_group = (int)p->groups.size(); p->groups.push_back(m); }
   }
   if (ctx->timing) {
     const size_t need = 2 * p->groups.size();
@@ -521,7 +550,8 @@ extern "C" int pgpu_dp_plan_create_parts(pgpu_ctx* ctx, const pgpu_index* idx, c
   const size_t total = off_ws + ws + 16;
   p->up_bytes = off_strs;                      // arena .. results (prefilled)
   p->off_results = off_results;
-  p->down_bytes = (off_strs - off_results) + strs;
+  p->off_keys = off_keys;
+  p->down_bytes = (off_strs - off_keys) + strs;           // keys (+ padding), results, strings
   if (p->pooled) {
     p->d_base = (uint8_t*)pgpu_ctx_pool_get(ctx, 0, 0, total);
     p->h_up = (uint8_t*)pinned(ctx, 0, p->up_bytes);
@@ -567,11 +597,6 @@ extern "C" int pgpu_dp_plan_create_parts(pgpu_ctx* ctx, const pgpu_index* idx, c
 extern "C" int pgpu_dp_plan_launch(pgpu_ctx* ctx, pgpu_dp_plan* p) {
   if (!ctx || !p) return set_err(ctx, PGPU_EINVAL, "bad argument");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  // the upload (plan_create) is on the main stream; the groups fan out
-  if (ctx->fanout) {
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_upload, ctx->stream));
-    for (auto& a : ctx->aux) HIP_TRY(ctx, hipStreamWaitEvent(a, ctx->ev_upload, 0));
-  }
   // Launch order: the groups are independent, and the host needs a few microseconds per launch, so
   // the long poles go first (one-job-per-workgroup sweeps with many rows, then the alignments with
   // their tracebacks, ...) and the thousands of tiny edit distances last.  A traceback group
@@ -590,7 +615,7 @@ extern "C" int pgpu_dp_plan_launch(pgpu_ctx* ctx, pgpu_dp_plan* p) {
     auto weight = [&](size_t gi) -> long {
       const Group& g = p->groups[gi];
       switch (g.family) {
-        case KF_COUNT: return 9000;                        // the merged launch: behind the one-job-per-workgroup poles
+        case KF_COUNT: return p->batch ? 20000 : 9000;    // the merged launch: behind the one-job-per-workgroup poles it does not hold
         case KF_BORDERS: case KF_AFFIX: return g.R == 1 ? 150 : 10000 + (long)g.max_rows;
         case KF_ALIGN: return 5000;
         case KF_GAP: return 4000;
@@ -601,36 +626,54 @@ extern "C" int pgpu_dp_plan_launch(pgpu_ctx* ctx, pgpu_dp_plan* p) {
     };
     std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return weight(a) > weight(b); });
   }
-  int slot = 0;
+  // HIP spreads its streams over four hardware queues, and what shares a queue runs one after the
+  // other.  Packed: four streams (one per queue), the families dealt out so that the four sums of
+  // typical durations come out even; the batch launch stays on the main stream (lane -1), where the
+  // upload already is, and only the streams a plan uses are forked and joined.  Otherwise
+  // round-robin in launch order.
+  std::vector<int> lane_of(order.size(), 0);
   unsigned used_mask = 0;
+  for (size_t oi = 0; oi < order.size(); ++oi) {
+    const Group& g = p->groups[order[oi]];
+    int l = (int)(oi % (size_t)ctx->n_aux);
+    if (ctx->packed) {
+      const bool one_wave = g.R == 1;          // BORDERS / AFFIX with up to 64 rows
+      switch (g.family) {
+        case KF_AFFIX:   l = one_wave ? 1 : 0; break;
+        case KF_BORDERS: l = one_wave ? 0 : 1; break;
+        case KF_ED:      l = 1; break;
+        case KF_COUNT:   l = p->batch ? -1 : 2; break;
+        case KF_ALIGN: case KF_KBAND: l = 2; break;
+        default: l = 3; break;           // GAP, LCF
+      }
+    }
+    if (!ctx->fanout) l = -1;
+    lane_of[oi] = l;
+    if (l >= 0) used_mask |= 1u << l;
+  }
+  if (used_mask) {            // fork: the upload (plan_create) is on the main stream
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_upload, ctx->stream));
+    for (int i = 0; i < pgpu_ctx::NAUX; ++i)
+      if (used_mask & (1u << i)) HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux[i], ctx->ev_upload, 0));
+  }
   for (size_t oi = 0; oi < order.size(); ++oi) {
     for (size_t gi = order[oi]; gi < p->groups.size() && (gi == order[oi] || p->groups[gi].traceback); ++gi) {
       Group& g = p->groups[gi];
       const DevJob* jobs = p->d_jobs + g.first;
       const int n = (int)g.count;
-      // HIP spreads its streams over four hardware queues, and what shares a queue runs one after
-      // the other.  Packed: four streams (one per queue), the families dealt out so that the four
-      // sums of typical durations come out even (on C3, us per launch: affix_coop 190 + single-wave
-      // BORDERS 27 | borders_coop 175 + ED 22 + single-wave AFFIX 19 | ALIGN 157 + KBAND 55 | GAP 135 +
-      // LCF 98); otherwise round-robin in launch order.
-      int lane_of = slot % ctx->n_aux;
-      if (ctx->packed) {
-        const bool one_wave = g.R == 1;          // BORDERS / AFFIX with up to 64 rows
-        switch (g.family) {
-          case KF_AFFIX:   lane_of = one_wave ? 1 : 0; break;
-          case KF_BORDERS: lane_of = one_wave ? 0 : 1; break;
-          case KF_ED:      lane_of = 1; break;
-          case KF_ALIGN: case KF_KBAND: case KF_COUNT: lane_of = 2; break;
-          default: lane_of = 3; break;           // GAP, LCF
-        }
-        used_mask |= 1u << lane_of;
-      }
-      hipStream_t st = ctx->fanout ? ctx->aux[lane_of] : ctx->stream;
+      hipStream_t st = lane_of[oi] >= 0 ? ctx->aux[lane_of[oi]] : ctx->stream;
       if (g.ev0) HIP_TRY(ctx, hipEventRecord(g.ev0, st));
       g.launched = true;
       switch (g.family) {
         case KF_COUNT:
-          launch_wave_jobs(p->d_jobs, p->n_segs, p->seg_family, p->seg_start, p->seg_count, p->d_results, p->d_ws, p->d_strs, st); break;
+          if (p->batch) {
+            if (!launch_dp_batch(p->d_jobs, p->n_segs, p->seg_family, p->seg_start, p->seg_count, p->bc_start, p->bc_count,
+                                 p->bc_max_rows, p->ac_start, p->ac_count, p->d_results, p->d_ws, p->d_strs, st))
+              return set_err(ctx, PGPU_EDEVICE, "batch launch: LDS budget exceeded");
+          } else {
+            launch_wave_jobs(p->d_jobs, p->n_segs, p->seg_family, p->seg_start, p->seg_count, p->d_results, p->d_ws, p->d_strs, st);
+          }
+          break;
         case KF_ALIGN: case KF_ED: case KF_BORDERS: case KF_AFFIX: case KF_KBAND:
           launch_lev(g.family, g.R, g.max_rows, jobs, n, (int)g.n_big, p->d_results, p->d_ws, p->d_strs, st); break;
         case KF_GAP:
@@ -639,28 +682,39 @@ extern "C" int pgpu_dp_plan_launch(pgpu_ctx* ctx, pgpu_dp_plan* p) {
           break;
         case KF_LCF:
           launch_lcf(jobs, n, g.max_chunks, g.max_l2, p->d_keys + key_of[gi], st);
-          launch_lcf_finish(jobs, n, p->d_results, p->d_keys + key_of[gi], st);
           break;
         default: break;
       }
       if (g.ev1) HIP_TRY(ctx, hipEventRecord(g.ev1, st));
       HIP_TRY(ctx, hipGetLastError());
     }
-    ++slot;
   }
-  if (ctx->fanout) {            // join: the main stream continues after every auxiliary stream
-    const int used = ctx->packed ? 4 : (slot < ctx->n_aux ? slot : ctx->n_aux);
-    for (int i = 0; i < used; ++i) {
-      if (ctx->packed && !(used_mask & (1u << i))) continue;
-      HIP_TRY(ctx, hipEventRecord(ctx->ev_aux[i], ctx->aux[i]));
-      HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_aux[i], 0));
-    }
+  for (int i = 0; i < pgpu_ctx::NAUX; ++i) {      // join: the main stream continues after every stream that was used
+    if (!(used_mask & (1u << i))) continue;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_aux[i], ctx->aux[i]));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_aux[i], 0));
   }
   // results and alignment strings come back in one copy as soon as every group is done
   if (p->down_bytes)
-    HIP_TRY(ctx, hipMemcpyAsync(p->h_down, p->d_base + p->off_results, p->down_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(p->h_down, p->d_base + p->off_keys, p->down_bytes, hipMemcpyDeviceToHost, ctx->stream));
   p->launched = true;
   return PGPU_OK;
+}
+
+// find_longest_common_factor_dp's answer from the key the kernel left (lcf_key in pgpu_dp_kernels.hip)
+static void decode_lcf_keys(pgpu_dp_plan* p) {
+  if (p->lcf_decoded) return;
+  p->lcf_decoded = true;
+  const unsigned long long* keys = (const unsigned long long*)p->h_down;
+  DevResult* res = (DevResult*)(p->h_down + (p->off_results - p->off_keys));
+  for (size_t k = 0; k < p->lcf_out.size(); ++k) {
+    DevResult& r = res[p->lcf_out[k]];
+    const unsigned long long key = keys[k];
+    r.status = PGPU_OK;
+    r.v[0] = (int32_t)(key >> 44);
+    r.v[1] = key ? (int32_t)(0x0FFFFFFFu - (uint32_t)((key >> 16) & 0x0FFFFFFFu)) : 0;
+    r.v[2] = key ? (int32_t)(0xFFFFu - (uint32_t)(key & 0xFFFFu)) : 0;
+  }
 }
 
 extern "C" int pgpu_dp_plan_sync(pgpu_ctx* ctx, pgpu_dp_plan* p) {
@@ -668,6 +722,7 @@ extern "C" int pgpu_dp_plan_sync(pgpu_ctx* ctx, pgpu_dp_plan* p) {
   if (wait_stream(ctx, ctx->stream) != 0) return set_err(ctx, PGPU_EDEVICE, "waiting for the batch failed");
   p->synced = p->launched;
   if (p->launched) {
+    decode_lcf_keys(p);
     for (int k = 0; k < PGPU_DP_NKINDS; ++k) { p->ms[k] = 0; p->launches[k] = 0; }
     for (auto& g : p->groups) {
       float ms = 0.f;
@@ -690,8 +745,9 @@ extern "C" int pgpu_dp_plan_fetch(pgpu_ctx* ctx, pgpu_dp_plan* p, pgpu_dp_result
   // launch enqueued the download behind the kernels; after this wait the pinned image is complete
   if (!p->synced && wait_stream(ctx, ctx->stream) != 0) return set_err(ctx, PGPU_EDEVICE, "result download failed");
   p->synced = true;
+  decode_lcf_keys(p);
   const size_t rb = p->n_jobs * sizeof(DevResult);
-  if (rb) memcpy(results, p->h_down, rb);
+  if (rb) memcpy(results, p->h_down + (p->off_results - p->off_keys), rb);
   if (p->strs_bytes && strings) memcpy(strings, p->h_down + (p->down_bytes - p->strs_bytes), p->strs_bytes);
   return PGPU_OK;
 }
@@ -701,7 +757,12 @@ extern "C" int pgpu_dp_plan_results_to_device(pgpu_ctx* ctx, pgpu_dp_plan* p, vo
   const size_t bytes = p->n_jobs * sizeof(DevResult);
   if (cap < bytes) return set_err(ctx, PGPU_ENOSPC, "device buffer too small: need %zu", bytes);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  if (bytes) HIP_TRY(ctx, hipMemcpyAsync(dst, p->d_results, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  if (!p->launched) return set_err(ctx, PGPU_EINVAL, "the plan has not been launched");
+  // the complete results are in the pinned image (the LCF answers are decoded there)
+  if (!p->synced && wait_stream(ctx, ctx->stream) != 0) return set_err(ctx, PGPU_EDEVICE, "result download failed");
+  p->synced = true;
+  decode_lcf_keys(p);
+  if (bytes) HIP_TRY(ctx, hipMemcpyAsync(dst, p->h_down + (p->off_results - p->off_keys), bytes, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return PGPU_OK;
 }

@@ -30,6 +30,19 @@ __device__ __forceinline__ uint32_t wave_shr1(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xf, 0xf, false);
 }
 
+__device__ __forceinline__ uint32_t wave_shl1(uint32_t v) {
+  // DPP wave_shl:1 -- lane l receives lane l+1's v; lane 63 keeps its own (the caller masks it)
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x130, 0xf, 0xf, false);
+}
+// lane l receives lane l-1's v, lane 0 receives ITS OWN `first` (a lane without a source keeps the old value)
+__device__ __forceinline__ uint32_t wave_shr1_first(uint32_t first, uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)first, (int)v, 0x138, 0xf, 0xf, false);
+}
+// lane l receives lane l+1's v, lane 63 receives its own `last`
+__device__ __forceinline__ uint32_t wave_shl1_last(uint32_t last, uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)last, (int)v, 0x130, 0xf, 0xf, false);
+}
+
 __device__ __forceinline__ bool is_n(uint32_t c) { return c == 'n' || c == 'N'; }
 
 // getBursetFrequency (src/refine-intron.c:376-556) as a table: index = donor[0],donor[1],
@@ -103,20 +116,24 @@ template <int R> struct DirPack {          // 2 bits per row, R rows
   }
 };
 
-struct AffixBest {          // running best cut of find_longest_affix
-  uint32_t valid, v, s, e, g;
-  // One cell of the scan, branch-free (a lone wave pays for every taken branch): the cell is a
-  // candidate when the characters match and 200*v <= 17*(e+g); it replaces the running best when
-  // its weight v/(e+g) is smaller, or equal with a later (e,g).  `small`: e+g < 2^15, so every
-  // product fits 24x24 -> 32 bits (full-rate v_mul_u32_u24); otherwise 64-bit products.
+struct AffixBest {          // running best cut of find_longest_affix; s == 0: none yet
+  uint32_t v, s;            // its distance and e + g
+  uint64_t key;             // (e << 32) | g: the cell scanned later has the larger key
+  __device__ __forceinline__ uint32_t valid() const { return s != 0u ? 1u : 0u; }
+  __device__ __forceinline__ uint32_t e() const { return (uint32_t)(key >> 32); }
+  __device__ __forceinline__ uint32_t g() const { return (uint32_t)key; }
+  // One cell of the scan: the cell is a candidate when the characters match and
+  // 200*v <= 17*(e+g); it replaces the running best when its weight v/(e+g) is smaller, or equal
+  // with a later (e,g).  `small`: e+g < 2^15, so every product fits 24x24 -> 32 bits (full-rate
+  // v_mul_u32_u24); otherwise 64-bit products.  With no best yet (v = 1, s = 0) the first
+  // candidate wins: cv * 0 < 1 * cs.
   template <bool SMALL>
   __device__ __forceinline__ void consider(bool match, uint32_t cv, uint32_t ce, uint32_t cg) {
     const uint32_t cs = ce + cg;
     bool cand, less, equal;
     if constexpr (SMALL) cand = match & (__umul24(200u, cv) <= __umul24(17u, cs));
     else                 cand = match & (200ull * cv <= 17ull * cs);
-    // candidates are rare (a matching cell within 8.5 % of the diagonal sum): one scalar branch
-    // skips the comparison against the running best for the whole wave
+    // one scalar branch skips the comparison against the running best when no lane holds a candidate
     if (!__builtin_amdgcn_ballot_w64(cand)) return;
     if constexpr (SMALL) {
       const uint32_t lhs = __umul24(cv, s), rhs = __umul24(v, cs);
@@ -125,19 +142,26 @@ struct AffixBest {          // running best cut of find_longest_affix
       const uint64_t lhs = (uint64_t)cv * s, rhs = (uint64_t)v * cs;
       less = lhs < rhs; equal = lhs == rhs;
     }
-    const bool later = (ce > e) | ((ce == e) & (cg > g));
-    const bool take = cand & ((valid == 0u) | less | (equal & later));
-    valid = take ? 1u : valid; v = take ? cv : v; s = take ? cs : s; e = take ? ce : e; g = take ? cg : g;
+    const uint64_t ck = ((uint64_t)ce << 32) | cg;
+    const bool take = cand & (less | (equal & (ck > key)));
+    v = take ? cv : v; s = take ? cs : s; key = take ? ck : key;
   }
-  // true when candidate (cv/cs, ce, cg) replaces (v/s, e, g) under the reference's scan rule:
-  // smaller weight wins, equal weight -> the cell scanned later (larger (e,g)) wins.
-  __device__ __forceinline__ bool worse_than(uint32_t cv, uint32_t cs, uint32_t ce, uint32_t cg) const {
-    if (!valid) return true;
-    const uint64_t lhs = (uint64_t)cv * s, rhs = (uint64_t)v * cs;
+  // true when candidate o replaces this one under the reference's scan rule: smaller weight wins,
+  // equal weight -> the cell scanned later (larger (e,g)) wins.
+  __device__ __forceinline__ bool worse_than(const AffixBest& o) const {
+    if (!s) return true;
+    const uint64_t lhs = (uint64_t)o.v * s, rhs = (uint64_t)v * o.s;
     if (lhs != rhs) return lhs < rhs;
-    return ce > e || (ce == e && cg > g);
+    return o.key > key;
+  }
+  __device__ __forceinline__ AffixBest from_lane_xor(int off) const {
+    AffixBest o;
+    o.v = __shfl_xor(v, off); o.s = __shfl_xor(s, off);
+    o.key = ((uint64_t)__shfl_xor((uint32_t)(key >> 32), off) << 32) | __shfl_xor((uint32_t)key, off);
+    return o;
   }
 };
+constexpr AffixBest AFFIX_NONE{1u, 0u, 0ull};
 
 // One column sweep.  On return cur[r] = M[row(l,r)][nc].
 constexpr uint32_t BAND_INF = 0x3FFFFFu;   // "outside the band"; stays below the 24-bit value field
@@ -148,7 +172,7 @@ constexpr uint32_t BAND_INF = 0x3FFFFFu;   // "outside the band"; stays below th
 // The boundary values go through memory written and read by one wave: agent-scope atomics keep
 // the per-CU L1 out of the way.
 template <int R, bool WILD, bool DIRS, bool ROWMIN, bool AFFIX, bool BAND = false, bool ASMALL = false>
-__device__ __forceinline__ void lev_sweep(const Operand rows, const uint32_t nr,
+__device__ __forceinline__ void lev_sweep_strip(const Operand rows, const uint32_t nr,
                                           const Operand cols, const uint32_t nc,
                                           const uint32_t lane, uint32_t (&cur)[R],
                                           uint32_t (&minv)[R], uint32_t (&minpos)[R],
@@ -249,6 +273,98 @@ __device__ __forceinline__ void lev_sweep(const Operand rows, const uint32_t nr,
   }
 }
 
+// One column sweep over at most 64*R rows (the common case; strips of longer jobs: lev_sweep_strip).
+// The step loop is a chain of dependent instructions on one wave, so each instruction in it is
+// latency: per 64-step chunk the inputs of lane 0 (top value | column character) are prepared by
+// all lanes at once in ONE register (`feed`, lane t = step t) that moves one lane down per step, so
+// lane 0 always holds the input of the current step and the DPP shift that passes the strips' last
+// rows along drops it in: two DPP moves per step, no scalar round trip.  On return
+// cur[r] = M[row(l,r)][nc].
+template <int R, bool WILD, bool DIRS, bool ROWMIN, bool AFFIX, bool BAND = false, bool ASMALL = false>
+__device__ __forceinline__ void lev_sweep(const Operand rows, const uint32_t nr,
+                                          const Operand cols, const uint32_t nc,
+                                          const uint32_t lane, uint32_t (&cur)[R],
+                                          uint32_t (&minv)[R], uint32_t (&minpos)[R],
+                                          AffixBest& best, uint8_t* dir_ws, const uint32_t band_k = 0) {
+  uint32_t rc[R];                       // row characters of this lane's strip
+  const uint32_t row0 = lane * R;       // rows row0+1 .. row0+R
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const uint32_t i = row0 + r;
+    rc[r] = i < nr ? rows.at(i) : PAD_ROW;
+    cur[r] = i + 1;                     // M[i+1][0]
+    if constexpr (BAND) { if (i + 1 > band_k) cur[r] = BAND_INF; }
+    if constexpr (ROWMIN) { minv[r] = i + 1; minpos[r] = 0; }
+  }
+  if (nr == 0 || nc == 0) return;
+  const uint32_t last_lane = (nr - 1) / R;
+  const uint32_t steps = nc + last_lane;
+  uint32_t diag_in = row0;              // M[row0][j-1] for j = 1
+  uint32_t out = 0;                     // (value of the strip's last row) | (column char << 24)
+  constexpr uint32_t EB = R <= 4 ? 1u : R / 4;
+
+  for (uint32_t s0 = 0; s0 < steps; s0 += 64) {
+    const uint32_t jc = s0 + lane;      // column jc+1 enters lane 0 at step jc
+    uint32_t top = jc + 1u;             // M[0][jc+1]
+    if constexpr (BAND) { if (top > band_k) top = BAND_INF; }
+    uint32_t feed = top | ((jc < nc ? cols.at(jc) : PAD_COL) << 24);
+    const uint32_t tmax = (min(64u, steps - s0) + 7u) & ~7u;   // whole groups of 8; steps past the end touch no cell
+    for (uint32_t t0 = 0; t0 < tmax; t0 += 8) {
+#pragma unroll
+      for (uint32_t u = 0; u < 8; ++u) {
+        const uint32_t s = s0 + t0 + u;
+        const uint32_t in = wave_shr1_first(feed, out);
+        feed = wave_shl1(feed);
+        const uint32_t j = s - lane + 1;                   // column of this lane (wraps when idle)
+        if (j - 1u < nc) {
+          const uint32_t ch = in >> 24;
+          const uint32_t in_val = in & 0xFFFFFFu;
+          uint32_t up = in_val;
+          uint32_t diag = diag_in;
+          const bool ch_n = WILD && is_n(ch);
+          DirPack<R> dp;
+          if constexpr (DIRS) dp.clear();
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const uint32_t left = cur[r];
+            bool match = rc[r] == ch;
+            if constexpr (WILD) match = match || ch_n || is_n(rc[r]);
+            uint32_t v = diag + (match ? 0u : 1u);
+            if constexpr (DIRS) {
+              // ComputeAlignMatrix tie-break: diagonal, then up (dir 1), then left (dir 2), strict >
+              uint32_t d = 0;
+              if (v > up + 1) { v = up + 1; d = 1; }
+              if (v > left + 1) { v = left + 1; d = 2; }
+              dp.set(r, d);
+            } else {
+              v = min(v, min(up + 1, left + 1));
+            }
+            if constexpr (BAND) {
+              // K_band_edit_distance keeps cells with |column - row| <= k only; neighbours outside
+              // the band do not take part in the minimum (src/compute-alignments.c:375-443)
+              const uint32_t row = row0 + r + 1;
+              v = (j + band_k >= row && row + band_k >= j) ? min(v, BAND_INF) : BAND_INF;
+            }
+            if constexpr (ROWMIN) {
+              if (minv[r] > v) { minv[r] = v; minpos[r] = j; }   // strict: first arg-min
+            }
+            if constexpr (AFFIX) {
+              // cut_weight = 2*v/(e+g) <= 0.17  <=>  200*v <= 17*(e+g)   (exact)
+              best.template consider<ASMALL>(rc[r] == ch, v, row0 + r + 1, j);
+            }
+            diag = left;
+            cur[r] = v;
+            up = v;
+          }
+          diag_in = in_val;
+          out = up | (ch << 24);
+          if constexpr (DIRS) dp.store(dir_ws + ((size_t)s * 64 + lane) * EB);
+        }
+      }
+    }
+  }
+}
+
 // value of row `row` (1-based) after a sweep, written by the lane that owns it (predicated
 // stores instead of a dynamically indexed register array)
 template <int R>
@@ -270,11 +386,6 @@ enum { MODE_ED = 0, MODE_ALIGN = 1, MODE_BORDERS = 2, MODE_AFFIX = 3, MODE_KBAND
 // STRIPS (R = 64 only): jobs with more than 4096 rows, swept in strips of 4096 rows; the job's
 // workspace starts with the two boundary rows (strip_bnd_bytes each), ALIGN directions follow,
 // one block of (columns + 64) * 64 * 16 bytes per strip.
-
-__device__ __forceinline__ uint32_t wave_shl1(uint32_t v) {
-  // DPP wave_shl:1 -- lane l receives lane l+1's v; lane 63 keeps its own (the caller masks it)
-  return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x130, 0xf, 0xf, false);
-}
 
 // K_band_edit_distance (src/compute-alignments.c:375-443) with THE BAND ON THE LANES: lane s owns
 // slot s of the reference's 2k+1 wide row buffers, i.e. the diagonal column - row = s - k, and the
@@ -341,7 +452,7 @@ template <int R, int MODE, bool STRIPS = false>
 __device__ __forceinline__ void lev_wave_body(const DevJob& job, DevResult* res, uint8_t* __restrict__ ws,
                                               const uint32_t lane, uint32_t* wave_lds = nullptr) {
   uint32_t cur[R], minv[R], minpos[R];
-  AffixBest best{0, 0, 0, 0, 0};
+  AffixBest best = AFFIX_NONE;
 
   if constexpr (MODE == MODE_ED) {
     // distance is symmetric: keep the shorter string on the rows
@@ -356,7 +467,7 @@ __device__ __forceinline__ void lev_wave_body(const DevJob& job, DevResult* res,
       for (uint32_t k = 0; done < nr; ++k, done += SR) {
         const uint32_t part = min(SR, nr - done);
         const Operand rs{rows.base + done, 0, false};
-        lev_sweep<R, false, false, false, false>(rs, part, cols, nc, lane, cur, minv, minpos, best, nullptr, 0, done,
+        lev_sweep_strip<R, false, false, false, false>(rs, part, cols, nc, lane, cur, minv, minpos, best, nullptr, 0, done,
                                                  k ? bnd + ((k - 1) & 1) * bw : nullptr, done + part < nr ? bnd + (k & 1) * bw : nullptr);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // the next strip reads this strip's last row
         __builtin_amdgcn_wave_barrier();
@@ -389,7 +500,7 @@ __device__ __forceinline__ void lev_wave_body(const DevJob& job, DevResult* res,
       for (uint32_t k = 0; done < n; ++k, done += SR) {
         const uint32_t part = min(SR, n - done);
         const Operand rs{job.a + done, 0, false};
-        lev_sweep<R, true, true, false, false>(rs, part, cols, m, lane, cur, minv, minpos, best, dirs + k * strip_dirs, 0, done,
+        lev_sweep_strip<R, true, true, false, false>(rs, part, cols, m, lane, cur, minv, minpos, best, dirs + k * strip_dirs, 0, done,
                                                k ? bnd + ((k - 1) & 1) * bw : nullptr, done + part < n ? bnd + (k & 1) * bw : nullptr);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // the next strip reads this strip's last row
         __builtin_amdgcn_wave_barrier();
@@ -494,8 +605,8 @@ __device__ __forceinline__ void lev_wave_body(const DevJob& job, DevResult* res,
         const Operand rs{sht + done, 0, false};
         const uint32_t* tp = k ? bnd + ((k - 1) & 1) * bw : nullptr;
         uint32_t* bt = done + part < m ? bnd + (k & 1) * bw : nullptr;
-        if (banded) lev_sweep<R, false, false, false, false, true>(rs, part, cols, n, lane, cur, minv, minpos, best, nullptr, ub, done, tp, bt);
-        else        lev_sweep<R, false, false, false, false, false>(rs, part, cols, n, lane, cur, minv, minpos, best, nullptr, 0, done, tp, bt);
+        if (banded) lev_sweep_strip<R, false, false, false, false, true>(rs, part, cols, n, lane, cur, minv, minpos, best, nullptr, ub, done, tp, bt);
+        else        lev_sweep_strip<R, false, false, false, false, false>(rs, part, cols, n, lane, cur, minv, minpos, best, nullptr, 0, done, tp, bt);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // the next strip reads this strip's last row
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -522,7 +633,7 @@ __device__ __forceinline__ void lev_wave_body(const DevJob& job, DevResult* res,
       for (uint32_t k = 0; done < job.la; ++k, done += SR) {
         const uint32_t part = min(SR, job.la - done);
         const Operand rs{job.a + done, 0, false};
-        lev_sweep<R, false, false, false, true>(rs, part, cols, job.lb, lane, cur, minv, minpos, best, nullptr, 0, done,
+        lev_sweep_strip<R, false, false, false, true>(rs, part, cols, job.lb, lane, cur, minv, minpos, best, nullptr, 0, done,
                                                 k ? bnd + ((k - 1) & 1) * bw : nullptr, done + part < job.la ? bnd + (k & 1) * bw : nullptr);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // the next strip reads this strip's last row
         __builtin_amdgcn_wave_barrier();
@@ -535,14 +646,12 @@ __device__ __forceinline__ void lev_wave_body(const DevJob& job, DevResult* res,
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {       // wave-wide arg-best
-      AffixBest o;
-      o.valid = __shfl_xor(best.valid, off); o.v = __shfl_xor(best.v, off);
-      o.s = __shfl_xor(best.s, off); o.e = __shfl_xor(best.e, off); o.g = __shfl_xor(best.g, off);
-      if (o.valid && best.worse_than(o.v, o.s, o.e, o.g)) best = o;
+      const AffixBest o = best.from_lane_xor(off);
+      if (o.s && best.worse_than(o)) best = o;
     }
     if (lane == 0) {
-      res->status = 0; res->v[0] = (int32_t)best.valid;
-      res->v[1] = (int32_t)best.e; res->v[2] = (int32_t)best.g;
+      res->status = 0; res->v[0] = (int32_t)best.valid();
+      res->v[1] = (int32_t)best.e(); res->v[2] = (int32_t)best.g();
     }
   }
 }
@@ -658,55 +767,74 @@ __device__ __forceinline__ void lev_sweep_coop(const Operand rows, const uint32_
   const uint32_t steps = nc + last_lane;
   const uint32_t nchunks = (steps + 63u) / 64u;
   const bool wave_used = w * 64u <= last_lane;
-  uint32_t diag_in = row0, out = 0, chunk = 0, hin = 0, carry = 0;
+  uint32_t diag_in = row0, out = 0;
+  // The step loop is a chain of dependent instructions on one wave, so every instruction in it is
+  // latency, and the hand-off between the waves costs ONE DPP move per step on either side:
+  //  * producer: `hout` is a shift register, hout = (lanes move one down, lane 63 <- this step's
+  //    `out` of lane 63); after the T steps of a chunk lane 63-k holds the step k before the last.
+  //    It goes to the LDS array once per chunk (all lanes, one store);
+  //  * consumer: reads the array once per chunk and turns it (one ds_bpermute) into `feed`, lane t =
+  //    the input of step t = the producer's output of the step before; `feed` moves one lane down
+  //    per step so lane 0 always holds the current input, and the DPP shift that passes the strips'
+  //    last rows along drops it in.  Wave 0's feed is (top value | column character) instead.
+  // No per-step LDS access, scalar round trip or branch on the wave number.  A wave's first cell
+  // lies in chunk w; it looks at the array one chunk earlier for the step before its first.
+  uint32_t hout = 0, prev = 0;
   uint32_t* hand_in = hand + (w > 0 ? (w - 1) * 128u : 0u);
-  uint32_t* hand_out = hand + w * 128u;
+  uint32_t* hand_out = hand + (w + 1 < (uint32_t)COOP_W ? w : 0u) * 128u;
 
   for (uint32_t k = 0; k < nchunks + COOP_W - 1; ++k) {
     const int c = (int)k - (int)w;
-    // chunk w-1 holds no cell of this wave yet, but its hand-off carries the value for step 64w
-    if (wave_used && c >= (int)w - 1 && c >= 0 && c < (int)nchunks) {
-      if (w > 0) {
-        carry = (uint32_t)__builtin_amdgcn_readlane((int)hin, 63);
-        hin = hand_in[(c & 1) * 64 + lane];
-      }
+    if (wave_used && w > 0 && c == (int)w - 1) prev = hand_in[(c & 1) * 64 + lane];
+    if (wave_used && c >= (int)w && c < (int)nchunks) {
       const uint32_t s0 = (uint32_t)c * 64u;
-      const uint32_t tmax = min(64u, steps - s0);
-      for (uint32_t t = 0; t < tmax; ++t) {
-        const uint32_t s = s0 + t;
-        uint32_t in = wave_shr1(out);
-        if (w == 0) {
-          if (t == 0) { const uint32_t j = s + lane; chunk = j < nc ? cols.at(j) : PAD_COL; }
-          const uint32_t ch0 = (uint32_t)__builtin_amdgcn_readlane((int)chunk, (int)t);
-          if (lane == 0) in = (s + 1) | (ch0 << 24);
-        } else {
-          const uint32_t v = t == 0 ? carry : (uint32_t)__builtin_amdgcn_readlane((int)hin, (int)(t - 1));
-          if (lane == 0) in = v;
-        }
-        const uint32_t j = s - gl + 1;
-        if (j - 1u < nc) {
-          const uint32_t ch = in >> 24;
-          const uint32_t in_val = in & 0xFFFFFFu;
-          uint32_t up = in_val;
-          uint32_t diag = diag_in;
-#pragma unroll
-          for (int r = 0; r < R; ++r) {
-            const uint32_t left = cur[r];
-            uint32_t v = diag + (rc[r] == ch ? 0u : 1u);
-            v = min(v, min(up + 1, left + 1));
-            if constexpr (ROWMIN) {
-              if (minv[r] > v) { minv[r] = v; minpos[r] = j; }
-            }
-            if constexpr (AFFIX) best.template consider<ASMALL>(rc[r] == ch, v, row0 + r + 1, j);
-            diag = left;
-            cur[r] = v;
-            up = v;
-          }
-          diag_in = in_val;
-          out = up | (ch << 24);
-        }
-        if (w + 1 < COOP_W && lane == 63) hand_out[(c & 1) * 64 + t] = out;
+      const uint32_t tmax = (min(64u, steps - s0) + 7u) & ~7u;   // whole groups of 8; steps past the end touch no cell
+      uint32_t feed;
+      if (w == 0) {
+        const uint32_t jc = s0 + lane;                       // column jc+1 enters lane 0 at step jc
+        feed = (jc + 1u) | ((jc < nc ? cols.at(jc) : PAD_COL) << 24);
+      } else {
+        // the producer ran the same tmax steps on this chunk: its step t is in lane 64-tmax+t, the
+        // last step of the chunk before in lane 63-tmax -- or, after a full chunk, in lane 63 of
+        // what was read for the chunk before
+        const uint32_t cur_in = hand_in[(c & 1) * 64 + lane];
+        feed = (uint32_t)__shfl((int)cur_in, (int)((lane + 63u - tmax) & 63u));
+        const uint32_t carry = (uint32_t)__builtin_amdgcn_readlane((int)prev, 63);
+        if (tmax == 64u && lane == 0) feed = carry;
+        prev = cur_in;
       }
+      for (uint32_t t0 = 0; t0 < tmax; t0 += 8) {
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u) {
+          const uint32_t s = s0 + t0 + u;
+          const uint32_t in = wave_shr1_first(feed, out);
+          feed = wave_shl1(feed);
+          const uint32_t j = s - gl + 1;
+          if (j - 1u < nc) {
+            const uint32_t ch = in >> 24;
+            const uint32_t in_val = in & 0xFFFFFFu;
+            uint32_t up = in_val;
+            uint32_t diag = diag_in;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+              const uint32_t left = cur[r];
+              uint32_t v = diag + (rc[r] == ch ? 0u : 1u);
+              v = min(v, min(up + 1, left + 1));
+              if constexpr (ROWMIN) {
+                if (minv[r] > v) { minv[r] = v; minpos[r] = j; }
+              }
+              if constexpr (AFFIX) best.template consider<ASMALL>(rc[r] == ch, v, row0 + r + 1, j);
+              diag = left;
+              cur[r] = v;
+              up = v;
+            }
+            diag_in = in_val;
+            out = up | (ch << 24);
+          }
+          hout = wave_shl1_last(out, hout);
+        }
+      }
+      if (w + 1 < (uint32_t)COOP_W) hand_out[(c & 1) * 64 + lane] = hout;
     }
     __syncthreads();
   }
@@ -726,7 +854,7 @@ __device__ __forceinline__ void borders_coop_body(const DevJob& job, DevResult* 
   uint32_t* pre = lds + 2 * (COOP_W - 1) * 128; uint32_t* pre_pos = pre + (len_p + 1);
   uint32_t* suf = pre_pos + (len_p + 1); uint32_t* suf_pos = suf + (len_p + 1);
   uint32_t cur[R], minv[R], minpos[R];
-  AffixBest best{0, 0, 0, 0, 0};
+  AffixBest best = AFFIX_NONE;
   const Operand rows{job.a, len_p, sweep == 1}, cols{job.b, len_t, sweep == 1};
   lev_sweep_coop<R, true, false>(rows, len_p, cols, t_win, w, lane, hand, cur, minv, minpos, best);
   uint32_t* mv = sweep ? suf : pre; uint32_t* mp = sweep ? suf_pos : pre_pos;
@@ -764,10 +892,7 @@ __device__ __forceinline__ void borders_coop_body(const DevJob& job, DevResult* 
 }
 
 // every row class above 64 rows in one launch (one job per workgroup; see lev_any_kernel)
-__global__ __launch_bounds__(512)
-void borders_coop_any_kernel(const DevJob* __restrict__ jobs, int njobs, DevResult* __restrict__ results) {
-  const DevJob job = jobs[blockIdx.x];
-  DevResult* res = &results[job.out_idx];
+__device__ __forceinline__ void borders_coop_dispatch(const DevJob& job, DevResult* res) {
   switch (job.r_class) {                 // rows per lane of the 256-lane sweep = class / COOP_W
     case 2: case 4: borders_coop_body<1>(job, res); break;
     case 8:  borders_coop_body<2>(job, res); break;
@@ -777,33 +902,47 @@ void borders_coop_any_kernel(const DevJob* __restrict__ jobs, int njobs, DevResu
   }
 }
 
+__global__ __launch_bounds__(512)
+void borders_coop_any_kernel(const DevJob* __restrict__ jobs, int njobs, DevResult* __restrict__ results) {
+  const DevJob job = jobs[blockIdx.x];
+  borders_coop_dispatch(job, &results[job.out_idx]);
+}
+
 // find_longest_affix (src/factorization-refinement.c:1136-1173) for more than 64 rows
 template <int R>
 __device__ __forceinline__ void affix_coop_body(const DevJob& job, DevResult* res, uint32_t* hand, uint32_t (*wbest)[5]) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   uint32_t cur[R], minv[R], minpos[R];
-  AffixBest best{0, 0, 0, 0, 0};
+  AffixBest best = AFFIX_NONE;
   const Operand rows{job.a, 0, false}, cols{job.b, 0, false};
   // e + g < 2^15: every product of the cut test fits 24 x 24 -> 32 bits (AffixBest::consider)
   if (job.la + job.lb < 32768u) lev_sweep_coop<R, false, true, true>(rows, job.la, cols, job.lb, w, lane, hand, cur, minv, minpos, best);
   else                          lev_sweep_coop<R, false, true, false>(rows, job.la, cols, job.lb, w, lane, hand, cur, minv, minpos, best);
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {
-    AffixBest o;
-    o.valid = __shfl_xor(best.valid, off); o.v = __shfl_xor(best.v, off);
-    o.s = __shfl_xor(best.s, off); o.e = __shfl_xor(best.e, off); o.g = __shfl_xor(best.g, off);
-    if (o.valid && best.worse_than(o.v, o.s, o.e, o.g)) best = o;
+    const AffixBest o = best.from_lane_xor(off);
+    if (o.s && best.worse_than(o)) best = o;
   }
-  if (lane == 0) { wbest[w][0] = best.valid; wbest[w][1] = best.v; wbest[w][2] = best.s; wbest[w][3] = best.e; wbest[w][4] = best.g; }
+  if (lane == 0) { wbest[w][0] = best.v; wbest[w][1] = best.s; wbest[w][2] = best.e(); wbest[w][3] = best.g(); }
   __syncthreads();
   if (threadIdx.x == 0) {
     for (int k = 1; k < COOP_W; ++k) {
-      AffixBest o{wbest[k][0], wbest[k][1], wbest[k][2], wbest[k][3], wbest[k][4]};
-      if (o.valid && best.worse_than(o.v, o.s, o.e, o.g)) best = o;
+      const AffixBest o{wbest[k][0], wbest[k][1], ((uint64_t)wbest[k][2] << 32) | wbest[k][3]};
+      if (o.s && best.worse_than(o)) best = o;
     }
-    res->status = 0; res->v[0] = (int32_t)best.valid;
-    res->v[1] = (int32_t)best.e; res->v[2] = (int32_t)best.g;
+    res->status = 0; res->v[0] = (int32_t)best.valid();
+    res->v[1] = (int32_t)best.e(); res->v[2] = (int32_t)best.g();
+  }
+}
+
+__device__ __forceinline__ void affix_coop_dispatch(const DevJob& job, DevResult* res, uint32_t* hand, uint32_t (*wbest)[5]) {
+  switch (job.r_class) {
+    case 2: case 4: affix_coop_body<1>(job, res, hand, wbest); break;
+    case 8:  affix_coop_body<2>(job, res, hand, wbest); break;
+    case 16: affix_coop_body<4>(job, res, hand, wbest); break;
+    case 32: affix_coop_body<8>(job, res, hand, wbest); break;
+    default: affix_coop_body<16>(job, res, hand, wbest); break;
   }
 }
 
@@ -812,14 +951,7 @@ void affix_coop_any_kernel(const DevJob* __restrict__ jobs, int njobs, DevResult
   __shared__ uint32_t hand[(COOP_W - 1) * 128];
   __shared__ uint32_t wbest[COOP_W][5];
   const DevJob job = jobs[blockIdx.x];
-  DevResult* res = &results[job.out_idx];
-  switch (job.r_class) {
-    case 2: case 4: affix_coop_body<1>(job, res, hand, wbest); break;
-    case 8:  affix_coop_body<2>(job, res, hand, wbest); break;
-    case 16: affix_coop_body<4>(job, res, hand, wbest); break;
-    case 32: affix_coop_body<8>(job, res, hand, wbest); break;
-    default: affix_coop_body<16>(job, res, hand, wbest); break;
-  }
+  affix_coop_dispatch(job, &results[job.out_idx], hand, wbest);
 }
 
 // TracebackAlignment (src/compute-alignments.c:149-207), one WAVE per job.
@@ -942,59 +1074,67 @@ __device__ __forceinline__ void gap_wave_body(const DevJob& job, DevResult* res,
   if (n > 0 && m > 0) {
     const uint32_t last_lane = (n - 1) / R, steps = m + last_lane;
     int32_t dgL = 0, dgR = 0;                               // row above the strip, previous column
-    uint32_t out = 0, outc = 0, chunk = 0;
+    uint32_t out = 0, outc = 0;
     uint8_t* dirs = ws + job.ws_off;
-    for (uint32_t s = 0; s < steps; ++s) {
-      const uint32_t t = s & 63u;
-      if (t == 0) { const uint32_t j = s + lane; chunk = j < m ? job.b[j] : PAD_COL; }
-      uint32_t in = wave_shr1(out);
-      uint32_t inc = wave_shr1(outc);
-      const uint32_t ch0 = (uint32_t)__builtin_amdgcn_readlane((int)chunk, (int)t);
-      if (lane == 0) { in = 0; inc = ch0; }                 // row 0 of L and R is 0
-      const uint32_t j = s - lane + 1;
-      if (j - 1u < m) {
-        const uint32_t ch = inc;
-        const int32_t inL = (int32_t)(int16_t)(in & 0xFFFFu), inR = (int32_t)(int16_t)(in >> 16);
-        int32_t upL = inL, upR = inR, diagL = dgL, diagR = dgR;
-        const bool ch_n = is_n(ch);
-        uint32_t packed[(R + 3) / 4];
+    // per 64-step chunk the column characters sit in `feed` (lane t = step t), which moves one lane
+    // down per step: lane 0 always holds the current one (see lev_sweep)
+    for (uint32_t s0 = 0; s0 < steps; s0 += 64) {
+      const uint32_t jc = s0 + lane;
+      uint32_t feed = jc < m ? job.b[jc] : PAD_COL;
+      const uint32_t tmax = (min(64u, steps - s0) + 7u) & ~7u;   // whole groups of 8; steps past the end touch no cell
+      for (uint32_t t0 = 0; t0 < tmax; t0 += 8) {
 #pragma unroll
-        for (int q = 0; q < (R + 3) / 4; ++q) packed[q] = 0;
+        for (uint32_t u = 0; u < 8; ++u) {
+          const uint32_t s = s0 + t0 + u;
+          const uint32_t in = wave_shr1_first(0u, out);         // row 0 of L and R is 0
+          const uint32_t inc = wave_shr1_first(feed, outc);
+          feed = wave_shl1(feed);
+          const uint32_t j = s - lane + 1;
+          if (j - 1u < m) {
+            const uint32_t ch = inc;
+            const int32_t inL = (int32_t)(int16_t)(in & 0xFFFFu), inR = (int32_t)(int16_t)(in >> 16);
+            int32_t upL = inL, upR = inR, diagL = dgL, diagR = dgR;
+            const bool ch_n = is_n(ch);
+            uint32_t packed[(R + 3) / 4];
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-          const int32_t leftL = cL[r], leftG = cG[r], leftR = cR[r];
-          const int32_t sub = (rc[r] == ch || ch_n || is_n(rc[r])) ? 1 : -1;
-          // L plane: diag, up (1), left (2); strict '<' replaces
-          int32_t v = diagL + sub; uint32_t dl = 0;
-          if (v < upL - 1) { v = upL - 1; dl = 1; }
-          if (v < leftL - 1) { v = leftL - 1; dl = 2; }
-          // G plane: stay (2) or enter from L (-2)
-          int32_t g = leftG; uint32_t dg = 0;
-          if (g < leftL) { g = leftL; dg = 1; }
-          // R plane: diag, left (2; free in the last EST row), from G (-2), up (1)
-          int32_t rv = diagR + sub; uint32_t dr = 0;
-          const int32_t lc = (row0 + r + 1 != n) ? leftR - 1 : leftR;
-          if (rv < lc) { rv = lc; dr = 2; }
-          if (rv < leftG) { rv = leftG; dr = 3; }
-          if (rv < upR - 1) { rv = upR - 1; dr = 1; }
-          packed[r / 4] |= (dl | (dg << 2) | (dr << 3)) << (8 * (r % 4));
-          diagL = leftL; diagR = leftR;
-          cL[r] = v; cG[r] = g; cR[r] = rv;
-          upL = v; upR = rv;
-        }
-        dgL = inL; dgR = inR;
-        out = ((uint32_t)upL & 0xFFFFu) | ((uint32_t)upR << 16);
-        outc = ch;
-        uint8_t* p = dirs + ((size_t)s * 64 + lane) * R;
-        if constexpr (R == 1)      *p = (uint8_t)packed[0];
-        else if constexpr (R == 2) *reinterpret_cast<uint16_t*>(p) = (uint16_t)packed[0];
-        else if constexpr (R == 4) *reinterpret_cast<uint32_t*>(p) = packed[0];
-        else if constexpr (R == 8) *reinterpret_cast<uint2*>(p) = make_uint2(packed[0], packed[1]);
-        else {
+            for (int q = 0; q < (R + 3) / 4; ++q) packed[q] = 0;
 #pragma unroll
-          for (int q = 0; q < R / 16; ++q)
-            reinterpret_cast<uint4*>(p)[q] =
-                make_uint4(packed[4 * q], packed[4 * q + 1], packed[4 * q + 2], packed[4 * q + 3]);
+            for (int r = 0; r < R; ++r) {
+              const int32_t leftL = cL[r], leftG = cG[r], leftR = cR[r];
+              const int32_t sub = (rc[r] == ch || ch_n || is_n(rc[r])) ? 1 : -1;
+              // L plane: diag, up (1), left (2); strict '<' replaces
+              int32_t v = diagL + sub; uint32_t dl = 0;
+              if (v < upL - 1) { v = upL - 1; dl = 1; }
+              if (v < leftL - 1) { v = leftL - 1; dl = 2; }
+              // G plane: stay (2) or enter from L (-2)
+              int32_t g = leftG; uint32_t dg = 0;
+              if (g < leftL) { g = leftL; dg = 1; }
+              // R plane: diag, left (2; free in the last EST row), from G (-2), up (1)
+              int32_t rv = diagR + sub; uint32_t dr = 0;
+              const int32_t lc = (row0 + r + 1 != n) ? leftR - 1 : leftR;
+              if (rv < lc) { rv = lc; dr = 2; }
+              if (rv < leftG) { rv = leftG; dr = 3; }
+              if (rv < upR - 1) { rv = upR - 1; dr = 1; }
+              packed[r / 4] |= (dl | (dg << 2) | (dr << 3)) << (8 * (r % 4));
+              diagL = leftL; diagR = leftR;
+              cL[r] = v; cG[r] = g; cR[r] = rv;
+              upL = v; upR = rv;
+            }
+            dgL = inL; dgR = inR;
+            out = ((uint32_t)upL & 0xFFFFu) | ((uint32_t)upR << 16);
+            outc = ch;
+            uint8_t* p = dirs + ((size_t)s * 64 + lane) * R;
+            if constexpr (R == 1)      *p = (uint8_t)packed[0];
+            else if constexpr (R == 2) *reinterpret_cast<uint16_t*>(p) = (uint16_t)packed[0];
+            else if constexpr (R == 4) *reinterpret_cast<uint32_t*>(p) = packed[0];
+            else if constexpr (R == 8) *reinterpret_cast<uint2*>(p) = make_uint2(packed[0], packed[1]);
+            else {
+#pragma unroll
+              for (int q = 0; q < R / 16; ++q)
+                reinterpret_cast<uint4*>(p)[q] =
+                    make_uint4(packed[4 * q], packed[4 * q + 1], packed[4 * q + 2], packed[4 * q + 3]);
+            }
+          }
         }
       }
     }
@@ -1138,15 +1278,17 @@ __device__ __forceinline__ void gap_traceback_wave(const DevJob& job, DevResult*
 // ---------------------------------------------------------------------------------------------
 struct WaveSegs { int n; int start[6]; int count[6]; int family[6]; };
 
-__global__ __launch_bounds__(256)
-void wave_jobs_kernel(const DevJob* __restrict__ jobs, const WaveSegs segs, DevResult* __restrict__ results,
-                      uint8_t* __restrict__ ws, uint8_t* __restrict__ strs) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_win[4][TB_WIN_BYTES];
-  __shared__ uint8_t s_path[4][TB_PATH];
-  __shared__ uint32_t s_borders[4][4 * 65];
-  const uint32_t lane = threadIdx.x & 63u;
-  const int wave = (int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  int w = blockIdx.x * 4 + wave, fam = -1, idx = 0;
+constexpr size_t WAVE_JOBS_LDS = 4 * (size_t)TB_WIN_BYTES + 4 * (size_t)TB_PATH + 4 * 4 * 65 * sizeof(uint32_t);
+
+// wave `wave` (0..3) of workgroup `block` of the wave-per-job part; smem: WAVE_JOBS_LDS bytes, 16-aligned
+__device__ __forceinline__ void wave_jobs_body(const int block, const int wave, const uint32_t lane,
+                                               const DevJob* __restrict__ jobs, const WaveSegs& segs,
+                                               DevResult* __restrict__ results, uint8_t* __restrict__ ws,
+                                               uint8_t* __restrict__ strs, uint8_t* smem) {
+  uint8_t* s_win = smem + (size_t)wave * TB_WIN_BYTES;
+  uint8_t* s_path = smem + 4 * (size_t)TB_WIN_BYTES + (size_t)wave * TB_PATH;
+  uint32_t* s_borders = reinterpret_cast<uint32_t*>(smem + 4 * (size_t)TB_WIN_BYTES + 4 * (size_t)TB_PATH) + wave * (4 * 65);
+  int w = block * 4 + wave, fam = -1, idx = 0;
   for (int sgi = 0; sgi < segs.n; ++sgi) {
     if (w < segs.count[sgi]) { fam = segs.family[sgi]; idx = segs.start[sgi] + w; break; }
     w -= segs.count[sgi];
@@ -1158,7 +1300,7 @@ void wave_jobs_kernel(const DevJob* __restrict__ jobs, const WaveSegs segs, DevR
     case KF_ALIGN:
       lev_any_dispatch<MODE_ALIGN, false>(job, res, ws, lane);
       own_stores_visible();
-      align_traceback_wave(job, res, ws, strs, lane, s_win[wave], s_path[wave]);
+      align_traceback_wave(job, res, ws, strs, lane, s_win, s_path);
       break;
     case KF_GAP:
       switch (job.r_class) {
@@ -1167,15 +1309,58 @@ void wave_jobs_kernel(const DevJob* __restrict__ jobs, const WaveSegs segs, DevR
         default: gap_wave_body<4>(job, res, ws, lane); break;
       }
       own_stores_visible();
-      gap_traceback_wave(job, res, ws, strs, lane, s_win[wave], s_path[wave]);
+      gap_traceback_wave(job, res, ws, strs, lane, s_win, s_path);
       break;
     case KF_KBAND:   lev_any_dispatch<MODE_KBAND, false>(job, res, ws, lane); break;
     case KF_ED:      lev_any_dispatch<MODE_ED, false>(job, res, ws, lane); break;
-    case KF_BORDERS: lev_wave_body<1, MODE_BORDERS>(job, res, ws, lane, s_borders[wave]); break;
+    case KF_BORDERS: lev_wave_body<1, MODE_BORDERS>(job, res, ws, lane, s_borders); break;
     case KF_AFFIX:   lev_wave_body<1, MODE_AFFIX>(job, res, ws, lane); break;
     default: break;
   }
 }
+
+__global__ __launch_bounds__(256)
+void wave_jobs_kernel(const DevJob* __restrict__ jobs, const WaveSegs segs, DevResult* __restrict__ results,
+                      uint8_t* __restrict__ ws, uint8_t* __restrict__ strs) {
+  __shared__ __attribute__((aligned(16))) uint8_t smem[WAVE_JOBS_LDS];
+  const int wave = (int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  wave_jobs_body((int)blockIdx.x, wave, threadIdx.x & 63u, jobs, segs, results, ws, strs, smem);
+}
+
+// ---------------------------------------------------------------------------------------------
+// ONE launch for everything of a batch that is bound by the latency of its longest job: the
+// one-job-per-workgroup sweeps (BORDERS on eight waves, AFFIX on four) and the wave-per-job
+// families.  Workgroups of 512 threads; the role of a workgroup follows from its index -- the long
+// poles first, so they start first: [BORDERS coop jobs][AFFIX coop jobs][wave-job groups of four].
+// The roles with four waves let the upper four end at once (s_barrier only waits for the waves of
+// a workgroup that have not ended).  All roles share the dynamic LDS.
+// ---------------------------------------------------------------------------------------------
+struct BatchDesc { WaveSegs segs; int wave_blocks; int bc_start, bc_count, ac_start, ac_count; };
+
+__global__ __launch_bounds__(512)
+void dp_batch_kernel(const DevJob* __restrict__ jobs, const BatchDesc d, DevResult* __restrict__ results,
+                     uint8_t* __restrict__ ws, uint8_t* __restrict__ strs) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t batch_lds[];
+  int b = (int)blockIdx.x;
+  if (b < d.bc_count) {
+    const DevJob job = jobs[d.bc_start + b];
+    borders_coop_dispatch(job, &results[job.out_idx]);      // its LDS is the dynamic array
+    return;
+  }
+  b -= d.bc_count;
+  if (threadIdx.x >= 256) return;
+  if (b < d.ac_count) {
+    const DevJob job = jobs[d.ac_start + b];
+    uint32_t* hand = reinterpret_cast<uint32_t*>(batch_lds);
+    uint32_t (*wbest)[5] = reinterpret_cast<uint32_t (*)[5]>(batch_lds + (COOP_W - 1) * 128 * sizeof(uint32_t));
+    affix_coop_dispatch(job, &results[job.out_idx], hand, wbest);
+    return;
+  }
+  b -= d.ac_count;
+  const int wave = (int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  wave_jobs_body(b, wave, threadIdx.x & 63u, jobs, d.segs, results, ws, strs, batch_lds);
+}
+constexpr size_t AFFIX_COOP_LDS = (COOP_W - 1) * 128 * sizeof(uint32_t) + COOP_W * 5 * sizeof(uint32_t);
 
 // ---------------------------------------------------------------------------------------------
 // Longest common factor with N wildcard: find_longest_common_factor_dp
@@ -1193,77 +1378,71 @@ __device__ __forceinline__ unsigned long long lcf_key(uint32_t len, uint32_t occ
          (unsigned long long)(0xFFFFu - occ2);
 }
 
+// grid (workgroups per job, jobs); keys[job] (zeroed by the caller) collects the best key of the job's
+// workgroups.  The host turns the keys into results (pgpu_dp_plan_sync): a finish pass on the device
+// would cost a launch per batch, and "the last workgroup finishes" needs device-scope fences, i.e. a
+// write-back and an invalidation of the XCD's L2 per workgroup -- measured: six times slower, and every
+// kernel running beside it with it.
 __global__ __launch_bounds__(LCF_BLOCK)
 void lcf_kernel(const DevJob* __restrict__ jobs, int njobs, unsigned long long* __restrict__ keys) {
   extern __shared__ uint8_t lcf_lds[];         // [s2: l2 bytes][s1 tile: LCF_BLOCK + l2 bytes]
+  __shared__ unsigned long long wbest[LCF_BLOCK / 64];
   const DevJob job = jobs[blockIdx.y];
   const uint32_t l1 = job.la, l2 = job.lb;
-  if (l1 == 0 || l2 == 0) return;
-  uint8_t* s2 = lcf_lds;
-  uint8_t* tile = lcf_lds + ((l2 + 15u) & ~15u);
-  for (uint32_t i = threadIdx.x; i < l2; i += LCF_BLOCK) s2[i] = job.b[i];
-  const uint32_t ndiag = l1 + l2 - 1;
-  const uint32_t nchunks = (ndiag + LCF_BLOCK - 1) / LCF_BLOCK;
   unsigned long long best = 0;
-  for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-    // diagonal index dg in [0, ndiag): i1 - i2 = dg - (l2-1).  This chunk covers s1 positions
-    // [base, base + LCF_BLOCK + l2 - 1) where base = chunk*LCF_BLOCK - (l2-1) (may be negative)
-    const int64_t base = (int64_t)chunk * LCF_BLOCK - (int64_t)(l2 - 1);
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < LCF_BLOCK + l2 - 1; i += LCF_BLOCK) {
-      const int64_t g = base + i;
-      tile[i] = (g >= 0 && g < (int64_t)l1) ? job.a[g] : 0;
-    }
-    __syncthreads();
-    const uint32_t dg = chunk * LCF_BLOCK + threadIdx.x;
-    if (dg < ndiag) {
-      // cells of this diagonal: i2 from max(0, l2-1-dg), i1 = i2 + dg - (l2-1)
-      const uint32_t i2_lo = dg < l2 - 1 ? l2 - 1 - dg : 0;
-      const int64_t shift = (int64_t)dg - (int64_t)(l2 - 1);       // i1 - i2
-      uint32_t i2_hi = l2;                                          // exclusive
-      if ((int64_t)l1 - shift < (int64_t)i2_hi) i2_hi = (uint32_t)((int64_t)l1 - shift);
-      uint32_t run = 0, brun = 0, bend = 0;
-      for (uint32_t i2 = i2_lo; i2 < i2_hi; ++i2) {
-        const uint32_t c1 = tile[threadIdx.x + i2];                // s1[i2 + shift] = tile[i2+shift-base]
-        const uint32_t c2 = s2[i2];
-        run = (c1 == c2 || is_n(c1) || is_n(c2)) ? run + 1 : 0;
-        if (run > brun) { brun = run; bend = i2; }
+  if (l1 != 0 && l2 != 0) {                    // uniform over the workgroup
+    uint8_t* s2 = lcf_lds;
+    uint8_t* tile = lcf_lds + ((l2 + 15u) & ~15u);
+    for (uint32_t i = threadIdx.x; i < l2; i += LCF_BLOCK) s2[i] = job.b[i];
+    const uint32_t ndiag = l1 + l2 - 1;
+    const uint32_t nchunks = (ndiag + LCF_BLOCK - 1) / LCF_BLOCK;
+    for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+      // diagonal index dg in [0, ndiag): i1 - i2 = dg - (l2-1).  This chunk covers s1 positions
+      // [base, base + LCF_BLOCK + l2 - 1) where base = chunk*LCF_BLOCK - (l2-1) (may be negative)
+      const int64_t base = (int64_t)chunk * LCF_BLOCK - (int64_t)(l2 - 1);
+      __syncthreads();
+      for (uint32_t i = threadIdx.x; i < LCF_BLOCK + l2 - 1; i += LCF_BLOCK) {
+        const int64_t g = base + i;
+        tile[i] = (g >= 0 && g < (int64_t)l1) ? job.a[g] : 0;
       }
-      if (brun > 0) {
-        const uint32_t occ2 = bend + 1 - brun;
-        const uint32_t occ1 = (uint32_t)((int64_t)occ2 + shift);
-        const unsigned long long key = lcf_key(brun, occ1, occ2);
-        best = key > best ? key : best;
+      __syncthreads();
+      const uint32_t dg = chunk * LCF_BLOCK + threadIdx.x;
+      if (dg < ndiag) {
+        // cells of this diagonal: i2 from max(0, l2-1-dg), i1 = i2 + dg - (l2-1)
+        const uint32_t i2_lo = dg < l2 - 1 ? l2 - 1 - dg : 0;
+        const int64_t shift = (int64_t)dg - (int64_t)(l2 - 1);       // i1 - i2
+        uint32_t i2_hi = l2;                                          // exclusive
+        if ((int64_t)l1 - shift < (int64_t)i2_hi) i2_hi = (uint32_t)((int64_t)l1 - shift);
+        uint32_t run = 0, brun = 0, bend = 0;
+        for (uint32_t i2 = i2_lo; i2 < i2_hi; ++i2) {
+          const uint32_t c1 = tile[threadIdx.x + i2];                // s1[i2 + shift] = tile[i2+shift-base]
+          const uint32_t c2 = s2[i2];
+          run = (c1 == c2 || is_n(c1) || is_n(c2)) ? run + 1 : 0;
+          if (run > brun) { brun = run; bend = i2; }
+        }
+        if (brun > 0) {
+          const uint32_t occ2 = bend + 1 - brun;
+          const uint32_t occ1 = (uint32_t)((int64_t)occ2 + shift);
+          const unsigned long long key = lcf_key(brun, occ1, occ2);
+          best = key > best ? key : best;
+        }
       }
     }
-  }
-  // workgroup reduction, one atomic per workgroup
+    // workgroup reduction, one atomic per workgroup
 #pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    const unsigned long long o = __shfl_xor(best, off);
-    best = o > best ? o : best;
+    for (int off = 32; off >= 1; off >>= 1) {
+      const unsigned long long o = __shfl_xor(best, off);
+      best = o > best ? o : best;
+    }
+    if ((threadIdx.x & 63) == 0) wbest[threadIdx.x >> 6] = best;
+    __syncthreads();
   }
-  __shared__ unsigned long long wbest[LCF_BLOCK / 64];
-  if ((threadIdx.x & 63) == 0) wbest[threadIdx.x >> 6] = best;
-  __syncthreads();
   if (threadIdx.x == 0) {
-    for (int wv = 1; wv < LCF_BLOCK / 64; ++wv) best = wbest[wv] > best ? wbest[wv] : best;
-    if (best) atomicMax(&keys[blockIdx.y], best);
+    if (l1 != 0 && l2 != 0) {
+      for (int wv = 1; wv < LCF_BLOCK / 64; ++wv) best = wbest[wv] > best ? wbest[wv] : best;
+      if (best) atomicMax(&keys[blockIdx.y], best);
+    }
   }
-}
-
-__global__ void lcf_finish_kernel(const DevJob* __restrict__ jobs, int njobs,
-                                  DevResult* __restrict__ results,
-                                  const unsigned long long* __restrict__ keys) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= njobs) return;
-  DevResult* res = &results[jobs[t].out_idx];
-  const unsigned long long key = keys[t];
-  res->status = 0;
-  if (key == 0) { res->v[0] = 0; res->v[1] = 0; res->v[2] = 0; return; }
-  res->v[0] = (int32_t)(key >> 44);
-  res->v[1] = (int32_t)(0x0FFFFFFFu - (uint32_t)((key >> 16) & 0x0FFFFFFFu));
-  res->v[2] = (int32_t)(0xFFFFu - (uint32_t)(key & 0xFFFFu));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1492,8 +1671,34 @@ void launch_lcf(const DevJob* jobs, int njobs, uint32_t max_chunks, uint32_t max
   hipLaunchKernelGGL(lcf_kernel, dim3(gx, njobs), dim3(LCF_BLOCK), lds, st, jobs, njobs, keys);
 }
 
-void launch_lcf_finish(const DevJob* jobs, int njobs, DevResult* res,
-                       const unsigned long long* keys, hipStream_t st) {
-  if (njobs <= 0) return;
-  hipLaunchKernelGGL(lcf_finish_kernel, dim3((njobs + 255) / 256), dim3(256), 0, st, jobs, njobs, res, keys);
+constexpr size_t DP_BATCH_MAX_LDS = 64 * 1024;
+
+size_t dp_batch_lds_bytes(bool wave_jobs, int bc_count, uint32_t bc_max_rows, int ac_count) {
+  size_t lds = 16;
+  if (wave_jobs) lds = std::max(lds, WAVE_JOBS_LDS);
+  if (ac_count > 0) lds = std::max(lds, AFFIX_COOP_LDS);
+  if (bc_count > 0) lds = std::max(lds, (2 * (COOP_W - 1) * 128 + 4 * ((size_t)bc_max_rows + 1)) * sizeof(uint32_t));
+  return lds;
+}
+
+bool launch_dp_batch(const DevJob* jobs, int n_segs, const int* family, const int* start, const int* count,
+                     int bc_start, int bc_count, uint32_t bc_max_rows, int ac_start, int ac_count,
+                     DevResult* res, uint8_t* ws, uint8_t* strs, hipStream_t st) {
+  BatchDesc d;
+  d.segs.n = 0;
+  int total = 0;
+  for (int k = 0; k < n_segs && d.segs.n < 6; ++k) {
+    if (count[k] <= 0) continue;
+    d.segs.family[d.segs.n] = family[k]; d.segs.start[d.segs.n] = start[k]; d.segs.count[d.segs.n] = count[k]; ++d.segs.n;
+    total += count[k];
+  }
+  d.wave_blocks = (total + 3) / 4;
+  d.bc_start = bc_start; d.bc_count = bc_count > 0 ? bc_count : 0;
+  d.ac_start = ac_start; d.ac_count = ac_count > 0 ? ac_count : 0;
+  const int blocks = d.bc_count + d.ac_count + d.wave_blocks;
+  if (blocks == 0) return true;
+  const size_t lds = dp_batch_lds_bytes(total > 0, d.bc_count, bc_max_rows, d.ac_count);
+  if (lds > DP_BATCH_MAX_LDS) return false;
+  hipLaunchKernelGGL(dp_batch_kernel, dim3(blocks), dim3(512), lds, st, jobs, d, res, ws, strs);
+  return true;
 }

@@ -33,10 +33,15 @@ void launch_gap(const DevJob* jobs, int njobs, int n_big, DevResult* res, uint8_
 void launch_gap_slow(const DevJob* jobs, int njobs, DevResult* res, uint8_t* ws, uint8_t* strs, hipStream_t st);   // beyond 2048 rows
 void launch_wave_jobs(const DevJob* jobs, int n_segs, const int* family, const int* start, const int* count,
                       DevResult* res, uint8_t* ws, uint8_t* strs, hipStream_t st);   // every wave-per-job family in one launch
+// one launch for the one-job-per-workgroup sweeps and the wave-per-job families of a batch; returns
+// false (nothing launched) when the largest BORDERS pattern needs more LDS than a workgroup may share
+bool launch_dp_batch(const DevJob* jobs, int n_segs, const int* family, const int* start, const int* count,
+                     int bc_start, int bc_count, uint32_t bc_max_rows, int ac_start, int ac_count,
+                     DevResult* res, uint8_t* ws, uint8_t* strs, hipStream_t st);
+size_t dp_batch_lds_bytes(bool wave_jobs, int bc_count, uint32_t bc_max_rows, int ac_count);
+// keys: one zeroed entry per job, (length << 44) | (2^28-1 - occ1) << 16 | (2^16-1 - occ2) of the best run; 0: none
 void launch_lcf(const DevJob* jobs, int njobs, uint32_t max_chunks, uint32_t max_l2,
                 unsigned long long* keys, hipStream_t st);
-void launch_lcf_finish(const DevJob* jobs, int njobs, DevResult* res,
-                       const unsigned long long* keys, hipStream_t st);
 
 // bytes of one traceback entry (all rows of one lane in one column)
 // row class of jobs with more than 4096 rows: run by the R = 64 kernels in strips of 4096 rows

@@ -23,6 +23,7 @@
 #define _GNU_SOURCE
 #include <malloc.h>
 #include <pthread.h>
+#include <sys/prctl.h>
 #include <sched.h>
 #include <dirent.h>
 #include <time.h>
@@ -467,6 +468,9 @@ static void kstat_add(ef_sched_stats* st, const ef_kernel_stat* k);
 /* service thread: merge everything posted, run it as one plan, publish the results */
 static void* service_main(void* arg) {
   pthread_setname_np(pthread_self(), "ef-gpu-service");
+  /* the library waits for a batch in short sleeps (PGPU_WAIT, microseconds): with the default timer
+   * slack of 50 us a 20 us sleep takes 70 */
+  prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0);
   service_thread* me = (service_thread*)arg;
   service* sv = me->sv;
   shared* sh = sv->sh;

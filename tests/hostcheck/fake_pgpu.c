@@ -239,6 +239,23 @@ int pgpu_dp_plan_create(pgpu_ctx* ctx, const pgpu_index* idx, const pgpu_dp_job*
   p->jobs = (pgpu_dp_job*)malloc((n + 1) * sizeof(pgpu_dp_job)); memcpy(p->jobs, jobs, n * sizeof(pgpu_dp_job));
   p->n = n; p->arena = (char*)calloc(alen + 8, 1); memcpy(p->arena, arena, alen); p->idx = idx;
   for (size_t i = 0; i < n; ++i) if (jobs[i].kind <= PGPU_DP_GAP) p->strs_bytes += 2 * ((size_t)jobs[i].a_len + jobs[i].b_len + 1);
+  if (getenv("PINTRON_FAKE_STATS")) {    /* one line per batch and kind: jobs, longest sweep (rows + columns) and its shape */
+    static pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
+    pthread_mutex_lock(&mu);
+    static FILE* f; if (!f) f = fopen(getenv("PINTRON_FAKE_STATS"), "w");
+    for (uint32_t k = 0; k < 7; ++k) {
+      size_t cnt = 0, best = 0, br = 0, bc = 0, big = 0;
+      for (size_t i = 0; i < n; ++i) if (jobs[i].kind == k) {
+        size_t r = jobs[i].a_len, c = jobs[i].b_len;
+        if (k == PGPU_DP_BORDERS) c = r + jobs[i].p2 < c ? r + jobs[i].p2 : c;
+        if (k == PGPU_DP_ED || k == PGPU_DP_KBAND) { if (r > c) { size_t t = r; r = c; c = t; } }
+        ++cnt; if (r > 64) ++big;
+        if (r + c >= best) { best = r + c; br = r; bc = c; }
+      }
+      if (cnt) fprintf(f, "%u %zu %zu %zu %zu %zu\n", k, cnt, big, best, br, bc);
+    }
+    pthread_mutex_unlock(&mu);
+  }
   *out = p; return PGPU_OK;
 }
 /* PINTRON_FAKE_CACHE=1 (profiling aid for tests/hostcheck/sched_profile): answers are remembered by
