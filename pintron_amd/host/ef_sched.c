@@ -132,6 +132,15 @@ typedef struct fiber {
 
 static const char FIBER_SENTINEL[16] = "pintron-fibre-s";
 
+static inline void fiber_prefetch(const fiber* f) {
+#if defined(__x86_64__) && !defined(EF_USE_UCONTEXT)
+  const char* sp = (const char*)f->ctx.sp;
+  for (int k = 0; k < 12; ++k) __builtin_prefetch(sp + 64 * k, 0, 3);
+#endif
+  __builtin_prefetch(f->ress, 0, 3);
+  __builtin_prefetch(f->reqs, 0, 3);
+}
+
 /* Fibre stacks are their own mappings with an inaccessible page below the lowest address: a stack
  * that overflows (the embedding enumeration recurses as deep as the MEG is long) faults on the
  * guard page instead of writing over a neighbouring heap block.  When the mapping cannot be had
@@ -622,6 +631,7 @@ static void* worker_main(void* arg) {
   }
   bool more = true;
   int cursor = 0;
+  const bool prefetch_on = !getenv("PINTRON_NO_FIBER_PREFETCH");
   while (!sh->failed) {
     /* next lane: the first one (round robin) that is not waiting for the GPU -- nothing posted, or
      * its batch is back; when every lane is in flight, sleep on the one posted longest ago */
@@ -648,6 +658,10 @@ static void* worker_main(void* arg) {
       t0 = now_s();
       for (size_t i = 0; i < ln->n_fibers; ++i) {
         fiber* f = ln->fibers[i];
+        /* a thousand other fibres ran since this one stopped: what it resumes on has left the
+         * caches.  While fibre i runs, the top of the stack of the one after the next (the frames of
+         * the DP call it returns through) and its answers are fetched. */
+        if (prefetch_on && i + 2 < ln->n_fibers) fiber_prefetch(ln->fibers[i + 2]);
         if (f->state == F_RUNNABLE) { if (EF_TSAN) tsan_to(f->tsan); ctx_switch(&w->sched, &f->ctx); }
       }
       size_t keep = 0;
