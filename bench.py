@@ -91,7 +91,7 @@ def rocprof_symbol(group_name):
 def pmc_traffic(group_name):
     """HBM bytes per launch of that kernel from the committed PMC passes (tools/pmc_traffic.sh:
     (2 x FETCH_SIZE + WRITE_SIZE) x 1024, separate --pmc runs), or None."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
     if not os.path.exists(path):
         return None
     sym = rocprof_symbol(group_name)

@@ -838,7 +838,34 @@ struct ef_session {
   double pre_kernel_ms[6], pre_meg_ms, pre_t0, pre_wall;
   size_t nthreads;
   double load_s, index_s;
+  /* the fibres of the first step (structure + guarded stack) are made while the GPU runtime comes up */
+  pthread_t pool_thread[2]; int n_pool_threads;
+  struct pool_job { shared* sh; size_t count; } pool_job[2];
 };
+
+/* Mapping a stack and protecting its guard page are two system calls that take the address-space
+ * lock: sixteen workers making a thousand fibres each at the start of the first step queue up
+ * behind each other (measured: 0.2 s single-threaded for 16 384 stacks, 0.4 s of WALL with eight
+ * threads contending).  Two threads make them here, beside the runtime start-up, touch the pages
+ * a fibre starts on and leave them in the shared pool the workers draw from. */
+static void* pool_builder_main(void* arg) {
+  pthread_setname_np(pthread_self(), "ef-fibre-pool");
+  struct pool_job* job = (struct pool_job*)arg;
+  shared* sh = job->sh;
+  for (size_t i = 0; i < job->count && !sh->failed; ++i) {
+    fiber* f = (fiber*)calloc(1, sizeof(fiber));
+    if (!f) break;
+    f->stack = stack_alloc(sh->stack_size, &f->guarded);
+    if (!f->stack) { free(f); break; }
+    memcpy(f->stack, FIBER_SENTINEL, sizeof FIBER_SENTINEL);
+    ((volatile char*)f->stack)[sh->stack_size - 64] = 0;
+    ((volatile char*)f->stack)[sh->stack_size - 4096 - 64] = 0;
+    pthread_mutex_lock(&sh->mu);
+    f->pool_next = sh->fiber_pool; sh->fiber_pool = f;
+    pthread_mutex_unlock(&sh->mu);
+  }
+  return NULL;
+}
 
 /* bringing up the HIP runtime takes a few tenths of a second and the index a tenth: both run
  * beside the parsing and preparation of the ESTs (the genomic sequence is loaded first) */
@@ -889,6 +916,17 @@ ef_session* ef_session_open(int argc, char** argv) {
   load_rc = ef_load_ests(&s->in);
   ef_classify_init();
   const double t_loaded = now_s();
+  if (load_rc == 0 && !getenv("PINTRON_NO_FIBER_POOL")) {
+    s->sh.stack_size = env_size("PINTRON_FIBER_STACK_KB", 256) * 1024;
+    size_t want = env_size("PINTRON_THREADS", host_core_share()) * env_size("PINTRON_FIBERS", 1024);
+    if (want > s->in.n) want = s->in.n;                 /* never more fibres than sequences */
+    if (want >= 64) {
+      for (int t = 0; t < 2; ++t) {
+        s->pool_job[t].sh = &s->sh; s->pool_job[t].count = want / 2;
+        if (pthread_create(&s->pool_thread[s->n_pool_threads], NULL, pool_builder_main, &s->pool_job[t]) == 0) ++s->n_pool_threads;
+      }
+    }
+  }
   if (booting) pthread_join(boot_thread, NULL); else gpu_boot_main(&boot);
   if (boot.rc == PGPU_OK) { s->ctx0 = boot.ctx; s->sh.idx = boot.idx_rc == PGPU_OK ? boot.idx : NULL; }
   if (load_rc != 0) { ef_session_close(s); return NULL; }
@@ -933,7 +971,7 @@ ef_session* ef_session_open(int argc, char** argv) {
     }
   }
   sh->svc.n_threads = (int)env_size("PINTRON_SERVICES", 3);
-  sh->svc.coalesce_us = getenv("PINTRON_COALESCE_US") ? atol(getenv("PINTRON_COALESCE_US")) : 0;
+  sh->svc.coalesce_us = getenv("PINTRON_COALESCE_US") ? atol(getenv("PINTRON_COALESCE_US")) : 50;
   if (sh->svc.n_threads > MAX_SERVICES) sh->svc.n_threads = MAX_SERVICES;
   for (int k = 0; k < sh->svc.n_threads; ++k) {
     if (pgpu_init(ef_gpu_device_from_env(), &sh->svc.threads[k].ctx) != PGPU_OK) { ef_session_close(s); return NULL; }
@@ -1181,6 +1219,8 @@ struct pgpu_ctx* ef_session_context(ef_session* s) { return s->ctx0; }
 void ef_session_close(ef_session* s) {
   if (!s) return;
   shared* sh = &s->sh;
+  for (int t = 0; t < s->n_pool_threads; ++t) pthread_join(s->pool_thread[t], NULL);
+  s->n_pool_threads = 0;
   free_unit_buffers(sh, true);
   while (sh->fiber_pool) {
     fiber* nx = sh->fiber_pool->pool_next;
