@@ -869,7 +869,17 @@ static void* pool_builder_main(void* arg) {
 
 /* bringing up the HIP runtime takes a few tenths of a second and the index a tenth: both run
  * beside the parsing and preparation of the ESTs (the genomic sequence is loaded first) */
-typedef struct { pgpu_ctx* ctx; int rc; const char* gen; size_t gen_len; pgpu_index* idx; int idx_rc; } gpu_boot;
+typedef struct {
+  pgpu_ctx* ctx; int rc; const char* gen; size_t gen_len; pgpu_index* idx; int idx_rc;
+  int n_svc; pgpu_ctx* svc[MAX_SERVICES]; int svc_rc;     /* the contexts of the service threads come up here too */
+} gpu_boot;
+static void boot_service_contexts(gpu_boot* b) {
+  b->svc_rc = PGPU_OK;
+  for (int k = 0; k < b->n_svc && b->svc_rc == PGPU_OK; ++k) {
+    b->svc_rc = pgpu_init(ef_gpu_device_from_env(), &b->svc[k]);
+    if (b->svc_rc == PGPU_OK && env_flag("PINTRON_KERNEL_TIMING")) pgpu_set_timing(b->svc[k], 1);
+  }
+}
 static void* gpu_boot_main(void* arg) {
   pthread_setname_np(pthread_self(), "ef-gpu-boot");
   gpu_boot* b = (gpu_boot*)arg;
@@ -885,11 +895,12 @@ static void* gpu_boot_main(void* arg) {
       for (size_t i = 0; i < b->gen_len; ++i) { h ^= (unsigned char)b->gen[i]; h *= 1099511628211ull; }
       snprintf(path, sizeof path, "%s/pintron-index-%016llx-%zu.bin", cache, h, b->gen_len);
       b->idx_rc = pgpu_index_load(b->ctx, path, b->gen, b->gen_len, &b->idx);
-      if (b->idx_rc == PGPU_OK) return NULL;
+      if (b->idx_rc == PGPU_OK) { boot_service_contexts(b); return NULL; }
     }
     b->idx_rc = pgpu_index_build(b->ctx, b->gen, b->gen_len, &b->idx);
     if (b->idx_rc == PGPU_OK && cache && cache[0] && pgpu_index_save(b->ctx, b->idx, b->gen, path) != PGPU_OK)
       fprintf(stderr, "* WARN the index could not be saved to %s\n", path);
+    if (b->idx_rc == PGPU_OK) boot_service_contexts(b);
   }
   return NULL;
 }
@@ -910,7 +921,12 @@ ef_session* ef_session_open(int argc, char** argv) {
   pthread_cond_init(&s->sh.svc.finished, NULL);
   int load_rc = ef_load_genomic(argc, argv, &s->in);
   if (load_rc != 0) { ef_session_close(s); return NULL; }
-  gpu_boot boot = { NULL, PGPU_EDEVICE, s->in.gen->seq, strlen(s->in.gen->seq), NULL, PGPU_EDEVICE };
+  gpu_boot boot;
+  memset(&boot, 0, sizeof boot);
+  boot.rc = boot.idx_rc = boot.svc_rc = PGPU_EDEVICE;
+  boot.gen = s->in.gen->seq; boot.gen_len = strlen(s->in.gen->seq);
+  boot.n_svc = (int)env_size("PINTRON_SERVICES", 3);
+  if (boot.n_svc > MAX_SERVICES) boot.n_svc = MAX_SERVICES;
   pthread_t boot_thread;
   const bool booting = pthread_create(&boot_thread, NULL, gpu_boot_main, &boot) == 0;
   load_rc = ef_load_ests(&s->in);
@@ -928,7 +944,9 @@ ef_session* ef_session_open(int argc, char** argv) {
     }
   }
   if (booting) pthread_join(boot_thread, NULL); else gpu_boot_main(&boot);
+  const double t_booted = now_s();
   if (boot.rc == PGPU_OK) { s->ctx0 = boot.ctx; s->sh.idx = boot.idx_rc == PGPU_OK ? boot.idx : NULL; }
+  for (int k = 0; k < boot.n_svc; ++k) s->sh.svc.threads[k].ctx = boot.svc[k];     /* (closed with the session) */
   if (load_rc != 0) { ef_session_close(s); return NULL; }
   if (boot.rc != PGPU_OK) {
     fprintf(stderr, "* FATAL no usable MI355X (gfx950) device / libpintron_gpu.so: est-fact has no CPU fallback\n");
@@ -956,27 +974,16 @@ ef_session* ef_session_open(int argc, char** argv) {
       const size_t u = sh->n_units * (size_t)cidx / (size_t)sh->n_pre;
       sh->pre_lo[cidx] = u < sh->n_units ? sh->units[u].first : in->n;
     }
-    for (int cidx = 0; cidx < sh->n_pre; ++cidx) {
-      const size_t lo = sh->pre_lo[cidx], hi = sh->pre_lo[cidx + 1];
-      size_t total = 0;
-      for (size_t k = lo; k < hi; ++k) total += strlen(in->list[k]->seq);
-      char* blob = (char*)malloc(total + 1);
-      uint64_t* off = (uint64_t*)malloc((hi - lo + 1) * sizeof(uint64_t));
-      size_t pos = 0;
-      for (size_t k = lo; k < hi; ++k) { const size_t m = strlen(in->list[k]->seq); off[k - lo] = pos; memcpy(blob + pos, in->list[k]->seq, m); pos += m; }
-      off[hi - lo] = pos;
-      const int prc = pgpu_pairing_plan_create(s->ctx0, sh->idx, blob, off, hi - lo, &s->pplan[cidx]);
-      free(blob); free(off);
-      if (prc != PGPU_OK) { fprintf(stderr, "* FATAL pairing plan: %s\n", pgpu_last_error(s->ctx0)); ef_session_close(s); return NULL; }
-    }
   }
-  sh->svc.n_threads = (int)env_size("PINTRON_SERVICES", 3);
+  sh->svc.n_threads = boot.n_svc;
   sh->svc.coalesce_us = getenv("PINTRON_COALESCE_US") ? atol(getenv("PINTRON_COALESCE_US")) : 50;
-  if (sh->svc.n_threads > MAX_SERVICES) sh->svc.n_threads = MAX_SERVICES;
-  for (int k = 0; k < sh->svc.n_threads; ++k) {
-    if (pgpu_init(ef_gpu_device_from_env(), &sh->svc.threads[k].ctx) != PGPU_OK) { ef_session_close(s); return NULL; }
-    if (env_flag("PINTRON_KERNEL_TIMING")) pgpu_set_timing(sh->svc.threads[k].ctx, 1);
+  if (boot.svc_rc != PGPU_OK) {
+    fprintf(stderr, "* FATAL the GPU contexts of the service threads could not be created\n");
+    ef_session_close(s); return NULL;
   }
+  if (getenv("PINTRON_VERBOSE"))
+    fprintf(stderr, "* open: load %.3fs, then GPU runtime + index + service contexts still %.3fs, rest %.3fs\n",
+            t_loaded - t_start, t_booted - t_loaded, now_s() - t_booted);
   /* the workers hide the GPU latency with lanes, not with oversubscription */
   s->nthreads = env_size("PINTRON_THREADS", host_core_share());
   if (s->nthreads > sh->n_units) s->nthreads = sh->n_units ? sh->n_units : 1;
@@ -1012,13 +1019,34 @@ static void free_unit_buffers(shared* sh, bool release) {
  * fibres (MEG, embeddings, DP batches, refinement) on all worker threads */
 /* prefetch thread: the pairings of chunk after chunk (one resident batch each); every finished
  * chunk releases its units to the workers */
+/* the prepared sequences (both strands) of chunk c, concatenated, as a resident pairing plan */
+static int make_pattern_plan(ef_session* s, int c) {
+  shared* sh = &s->sh;
+  ef_inputs* in = &s->in;
+  const size_t lo = sh->pre_lo[c], hi = sh->pre_lo[c + 1];
+  size_t total = 0;
+  for (size_t k = lo; k < hi; ++k) total += strlen(in->list[k]->seq);
+  char* blob = (char*)malloc(total + 1);
+  uint64_t* off = (uint64_t*)malloc((hi - lo + 1) * sizeof(uint64_t));
+  if (!blob || !off) { free(blob); free(off); return PGPU_ENOMEM; }
+  size_t pos = 0;
+  for (size_t k = lo; k < hi; ++k) { const size_t m = strlen(in->list[k]->seq); off[k - lo] = pos; memcpy(blob + pos, in->list[k]->seq, m); pos += m; }
+  off[hi - lo] = pos;
+  const int prc = pgpu_pairing_plan_create(s->ctx0, sh->idx, blob, off, hi - lo, &s->pplan[c]);
+  free(blob); free(off);
+  return prc;
+}
+
 static void* prefetch_main(void* arg) {
   pthread_setname_np(pthread_self(), "ef-pairings");
   ef_session* s = (ef_session*)arg;
   shared* sh = &s->sh;
   pgpu_pairing_params prm = { s->in.cfg.min_factor_len, 0, s->in.cfg.min_string_depth_rate };
   for (int c = 0; c < sh->n_pre; ++c) {
-    int prc = pgpu_pairing_plan_run(s->ctx0, s->pplan[c], &prm);
+    /* first step: the chunk's sequences go to the device here, chunk after chunk beside the workers
+     * that already factorize the chunks before (they stay resident for the steps that follow) */
+    int prc = s->pplan[c] ? PGPU_OK : make_pattern_plan(s, c);
+    if (prc == PGPU_OK) prc = pgpu_pairing_plan_run(s->ctx0, s->pplan[c], &prm);
     bool have_meg = false;
     if (prc == PGPU_OK && sh->use_meg) {
       /* the graphs are built where the pairings lie; only the finished records cross PCIe */
