@@ -255,7 +255,8 @@ size_t pgpu_dp_plan_string_bytes(const pgpu_dp_plan* plan);
 int pgpu_dp_plan_fetch(pgpu_ctx* ctx, pgpu_dp_plan* plan, pgpu_dp_result* results,
                        char* strings, size_t strings_cap);
 /* copies the result table (n_jobs * sizeof(pgpu_dp_result), caller order) into DEVICE memory the
- * caller owns (e.g. a buffer handed to an RCCL gather), stream-ordered after the plan's kernels;
+ * caller owns (e.g. a buffer handed to an RCCL gather); waits for the plan first (the table is
+ * completed on the host: the LCF answers are decoded there from the keys the kernel leaves);
  * returns after the copy has completed */
 int pgpu_dp_plan_results_to_device(pgpu_ctx* ctx, pgpu_dp_plan* plan, void* device_dst, size_t cap);
 int pgpu_dp_plan_destroy(pgpu_ctx* ctx, pgpu_dp_plan* plan);

@@ -1250,6 +1250,16 @@ void ef_session_close(ef_session* s) {
   for (int t = 0; t < s->n_pool_threads; ++t) pthread_join(s->pool_thread[t], NULL);
   s->n_pool_threads = 0;
   free_unit_buffers(sh, true);
+  if (getenv("PINTRON_STACK_STATS")) {      /* how deep did the fibres' stacks get? (first byte written above the sentinel) */
+    size_t n = 0, sum = 0, mx = 0;
+    for (fiber* f = sh->fiber_pool; f; f = f->pool_next) {
+      size_t lo = sizeof FIBER_SENTINEL;
+      while (lo < sh->stack_size && f->stack[lo] == 0) lo += 64;
+      const size_t used = lo < sh->stack_size ? sh->stack_size - lo : 0;
+      ++n; sum += used; if (used > mx) mx = used;
+    }
+    fprintf(stderr, "* fibre stacks: %zu fibres, %zu B used on average, %zu B at most (of %zu)\n", n, n ? sum / n : 0, mx, sh->stack_size);
+  }
   while (sh->fiber_pool) {
     fiber* nx = sh->fiber_pool->pool_next;
     for (int k = 0; k < EF_N_OUT; ++k) free(sh->fiber_pool->out[k].mem);

@@ -246,3 +246,42 @@ def test_kband_band_on_lanes(gpu_ctx, O):
     cases.append(D.Case(D.KBAND, a[7:], a, p0=7))
     cases.append(D.Case(D.KBAND, a, D.rand_seq(rng, 400), p0=20))   # unrelated: far above the bound
     run_and_check(gpu_ctx, O, cases)
+
+
+def test_results_to_device_and_launch_modes(gpu_ctx, O):
+    """pgpu_dp_plan_results_to_device hands the COMPLETE table to device memory (the LCF answers are
+    decoded on the host from the kernel's keys); and the three launch modes of the library (PGPU_MERGED
+    = 2: one batch launch + LCF, 1: wave-per-job launch + sweeps, 0: a launch per family) give the same
+    answers for a batch that holds every family, one-job-per-workgroup sweeps included."""
+    import ctypes as C
+    import os
+    import torch
+    import pintron_amd.capi as capi
+    rng = random.Random(31)
+    cases = D.random_cases(rng, n_per_kind=12, max_len=200)
+    for rows in (70, 130, 300, 520):                      # BORDERS / AFFIX above 64 rows: the cooperative sweeps
+        a = bytes(rng.choice(b"ACGT") for _ in range(rows))
+        b = bytes(c if rng.random() > 0.05 else rng.choice(b"ACGT") for c in a)
+        cases.append(D.Case(D.AFFIX, a, b))
+        cases.append(D.Case(D.BORDERS, a, b + bytes(rng.choice(b"ACGT") for _ in range(500)), p0=1, p1=rows - 1, p2=rows // 10, b_tail=b"GT"))
+    jl = capi.JobList()
+    for c in cases:
+        c.add_to(jl)
+    p = capi.Plan(gpu_ctx, jl)
+    p.launch()
+    dev = torch.empty(len(cases) * C.sizeof(capi.DpResult), dtype=torch.uint8, device="cuda:0")
+    p.results_to_device(dev.data_ptr(), dev.numel())
+    res, strs = p.fetch()
+    p.close()
+    assert bytes(dev.cpu().numpy().tobytes()) == bytes(res)[:dev.numel()]
+    base = [capi.decode(c.kind, r, strs) for c, r in zip(cases, res)]
+    for c, got in zip(cases, base):
+        assert D.check_case(c, got, O), (c, got)
+    for mode in ("1", "0"):
+        os.environ["PGPU_MERGED"] = mode
+        try:
+            with capi.Context(0) as ctx2:
+                out = capi.run_jobs(ctx2, jl)
+        finally:
+            del os.environ["PGPU_MERGED"]
+        assert out == base, "PGPU_MERGED=%s differs" % mode
