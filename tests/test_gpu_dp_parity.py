@@ -255,7 +255,6 @@ def test_results_to_device_and_launch_modes(gpu_ctx, O):
     answers for a batch that holds every family, one-job-per-workgroup sweeps included."""
     import ctypes as C
     import os
-    import torch
     import pintron_amd.capi as capi
     rng = random.Random(31)
     cases = D.random_cases(rng, n_per_kind=12, max_len=200)
@@ -269,11 +268,18 @@ def test_results_to_device_and_launch_modes(gpu_ctx, O):
         c.add_to(jl)
     p = capi.Plan(gpu_ctx, jl)
     p.launch()
-    dev = torch.empty(len(cases) * C.sizeof(capi.DpResult), dtype=torch.uint8, device="cuda:0")
-    p.results_to_device(dev.data_ptr(), dev.numel())
+    # device memory from the HIP runtime the library itself runs on (torch brings its own copy of it)
+    hip = C.CDLL("libamdhip64.so")
+    nbytes = len(cases) * C.sizeof(capi.DpResult)
+    dev = C.c_void_p()
+    assert hip.hipMalloc(C.byref(dev), C.c_size_t(nbytes)) == 0
+    p.results_to_device(dev.value, nbytes)
     res, strs = p.fetch()
     p.close()
-    assert bytes(dev.cpu().numpy().tobytes()) == bytes(res)[:dev.numel()]
+    back = C.create_string_buffer(nbytes)
+    assert hip.hipMemcpy(back, dev, C.c_size_t(nbytes), 2) == 0          # hipMemcpyDeviceToHost
+    hip.hipFree(dev)
+    assert back.raw == bytes(res)[:nbytes]
     base = [capi.decode(c.kind, r, strs) for c, r in zip(cases, res)]
     for c, got in zip(cases, base):
         assert D.check_case(c, got, O), (c, got)
