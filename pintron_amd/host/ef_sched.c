@@ -24,6 +24,7 @@
 #include <malloc.h>
 #include <pthread.h>
 #include <sys/prctl.h>
+#include <sys/resource.h>
 #include <sched.h>
 #include <dirent.h>
 #include <time.h>
@@ -1091,9 +1092,19 @@ static void* prefetch_main(void* arg) {
   return NULL;
 }
 
+typedef struct { double wall, user, sys; long minflt; } run_mark;
+static run_mark run_mark_now(void) {
+  struct rusage ru;
+  getrusage(RUSAGE_SELF, &ru);
+  run_mark m = { now_s(), ru.ru_utime.tv_sec + 1e-6 * ru.ru_utime.tv_usec, ru.ru_stime.tv_sec + 1e-6 * ru.ru_stime.tv_usec, ru.ru_minflt };
+  return m;
+}
+
 int ef_session_step(ef_session* s, ef_sched_stats* stats_out) {
   shared* sh = &s->sh;
   const double t0 = now_s();
+  const bool step_rusage = getenv("PINTRON_STEP_RUSAGE") != NULL;
+  run_mark ru0; if (step_rusage) ru0 = run_mark_now();
   free_unit_buffers(sh, false);
   for (int c = 0; c < PRE_CHUNKS; ++c) { free(sh->pre_tri[c]); free(sh->pre_first[c]); sh->pre_tri[c] = NULL; sh->pre_first[c] = NULL; }
   sh->next_unit = 0; sh->failed = 0; sh->ready_entries = 0;
@@ -1179,6 +1190,11 @@ int ef_session_step(ef_session* s, ef_sched_stats* stats_out) {
   for (size_t u = 0; u < sh->n_units; ++u) if (sh->units[u].len[1]) ++st.aligned;
   if (stats_out) *stats_out = st;
   free(ws); free(th);
+  if (step_rusage) {
+    const run_mark ru1 = run_mark_now();
+    fprintf(stderr, "* step: %.3fs wall, user %.2fs sys %.2fs (all threads of the process), %ld page faults\n",
+            ru1.wall - ru0.wall, ru1.user - ru0.user, ru1.sys - ru0.sys, ru1.minflt - ru0.minflt);
+  }
   return sh->failed ? 1 : 0;
 }
 
@@ -1286,22 +1302,26 @@ void ef_session_close(ef_session* s) {
 int ef_leave_without_cleanup = 0;
 
 int ef_run_batched_stats(int argc, char** argv, ef_sched_stats* stats_out) {
-  const double t0 = now_s();
+  const run_mark m0 = run_mark_now();
   ef_session* s = ef_session_open(argc, argv);
   if (!s) return 1;
   ef_sched_stats st;
-  const double t1 = now_s();
+  const run_mark m1 = run_mark_now();
   int rc = ef_session_step(s, &st);
-  const double t2 = now_s();
+  const run_mark m2 = run_mark_now();
   if (rc == 0) rc = ef_session_write_outputs(s);
-  const double t3 = now_s();
+  const run_mark m3 = run_mark_now();
   if (stats_out) *stats_out = st;
   /* The files are on disk and every stream has been waited for.  A process that is about to
    * exit (ef_leave_without_cleanup, set by the est-fact program) does not take the session apart
    * (200 000 sequences, fibre stacks, device pools: 0.3 s): the caller ends it with _exit. */
   if (!ef_leave_without_cleanup) ef_session_close(s);
-  if (getenv("PINTRON_VERBOSE"))
-    fprintf(stderr, "* run: open %.3fs step %.3fs write %.3fs close %.3fs\n", t1 - t0, t2 - t1, t3 - t2, now_s() - t3);
+  if (getenv("PINTRON_VERBOSE")) {
+    fprintf(stderr, "* run: open %.3fs step %.3fs write %.3fs close %.3fs\n", m1.wall - m0.wall, m2.wall - m1.wall, m3.wall - m2.wall, now_s() - m3.wall);
+    fprintf(stderr, "* cpu (all threads): open user %.2fs sys %.2fs, %ld page faults; step user %.2fs sys %.2fs, %ld page faults; write user %.2fs sys %.2fs\n",
+            m1.user - m0.user, m1.sys - m0.sys, m1.minflt - m0.minflt, m2.user - m1.user, m2.sys - m1.sys, m2.minflt - m1.minflt,
+            m3.user - m2.user, m3.sys - m2.sys);
+  }
   return rc;
 }
 
