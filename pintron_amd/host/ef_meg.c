@@ -29,7 +29,7 @@ static ef_list empty_position = { { &empty_position.sent, &empty_position.sent, 
 ef_meg* ef_meg_from_pairings(const ef_triple* tr, size_t n_tr, size_t m) {
   ef_meg* V = (ef_meg*)malloc(sizeof(ef_meg));
   V->n = m + 2;
-  V->rec = NULL;
+  V->rec = NULL; V->slab = false;
   /* one list per EST position, most of them empty: headers exist only for the positions that
    * hold a vertex (source, sink and the distinct p of the pairings) */
   V->v = (ef_list**)malloc(V->n * sizeof(ef_list*) + (n_tr + 2) * sizeof(ef_list));
@@ -61,32 +61,45 @@ ef_meg* ef_meg_from_record(const void* rec, size_t m) {
   const int32_t* vt = (const int32_t*)((const char*)rec + 16);
   const uint16_t* first = (const uint16_t*)((const char*)rec + 16 + 12 * (size_t)nv);
   const uint8_t* tgt = (const uint8_t*)rec + 16 + 12 * (size_t)nv + 2 * ((size_t)nv + 1);
-  ef_meg* V = (ef_meg*)malloc(sizeof(ef_meg));
-  V->n = m + 2;
-  V->rec = rec;
-  V->v = (ef_list**)malloc(V->n * sizeof(ef_list*) + (nv + 2) * sizeof(ef_list));
-  ef_list* heads = (ef_list*)(V->v + V->n);
-  for (size_t i = 0; i < V->n; ++i) V->v[i] = &empty_position;
-  V->act = (size_t*)malloc((nv + 2) * sizeof(size_t));
+  const size_t ne = first[nv], n = m + 2;
+  /* one block: [ef_meg][v: n pointers][act: nv][position headers: nv][vertices: nv][adjs + incs
+   * headers: 2 nv][nodes: nv (position lists) + ne (adjacency)] -- a few hundred bytes of structure
+   * for a dozen vertices instead of three pool cells per vertex and one per edge, and one free() */
+  const size_t bytes = sizeof(ef_meg) + n * sizeof(ef_list*) + nv * sizeof(size_t) + nv * sizeof(ef_list) +
+                       nv * sizeof(ef_pairing) + 2 * (size_t)nv * sizeof(ef_list) + ((size_t)nv + ne) * sizeof(ef_node);
+  char* blk = (char*)malloc(bytes + 8);
+  ef_meg* V = (ef_meg*)blk; blk += sizeof(ef_meg);
+  V->n = n; V->rec = rec; V->slab = true;
+  V->v = (ef_list**)blk; blk += n * sizeof(ef_list*);
+  V->act = (size_t*)blk; blk += nv * sizeof(size_t);
+  ef_list* heads = (ef_list*)blk; blk += nv * sizeof(ef_list);
+  ef_pairing* vx = (ef_pairing*)blk; blk += nv * sizeof(ef_pairing);
+  ef_list* lists = (ef_list*)blk; blk += 2 * (size_t)nv * sizeof(ef_list);
+  ef_node* node = (ef_node*)blk;
+  for (size_t i = 0; i < n; ++i) V->v[i] = &empty_position;
   V->n_act = 0;
-  ef_pairing* small[64];
-  ef_pairing** vx = nv <= 64 ? small : (ef_pairing**)malloc(nv * sizeof(ef_pairing*));
+#define SLAB_PUSH_BACK(l_, el_) do { ef_node* nd_ = node++; nd_->el = (el_); nd_->prev = (l_)->sent.prev; nd_->next = &(l_)->sent; \
+                                      (l_)->sent.prev->next = nd_; (l_)->sent.prev = nd_; ++(l_)->size; } while (0)
   size_t h = 0;
   for (uint32_t k = 0; k < nv; ++k) {
     const int p = vt[3 * k], t = vt[3 * k + 1], l = vt[3 * k + 2];
-    const size_t pos = p == EF_SOURCE_START ? 0 : (p == EF_SINK_START ? V->n - 1 : 1 + (size_t)p);
+    const size_t pos = p == EF_SOURCE_START ? 0 : (p == EF_SINK_START ? n - 1 : 1 + (size_t)p);
     if (V->v[pos] == &empty_position) { V->v[pos] = &heads[h++]; efl_init(V->v[pos]); V->act[V->n_act++] = pos; }
-    vx[k] = pairing_new(p, t, l);
-    efl_push_back(V->v[pos], vx[k]);
+    ef_pairing* x = &vx[k];
+    x->p = p; x->t = t; x->l = l; x->id = 0; x->visited = false; x->emb_memo = NULL;
+    x->adjs = &lists[2 * k]; x->incs = &lists[2 * k + 1];
+    efl_init(x->adjs); efl_init(x->incs);
+    SLAB_PUSH_BACK(V->v[pos], x);
   }
   for (uint32_t k = 0; k < nv; ++k)
-    for (uint32_t e = first[k]; e < first[k + 1]; ++e) efl_push_back(vx[k]->adjs, vx[tgt[e]]);
-  if (vx != small) free(vx);
+    for (uint32_t e = first[k]; e < first[k + 1]; ++e) SLAB_PUSH_BACK(vx[k].adjs, &vx[tgt[e]]);
+#undef SLAB_PUSH_BACK
   return V;
 }
 
 void ef_meg_free(ef_meg* V) {
   if (!V) return;
+  if (V->slab) { free(V); return; }
   EF_MEG_FOR_POS(V, i, 0, V->n) efl_clear(V->v[i], pairing_free);
   free(V->v); free(V->act);
   free(V);

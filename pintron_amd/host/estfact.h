@@ -116,6 +116,9 @@ typedef struct {
   /* the device-built record this graph was made from (its two texts are printed as they are),
    * NULL for a graph built on the host */
   const void* rec;
+  /* a graph made from a record is read-only and lives in ONE block (this structure first): position
+   * table, list headers, vertices and list nodes are carved from it and freed with it */
+  bool slab;
 } ef_meg;
 
 /* first index k with act[k] >= lo */
