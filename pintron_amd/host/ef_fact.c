@@ -72,26 +72,27 @@ uint32_t ef_compute_edit_distance(ef_backend* be, const char* a, size_t la, cons
 /* ---------------------------------------------------------------------------------------------- */
 /* embeddings (src/est-factorizations.c:597-917, 1362-1460)                                       */
 /* ---------------------------------------------------------------------------------------------- */
-/* embedding elements come from the per-thread cell pool like the list nodes that carry them */
-static ptl* ptl_new(int p, int t, int l) { ptl* x = (ptl*)ef_cell_get(); x->p = p; x->t = t; x->l = l; return x; }
-static void ptl_free(void* x) { ef_cell_put(x); }
-static void embedding_free(void* e) { efl_free((ef_list*)e, ptl_free); }
+/* An embedding is a short sequence of (p, t, l) that is only ever copied, extended at its head and read
+ * front to back: one block, e[0] = head (the reference keeps a linked list of heap records; here a
+ * copy is a memcpy and a walk touches one or two cache lines instead of two per element). */
+typedef struct { uint32_t n; ptl e[]; } emb;
+static emb* emb_new(uint32_t n) { emb* x = (emb*)malloc(sizeof(emb) + (size_t)n * sizeof(ptl)); x->n = n; return x; }
+static void embedding_free(void* e) { free(e); }
 
-static ef_list* embedding_copy(ef_list* e) {
-  ef_list* c = efl_new();
-  ef_iter it = efl_begin(e);
-  while (efi_has_next(&it)) { const ptl* x = (const ptl*)efi_next(&it); efl_push_back(c, ptl_new(x->p, x->t, x->l)); }
+static emb* embedding_copy(const emb* e) {
+  emb* c = emb_new(e->n);
+  memcpy(c->e, e->e, (size_t)e->n * sizeof(ptl));
   return c;
 }
 
 /* update_embedding (:765-917): the embedding extended by `node` at its head, or NULL */
-static ef_list* update_embedding(ef_list* embedding, const ef_pairing* node, const char* GEN,
-                                 const ef_config* cfg) {
-  const ptl* head = (const ptl*)efl_head(embedding);
+static emb* update_embedding(const emb* embedding, const ef_pairing* node, const char* GEN,
+                             const ef_config* cfg) {
+  const ptl* head = &embedding->e[0];
   if (head->p == EF_SINK_START) {
     if (node->p < 0) return NULL;
-    ef_list* e = efl_new();
-    efl_push_front(e, ptl_new(node->p, node->t, node->l));
+    emb* e = emb_new(1);
+    e->e[0].p = node->p; e->e[0].t = node->t; e->e[0].l = node->l;
     return e;
   }
   if (node->p < 0) return embedding_copy(embedding);
@@ -134,10 +135,10 @@ static ef_list* update_embedding(ef_list* embedding, const ef_pairing* node, con
     node_l = node->l - (node->p + node->l - best_cut);
   }
   if (!(gap_on_t <= fl || intron_on_t)) return NULL;
-  ef_list* c = embedding_copy(embedding);
-  ptl* hc = (ptl*)efl_head(c);
-  hc->p = head_p; hc->t = head_t; hc->l = head_l;
-  efl_push_front(c, ptl_new(node->p, node->t, node_l));
+  emb* c = emb_new(embedding->n + 1);               /* the new head, the old head trimmed, the rest as it was */
+  c->e[0].p = node->p; c->e[0].t = node->t; c->e[0].l = node_l;
+  c->e[1].p = head_p; c->e[1].t = head_t; c->e[1].l = head_l;
+  memcpy(c->e + 2, embedding->e + 1, (size_t)(embedding->n - 1) * sizeof(ptl));
   return c;
 }
 
@@ -149,36 +150,22 @@ static bool pair_inside(const ptl* inner, const ptl* outer) {
 }
 
 /* maximality_relation (:1362-1460): 2 = add is maximal, 1 = both, 0 = cmp is maximal */
-static int maximality_relation(ef_list* add, ef_list* cmp) {
-  ef_iter ia = efl_begin(add), ic = efl_begin(cmp);
-  if (efl_size(add) > efl_size(cmp)) {
+static int maximality_relation(const emb* add, const emb* cmp) {
+  if (add->n > cmp->n) {
     bool check = true;
-    while (efi_has_next(&ic) && check) {
-      const ptl* a = (const ptl*)efi_next(&ia); const ptl* c = (const ptl*)efi_next(&ic);
-      check = pair_inside(c, a);
-    }
+    for (uint32_t i = 0; i < cmp->n && check; ++i) check = pair_inside(&cmp->e[i], &add->e[i]);
     return check ? 2 : 1;
   }
-  if (efl_size(add) < efl_size(cmp)) {
+  if (add->n < cmp->n) {
     bool check = true;
-    while (efi_has_next(&ia) && check) {
-      const ptl* a = (const ptl*)efi_next(&ia); const ptl* c = (const ptl*)efi_next(&ic);
-      check = pair_inside(a, c);
-    }
+    for (uint32_t i = 0; i < add->n && check; ++i) check = pair_inside(&add->e[i], &cmp->e[i]);
     return check ? 0 : 1;
   }
   bool check = true;
-  while (efi_has_next(&ia) && check) {
-    const ptl* a = (const ptl*)efi_next(&ia); const ptl* c = (const ptl*)efi_next(&ic);
-    check = pair_inside(a, c);
-  }
+  for (uint32_t i = 0; i < add->n && check; ++i) check = pair_inside(&add->e[i], &cmp->e[i]);
   if (check) return 0;
-  ia = efl_begin(add); ic = efl_begin(cmp);
   check = true;
-  while (efi_has_next(&ia) && check) {
-    const ptl* a = (const ptl*)efi_next(&ia); const ptl* c = (const ptl*)efi_next(&ic);
-    check = pair_inside(c, a);
-  }
+  for (uint32_t i = 0; i < add->n && check; ++i) check = pair_inside(&cmp->e[i], &add->e[i]);
   return check ? 2 : 1;
 }
 
@@ -208,8 +195,8 @@ static ef_list* subtree_embeddings(ef_pairing* root, const ef_config* cfg, const
   ef_list* out = efl_new();
   root->visited = true;
   if (efl_empty(root->adjs)) {
-    ef_list* e = efl_new();
-    efl_push_front(e, ptl_new(root->p, root->t, root->l));
+    emb* e = emb_new(1);
+    e->e[0].p = root->p; e->e[0].t = root->t; e->e[0].l = root->l;
     efl_push_front(out, e);
   } else {
     ef_iter ai = efl_begin(root->adjs);
@@ -219,13 +206,13 @@ static ef_list* subtree_embeddings(ef_pairing* root, const ef_config* cfg, const
       if (!sub) { efl_free(out, embedding_free); return NULL; }
       ef_iter si = efl_begin(sub);
       while (efi_has_next(&si)) {
-        ef_list* add = update_embedding((ef_list*)efi_next(&si), root, GEN, cfg);
+        emb* add = update_embedding((const emb*)efi_next(&si), root, GEN, cfg);
         if (!add) continue;
         if (++wk->used > wk->limit) { embedding_free(add); efl_free(out, embedding_free); return NULL; }
         int is_max = 2;
         ef_iter ci = efl_begin(out);
         while (efi_has_next(&ci) && is_max >= 1) {
-          ef_list* cmp = (ef_list*)efi_next(&ci);
+          const emb* cmp = (const emb*)efi_next(&ci);
           is_max = maximality_relation(add, cmp);
           if (is_max == 2) efi_remove(&ci, embedding_free);
         }
@@ -243,12 +230,11 @@ static ef_list* factorizations_from_embeddings(ef_list* embeddings, const ef_con
   const int fl = 2 * (int)cfg->min_factor_len;
   ef_iter ei = efl_begin(embeddings);
   while (efi_has_next(&ei)) {
-    ef_list* emb = (ef_list*)efi_next(&ei);
+    const emb* em = (const emb*)efi_next(&ei);
     ef_list* fact = efl_new();
     ef_factor* last = NULL;
-    ef_iter pi = efl_begin(emb);
-    while (efi_has_next(&pi)) {
-      const ptl* x = (const ptl*)efi_next(&pi);
+    for (uint32_t q = 0; q < em->n; ++q) {
+      const ptl* x = &em->e[q];
       if (efl_empty(fact) || (x->t - last->GEN_end - 1) > fl) {
         last = factor_new(x->p, x->p + x->l - 1, x->t, x->t + x->l - 1);
         efl_push_back(fact, last);
