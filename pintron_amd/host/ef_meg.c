@@ -62,34 +62,39 @@ ef_meg* ef_meg_from_record(const void* rec, size_t m) {
   const uint16_t* first = (const uint16_t*)((const char*)rec + 16 + 12 * (size_t)nv);
   const uint8_t* tgt = (const uint8_t*)rec + 16 + 12 * (size_t)nv + 2 * ((size_t)nv + 1);
   const size_t ne = first[nv], n = m + 2;
-  /* one block: [ef_meg][v: n pointers][act: nv][position headers: nv][vertices: nv][adjs + incs
-   * headers: 2 nv][nodes: nv (position lists) + ne (adjacency)] -- a few hundred bytes of structure
-   * for a dozen vertices instead of three pool cells per vertex and one per edge, and one free() */
-  const size_t bytes = sizeof(ef_meg) + n * sizeof(ef_list*) + nv * sizeof(size_t) + nv * sizeof(ef_list) +
+  /* one block: [ef_meg][v: nv pointers][act: nv][position headers: nv][vertices: nv][adjs + incs
+   * headers: 2 nv][nodes: nv (position lists) + ne (adjacency)] -- about a kilobyte for a dozen
+   * vertices instead of three pool cells per vertex, one per edge and a table of |P| + 2 pointers, and
+   * one free().  What reads such a graph visits "every position that holds vertices, ascending" and
+   * never asks which position it is (the vertices carry p), so the position table is compact here:
+   * v[k] = the k-th such position's list, act[k] = k (EF_MEG_FOR_POS then yields k). */
+  const size_t bytes = sizeof(ef_meg) + nv * sizeof(ef_list*) + nv * sizeof(size_t) + nv * sizeof(ef_list) +
                        nv * sizeof(ef_pairing) + 2 * (size_t)nv * sizeof(ef_list) + ((size_t)nv + ne) * sizeof(ef_node);
   char* blk = (char*)malloc(bytes + 8);
   ef_meg* V = (ef_meg*)blk; blk += sizeof(ef_meg);
   V->n = n; V->rec = rec; V->slab = true;
-  V->v = (ef_list**)blk; blk += n * sizeof(ef_list*);
+  V->v = (ef_list**)blk; blk += nv * sizeof(ef_list*);
   V->act = (size_t*)blk; blk += nv * sizeof(size_t);
   ef_list* heads = (ef_list*)blk; blk += nv * sizeof(ef_list);
   ef_pairing* vx = (ef_pairing*)blk; blk += nv * sizeof(ef_pairing);
   ef_list* lists = (ef_list*)blk; blk += 2 * (size_t)nv * sizeof(ef_list);
   ef_node* node = (ef_node*)blk;
-  for (size_t i = 0; i < n; ++i) V->v[i] = &empty_position;
   V->n_act = 0;
 #define SLAB_PUSH_BACK(l_, el_) do { ef_node* nd_ = node++; nd_->el = (el_); nd_->prev = (l_)->sent.prev; nd_->next = &(l_)->sent; \
                                       (l_)->sent.prev->next = nd_; (l_)->sent.prev = nd_; ++(l_)->size; } while (0)
-  size_t h = 0;
+  size_t last_pos = (size_t)-1;
   for (uint32_t k = 0; k < nv; ++k) {
     const int p = vt[3 * k], t = vt[3 * k + 1], l = vt[3 * k + 2];
     const size_t pos = p == EF_SOURCE_START ? 0 : (p == EF_SINK_START ? n - 1 : 1 + (size_t)p);
-    if (V->v[pos] == &empty_position) { V->v[pos] = &heads[h++]; efl_init(V->v[pos]); V->act[V->n_act++] = pos; }
+    if (pos != last_pos) {                 /* vertices come in position-list order */
+      V->v[V->n_act] = &heads[V->n_act]; efl_init(V->v[V->n_act]); V->act[V->n_act] = V->n_act; ++V->n_act;
+      last_pos = pos;
+    }
     ef_pairing* x = &vx[k];
     x->p = p; x->t = t; x->l = l; x->id = 0; x->visited = false; x->emb_memo = NULL;
     x->adjs = &lists[2 * k]; x->incs = &lists[2 * k + 1];
     efl_init(x->adjs); efl_init(x->incs);
-    SLAB_PUSH_BACK(V->v[pos], x);
+    SLAB_PUSH_BACK(V->v[V->n_act - 1], x);
   }
   for (uint32_t k = 0; k < nv; ++k)
     for (uint32_t e = first[k]; e < first[k + 1]; ++e) SLAB_PUSH_BACK(vx[k].adjs, &vx[tgt[e]]);
