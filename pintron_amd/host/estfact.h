@@ -160,7 +160,7 @@ void ef_intronic_edges_write(struct ef_sink* f, ef_meg* V);                     
 typedef struct ef_sink { FILE* f; char* mem; size_t len, cap; } ef_sink;
 static inline void ef_sink_write(ef_sink* s, const char* p, size_t n) {
   if (s->f) { fwrite(p, 1, n, s->f); return; }
-  if (s->len + n > s->cap) { s->cap = (s->len + n) * 2 + 4096; s->mem = (char*)realloc(s->mem, s->cap); }
+  if (s->len + n > s->cap) { s->cap = (s->len + n) * 2 + 256; s->mem = (char*)realloc(s->mem, s->cap); }
   memcpy(s->mem + s->len, p, n); s->len += n;
 }
 static inline void ef_sink_puts(ef_sink* s, const char* str) { ef_sink_write(s, str, strlen(str)); }
@@ -172,7 +172,7 @@ static inline void efw_room(ef_wbuf* w, size_t need);
 static inline void efw_open(ef_wbuf* w, ef_sink* s) {
   w->s = s;
   if (s->f) { w->p = w->b; w->end = w->b + sizeof w->b; }
-  else { w->p = w->end = NULL; efw_room(w, 1024); }
+  else { w->p = w->end = NULL; efw_room(w, 128); }
 }
 static inline void efw_flush(ef_wbuf* w) {
   if (w->s->f) { if (w->p != w->b) { fwrite(w->b, 1, (size_t)(w->p - w->b), w->s->f); w->p = w->b; } }
@@ -184,7 +184,7 @@ static inline void efw_room(ef_wbuf* w, size_t need) {
   ef_sink* s = w->s;
   if (s->f) { efw_flush(w); return; }
   if (w->p) s->len = (size_t)(w->p - s->mem);
-  if (s->len + need > s->cap) { s->cap = (s->len + need) * 2 + 4096; s->mem = (char*)realloc(s->mem, s->cap); }
+  if (s->len + need > s->cap) { s->cap = (s->len + need) * 2 + 256; s->mem = (char*)realloc(s->mem, s->cap); }
   w->p = s->mem + s->len; w->end = s->mem + s->cap;
 }
 static inline void efw_ch(ef_wbuf* w, char c) { efw_room(w, 1); *w->p++ = c; }
