@@ -88,16 +88,23 @@ def rocprof_symbol(group_name):
             "gap_traceback": "gap_traceback_wave_kernel"}.get(group_name, group_name.split("+")[0] + "_kernel")
 
 
-def pmc_traffic(group_name):
+def pmc_traffic(group_name, ests_per_launch=None):
     """HBM bytes per launch of that kernel from the committed PMC passes (tools/pmc_traffic.sh:
-    (2 x FETCH_SIZE + WRITE_SIZE) x 1024, separate --pmc runs), or None."""
+    (2 x FETCH_SIZE + WRITE_SIZE) x 1024, separate --pmc runs), or None.  The counter passes run a smaller
+    batch whose launches carry a different number of ESTs, so the per-launch figure is scaled to the
+    launches of THIS run by ESTs per launch when both are known."""
     path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
     if not os.path.exists(path):
         return None
     sym = rocprof_symbol(group_name)
-    for k, v in json.load(open(path)).items():
-        if sym in k:
-            return v["hbm_bytes_per_launch"]
+    table = json.load(open(path))
+    run = table.get("_run", {})
+    for k, v in table.items():
+        if k != "_run" and sym in k:
+            per_launch = v["hbm_bytes_per_launch"]
+            if ests_per_launch and run.get("ests") and v.get("launches"):
+                per_launch *= ests_per_launch / (run["ests"] / v["launches"])
+            return per_launch
     return None
 
 
@@ -302,7 +309,8 @@ def main():
             per_launch_ms = dom["ms"] / max(dom["launches"], 1)
             ach = dom["algo_bytes"] / (dom["ms"] * 1e-3) / 1e9 if dom["ms"] and dom["algo_bytes"] else None
             out["roofline"] = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": ach / HBM_PEAK_GBS if ach else None, "traffic": pmc_traffic(name),
+                               "frac": ach / HBM_PEAK_GBS if ach else None,
+                               "traffic": pmc_traffic(name, n_est / max(dom["launches"], 1)),
                                "avg_launch_ms": per_launch_ms, "launches_per_step": dom["launches"],
                                "algo_bytes_per_launch": dom["algo_bytes"] / max(dom["launches"], 1)}
             # integer DP: the arithmetic bound is VALU issue, not MFMA.  Chip peak = 256 CU x 4 SIMD x 32

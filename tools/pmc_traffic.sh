@@ -5,6 +5,7 @@
 set -e
 export TMPDIR=/tmp
 N=${1:-20000}
+export PMC_ESTS=$N
 mkdir -p gpurun_out
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/pmc_$C
@@ -29,7 +30,10 @@ for k, v in out.items():
     # FETCH_SIZE / WRITE_SIZE are KiB; gfx950 tallies 128-B read requests at 64 B -> double the reads
     res[k] = {"launches": v["launches"], "fetch_KiB": v["FETCH_SIZE"], "write_KiB": v["WRITE_SIZE"],
               "hbm_bytes_per_launch": (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0 / n}
+import os
+res["_run"] = {"ests": int(os.environ.get("PMC_ESTS", "20000")), "note": "bench.py --steps 1 --warmup 0 --ests <ests>: the launches of this run carry a different number of ESTs than the full bench's"}
 json.dump(res, open("gpurun_out/pmc_traffic.json", "w"), indent=1, sort_keys=True)
+res.pop("_run")
 for k, v in sorted(res.items(), key=lambda kv: -kv[1]["launches"])[:12]:
     print(k[:70], v["launches"], round(v["hbm_bytes_per_launch"]))
 PY
