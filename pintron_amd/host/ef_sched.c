@@ -24,6 +24,8 @@
 #include <malloc.h>
 #include <pthread.h>
 #include <sys/prctl.h>
+#include <sys/syscall.h>
+#include <linux/futex.h>
 #include <sys/resource.h>
 #include <sched.h>
 #include <dirent.h>
@@ -182,9 +184,20 @@ typedef struct merged_batch {
 typedef struct dp_request {
   const pgpu_dp_job* jobs; size_t n; const char* arena; size_t arena_len;
   merged_batch* batch; size_t base;      /* filled by the service */
-  int rc; bool done;
+  int rc;
+  uint32_t done;                         /* 0 -> 1 by the service; the poster sleeps on this word (futex): a finished batch
+                                            wakes the posters of ITS requests, not every worker that waits for some batch */
   struct dp_request* next;
 } dp_request;
+
+static inline void request_wait(dp_request* rq) {
+  while (!__atomic_load_n(&rq->done, __ATOMIC_ACQUIRE))
+    syscall(SYS_futex, &rq->done, FUTEX_WAIT_PRIVATE, 0u, NULL, NULL, 0);
+}
+static inline void request_publish(dp_request* rq) {
+  __atomic_store_n(&rq->done, 1u, __ATOMIC_RELEASE);
+  syscall(SYS_futex, &rq->done, FUTEX_WAKE_PRIVATE, 1, NULL, NULL, 0);
+}
 
 #define MAX_SERVICES 4
 typedef struct service_thread {          /* one submitter: own context (stream, device buffers) */
@@ -549,11 +562,9 @@ static void* service_main(void* arg) {
     me->phase_s[5] += now_s() - t_d;
     if (rc != PGPU_OK) fprintf(stderr, "* FATAL DP batch failed: %s\n", pgpu_last_error(me->ctx));
     me->stats.dp_batches++; me->stats.dp_jobs += nj;
-    pthread_mutex_lock(&sv->mu);
-    /* `done` is also polled without the mutex by the poster's lane choice: release store */
-    for (dp_request* r = list; r;) { dp_request* nx = r->next; r->batch = mb; r->rc = rc; __atomic_store_n(&r->done, true, __ATOMIC_RELEASE); r = nx; }
-    pthread_cond_broadcast(&sv->finished);
-    pthread_mutex_unlock(&sv->mu);
+    /* `done` is what the poster sleeps on and what its lane choice polls: written last (release); the
+     * request may be reused by its owner the moment it is published, so `next` is read before */
+    for (dp_request* r = list; r;) { dp_request* nx = r->next; r->batch = mb; r->rc = rc; request_publish(r); r = nx; }
   }
   free(parts);
   return NULL;
@@ -588,11 +599,8 @@ static int launch_dp(worker* w, lane* ln) {
 /* sleep until the lane's posted requests are back, then decode this lane's slice */
 static int collect_dp(worker* w, lane* ln) {
   if (!ln->posted) return 0;
-  service* sv = &w->sh->svc;
   dp_request* rq = &ln->rq;
-  pthread_mutex_lock(&sv->mu);
-  while (!rq->done) pthread_cond_wait(&sv->finished, &sv->mu);
-  pthread_mutex_unlock(&sv->mu);
+  request_wait(rq);
   ln->posted = false;
   const int rc = rq->rc;
   if (rc == PGPU_OK) {
@@ -610,9 +618,7 @@ static int collect_dp(worker* w, lane* ln) {
       f->state = F_RUNNABLE;
     }
   }
-  pthread_mutex_lock(&sv->mu);
-  const bool last = --rq->batch->refs == 0;
-  pthread_mutex_unlock(&sv->mu);
+  const bool last = __atomic_sub_fetch(&rq->batch->refs, 1, __ATOMIC_ACQ_REL) == 0;
   if (last) { free(rq->batch->results); free(rq->batch->strings); free(rq->batch); }
   ln->n_inflight = 0;
   return rc;
