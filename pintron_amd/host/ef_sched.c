@@ -185,18 +185,23 @@ typedef struct dp_request {
   const pgpu_dp_job* jobs; size_t n; const char* arena; size_t arena_len;
   merged_batch* batch; size_t base;      /* filled by the service */
   int rc;
-  uint32_t done;                         /* 0 -> 1 by the service; the poster sleeps on this word (futex): a finished batch
-                                            wakes the posters of ITS requests, not every worker that waits for some batch */
+  uint32_t done;                         /* 0 -> 1 by the service, written last (release) */
+  uint32_t* wake;                        /* the posting worker's wake word: bumped and woken when this request is done,
+                                            so a finished batch wakes the posters of ITS requests (not every worker that
+                                            waits for some batch) and a worker with all lanes in flight resumes on
+                                            whichever of its batches returns first */
   struct dp_request* next;
 } dp_request;
 
-static inline void request_wait(dp_request* rq) {
-  while (!__atomic_load_n(&rq->done, __ATOMIC_ACQUIRE))
-    syscall(SYS_futex, &rq->done, FUTEX_WAIT_PRIVATE, 0u, NULL, NULL, 0);
-}
 static inline void request_publish(dp_request* rq) {
+  uint32_t* wake = rq->wake;             /* the owner may reuse the request the moment `done` is set */
   __atomic_store_n(&rq->done, 1u, __ATOMIC_RELEASE);
-  syscall(SYS_futex, &rq->done, FUTEX_WAKE_PRIVATE, 1, NULL, NULL, 0);
+  __atomic_add_fetch(wake, 1u, __ATOMIC_RELEASE);
+  syscall(SYS_futex, wake, FUTEX_WAKE_PRIVATE, 1, NULL, NULL, 0);
+}
+/* sleep until the worker's wake word moves on from `seen` */
+static inline void worker_sleep(uint32_t* wake, uint32_t seen) {
+  syscall(SYS_futex, wake, FUTEX_WAIT_PRIVATE, seen, NULL, NULL, 0);
 }
 
 #define MAX_SERVICES 4
@@ -275,6 +280,7 @@ typedef struct worker {
   fiber* free_fibers;
   out_chunk* chunk;                      /* current output chunk of this worker */
   lane lanes[MAX_LANES];
+  uint32_t wake;                         /* see dp_request */
   pgpu_ctx* ctx;                         /* for pairing retries only; created on first use */
   ef_sched_stats stats;
 } worker;
@@ -586,6 +592,7 @@ static int launch_dp(worker* w, lane* ln) {
   if (ln->n_inflight == 0) return 0;
   dp_request* rq = &ln->rq;
   memset(rq, 0, sizeof *rq);
+  rq->wake = &w->wake;
   rq->jobs = ln->jb.jobs; rq->n = ln->jb.n; rq->arena = ln->jb.arena; rq->arena_len = ln->jb.arena_len;
   pthread_mutex_lock(&sv->mu);
   if (sv->tail) sv->tail->next = rq; else sv->head = rq;
@@ -600,7 +607,11 @@ static int launch_dp(worker* w, lane* ln) {
 static int collect_dp(worker* w, lane* ln) {
   if (!ln->posted) return 0;
   dp_request* rq = &ln->rq;
-  request_wait(rq);
+  for (;;) {
+    const uint32_t seen = __atomic_load_n(&w->wake, __ATOMIC_ACQUIRE);
+    if (__atomic_load_n(&rq->done, __ATOMIC_ACQUIRE)) break;
+    worker_sleep(&w->wake, seen);
+  }
   ln->posted = false;
   const int rc = rq->rc;
   if (rc == PGPU_OK) {
@@ -651,7 +662,23 @@ static void* worker_main(void* arg) {
         if (first_posted < 0) first_posted = idx;
       } else if (c->n_fibers > 0 || more) { li = idx; break; }
     }
-    if (li < 0) li = first_posted;       /* everything that has work is on the GPU: wait for it */
+    if (li < 0 && first_posted >= 0) {
+      /* everything that has work is on the GPU: sleep until any of this worker's batches is back
+       * (the wake word is read before the lanes are looked at again, so a completion in between is
+       * not slept through) */
+      const double tw = now_s();
+      for (;;) {
+        const uint32_t seen = __atomic_load_n(&w->wake, __ATOMIC_ACQUIRE);
+        for (int k = 0; k < n_lanes && li < 0; ++k) {
+          const int idx = (cursor + k) % n_lanes;
+          if (w->lanes[idx].posted && __atomic_load_n(&w->lanes[idx].rq.done, __ATOMIC_ACQUIRE)) li = idx;
+        }
+        if (li >= 0 || sh->failed) break;
+        worker_sleep(&w->wake, seen);
+      }
+      w->stats.dp_s += now_s() - tw;
+      if (li < 0) break;
+    }
     if (li < 0) break;                   /* no fibres, no ESTs left, nothing in flight */
     cursor = (li + 1) % n_lanes;
     lane* ln = &w->lanes[li];
