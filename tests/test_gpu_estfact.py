@@ -26,7 +26,9 @@ def exe():
 @pytest.mark.parametrize("env", [{}, {"PINTRON_ESTFACT_MODE": "direct"}, {"PINTRON_THREADS": "2", "PINTRON_FIBERS": "5"},
                                  {"PINTRON_LANES": "1"}, {"PINTRON_LANES": "4", "PINTRON_SERVICES": "2", "PINTRON_FIBERS": "8"},
                                  {"PINTRON_NO_PREFETCH": "1", "PINTRON_THREADS": "3"},
-                                 {"PINTRON_GPU_MEG": "0"}])
+                                 {"PINTRON_GPU_MEG": "0"},
+                                 {"PGPU_MERGED": "1"}, {"PGPU_MERGED": "0"}, {"PGPU_MERGED": "0", "PGPU_FANOUT": "0"},
+                                 {"PGPU_WAIT": "0"}, {"PINTRON_NO_FIBER_POOL": "1", "PINTRON_NO_FIBER_PREFETCH": "1"}])
 def test_ambn_golden(exe, tmp_path, env):
     for f in ("genomic.txt", "ests.txt"):
         shutil.copy(os.path.join(GOLD, f), tmp_path)
@@ -37,9 +39,11 @@ def test_ambn_golden(exe, tmp_path, env):
         assert filecmp.cmp(os.path.join(tmp_path, f), os.path.join(GOLD, "expected-" + f), shallow=False), f
 
 
-def test_c3_sample_vs_compiled_reference(exe, tmp_path):
+@pytest.mark.parametrize("env", [{}, {"PGPU_MERGED": "1"}, {"PGPU_MERGED": "0"}])
+def test_c3_sample_vs_compiled_reference(exe, tmp_path, env):
     """2 000 C3-shaped ESTs (200 kb genomic, 3 % errors): byte-identical to the reference binary
-    (oracle/_ref/est-fact-core travels with the repository snapshot)."""
+    (oracle/_ref/est-fact-core travels with the repository snapshot), in every launch mode of the library
+    (one batch launch + LCF; wave-per-job launch + sweeps; a launch per family)."""
     ref = os.path.join(ROOT, "oracle", "_ref", "est-fact-core")
     if not os.path.exists(ref):
         pytest.skip("oracle/_ref/est-fact-core not present")
@@ -49,7 +53,7 @@ def test_c3_sample_vs_compiled_reference(exe, tmp_path):
     for d in (ref_dir, my_dir):
         synth.write_files(w, str(d))
     subprocess.run([ref], cwd=ref_dir, check=True, stderr=subprocess.DEVNULL)
-    subprocess.run([exe], cwd=my_dir, check=True)
+    subprocess.run([exe], cwd=my_dir, check=True, env=dict(os.environ, **env))
     for f in FILES:
         assert filecmp.cmp(my_dir / f, ref_dir / f, shallow=False), f
 
