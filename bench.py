@@ -33,7 +33,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 N_EST_BATCH = 100_000          # C3
-CPU_SAMPLE = 3000              # ESTs of the same workload given to the reference CPU est-fact
+# ESTs per GPU per step of each workload = the share of one GPU of an 8-GPU node in BASELINE.json's configs:
+# C2 and C3 whole, one gene of C4 (x genes on the rank), an eighth of C5's two million reads
+PER_GPU = {"C2": 1_000, "C3": N_EST_BATCH, "C4": 62_500, "C5": 250_000}
+# ESTs of the same workload given to the reference CPU est-fact (about 10-30 s of one core)
+CPU_SAMPLE_OF = {"C2": 1_000, "C3": 3_000, "C4": 3_000, "C5": 6_000}
+CPU_SAMPLE = CPU_SAMPLE_OF["C3"]
 
 
 from pintron_amd.estfact import RECORDS, Session, gather_tensor, load_host_lib  # noqa: E402
@@ -88,14 +93,18 @@ def rocprof_symbol(group_name):
             "gap_traceback": "gap_traceback_wave_kernel"}.get(group_name, group_name.split("+")[0] + "_kernel")
 
 
-def pmc_traffic(group_name, ests_per_launch=None):
+def pmc_traffic(group_name, ests_per_launch=None, workload="C3"):
     """HBM bytes per launch of that kernel from the committed PMC passes (tools/pmc_traffic.sh:
     (2 x FETCH_SIZE + WRITE_SIZE) x 1024, separate --pmc runs), or None.  The counter passes run a smaller
     batch whose launches carry a different number of ESTs, so the per-launch figure is scaled to the
-    launches of THIS run by ESTs per launch when both are known."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-    if not os.path.exists(path):
+    launches of THIS run by ESTs per launch when both are known.  The newest table of the workload wins
+    (profiles/rNN_pmc_traffic[_<workload>].json)."""
+    import glob
+    tag = "" if workload == "C3" else "_" + workload.lower()
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic%s.json" % tag)))
+    if not found:
         return None
+    path = found[-1]
     sym = rocprof_symbol(group_name)
     table = json.load(open(path))
     run = table.get("_run", {})
@@ -137,15 +146,15 @@ def usable_cores(cap=16):
     return max(1, min(n, cap))
 
 
-def cpu_reference_all_cores(n_proc, base_seed):
+def cpu_reference_all_cores(n_proc, base_seed, workload="C3", sample=CPU_SAMPLE):
     """The embarrassingly parallel CPU figure: one reference est-fact process per
-    usable core, each on its own seeded C3 sample of CPU_SAMPLE ESTs, all started together."""
+    usable core, each on its own seeded sample of `sample` ESTs of the workload, all started together."""
     from pintron_amd import synth
     exe = os.path.join(ROOT, "oracle", "_ref", "est-fact-core")
     dirs = []
     for k in range(n_proc):
         d = tempfile.mkdtemp(prefix="pintron_bench_refN_")
-        synth.write_files(synth.make("C3", n_est=CPU_SAMPLE, seed=base_seed + 1000 + k), d)
+        synth.write_files(synth.make(workload, n_est=sample, seed=base_seed + 1000 + k), d)
         dirs.append(d)
     t0 = time.perf_counter()
     procs = [subprocess.Popen([exe], cwd=d, stderr=subprocess.DEVNULL) for d in dirs]
@@ -161,13 +170,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--ests", type=int, default=N_EST_BATCH, help="ESTs per GPU per step (default: C3)")
+    ap.add_argument("--ests", type=int, default=None, help="ESTs per GPU per step (default: the workload's per-GPU share, PER_GPU)")
+    ap.add_argument("--genes", type=int, default=None, help="C4 only: number of genes (default 8 = BASELINE.json configs[3]; 1 = one GPU's share)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / parity leg")
     ap.add_argument("--no-oneshot", action="store_true", help="skip the one-process start-to-files measurement")
-    ap.add_argument("--workload", choices=("C3", "C4"), default="C3",
+    ap.add_argument("--workload", choices=("C2", "C3", "C4", "C5"), default="C3",
                     help="C3 (default, the metric's configuration): one 200 kb gene x --ests per GPU; "
-                         "C4: 8 genes x 200 kb, --ests ESTs each (62 500 = BASELINE.json configs[3]), gene g on rank g mod N")
+                         "C4: 8 genes x 200 kb, --ests ESTs each (62 500 = BASELINE.json configs[3]), gene g on rank g mod N; "
+                         "C2: 50 kb x 1 000 ESTs; C5: 1 Mb x 250 000 reads of 150 bp per GPU (an eighth of configs[4])")
     args = ap.parse_args()
+    if args.ests is None:
+        args.ests = PER_GPU[args.workload]
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         return launch_ranks(args)
@@ -198,14 +211,16 @@ def main():
 
     from pintron_amd import synth
     L = load_host_lib()
-    if args.workload == "C3":
-        # every rank gets its own C3 batch (weak scaling); rank r uses seed 3 + r so batches differ
-        genes = [("C3", synth.CONFIGS["C3"]["seed"] + rank, args.ests)]
+    wl = args.workload
+    if wl != "C4":
+        # every rank gets its own batch (weak scaling); rank r uses seed <config seed> + r so batches differ
+        genes = [(wl, synth.CONFIGS[wl]["seed"] + rank, args.ests)]
     else:
         # C4: eight independent est-fact problems; gene g runs on rank g mod N (strong scaling)
-        per_gene = synth.CONFIGS["C4"]["n_est"] if args.ests == N_EST_BATCH else args.ests
-        genes = [("C4", synth.CONFIGS["C4"]["seed"] + g, per_gene)
-                 for g in range(synth.CONFIGS["C4"]["genes"]) if g % world == rank]
+        n_genes = args.genes or synth.CONFIGS["C4"]["genes"]
+        genes = [("C4", synth.CONFIGS["C4"]["seed"] + g, args.ests) for g in range(n_genes) if g % world == rank]
+        if not genes:
+            raise SystemExit("bench: rank %d has no gene (%d genes over %d ranks)" % (rank, n_genes, world))
     works, sessions = [], []
     for name, seed, n in genes:
         work = tempfile.mkdtemp(prefix="pintron_bench_r%d_" % rank)
@@ -215,14 +230,14 @@ def main():
     n_est = sum(s.n_ests() for s in sessions)
 
     def step():
-        sts = []
-        for sess in sessions:
-            sts.append(sess.step())
-            if world > 1:
-                # the only exchange of the sharded path: the factorization records of the rank's ESTs
-                # (packed: 16 B per exon + 4 B per factorization, everything downstream stages parse out
-                # of raw-multifasta-out.txt) -> rank 0 over RCCL
-                gather_tensor(sess.output_tensor(RECORDS), dist, rank, world, xdev)
+        sts = [sess.step() for sess in sessions]
+        if world > 1:
+            # the only exchange of the sharded path: the factorization records of the rank's ESTs
+            # (packed: 16 B per exon + 4 B per factorization, everything downstream stages parse out
+            # of raw-multifasta-out.txt) -> rank 0 over RCCL.  ONE gather per step whatever the number
+            # of genes on the rank (ranks with different gene counts issue the same collectives)
+            recs = [sess.output_tensor(RECORDS) for sess in sessions]
+            gather_tensor(recs[0] if len(recs) == 1 else torch.cat(recs), dist, rank, world, xdev)
         return sts
 
     def fence():
@@ -243,10 +258,11 @@ def main():
         dt = float(tt.item())
 
     total_est = n_est
+    n_aligned = total_aligned = int(sum(x.aligned for x in stats[-1]))
     if world > 1:
-        tn = torch.tensor([n_est], dtype=torch.int64, device=xdev)
+        tn = torch.tensor([n_est, n_aligned], dtype=torch.int64, device=xdev)
         dist.all_reduce(tn)
-        total_est = int(tn.item())
+        total_est, total_aligned = int(tn[0].item()), int(tn[1].item())
     if rank == 0:
         st = stats[-1][-1]
         kernels = {}
@@ -260,16 +276,21 @@ def main():
         step_s = dt / args.steps
         out = {
             "metric": "ESTs aligned/sec (whole node) + DP Mcells/s; bit-exact factorizations vs ref",
-            "value": total_est / step_s, "unit": "ESTs/s", "n_gpus": world, "steps": args.steps,
+            # the metric says "ESTs ALIGNED per second": the ESTs that got at least one factorization (what
+            # processed-ests.txt lists); the input rate is beside it
+            "value": total_aligned / step_s, "unit": "aligned ESTs/s", "input_ests_per_s": total_est / step_s,
+            "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": step_s * 1e3, "higher_is_better": True,
-            "scaling": "weak" if args.workload == "C3" else "strong", "vs_baseline": None, "dtype": "u8/int32", "data": "synthetic",
-            "config": {"workload": ("C3: 200 kb genomic x %d ESTs ~600 bp, 3%% errors, per GPU" % n_est) if args.workload == "C3" else
-                                   ("C4: %d genes x 200 kb, %d ESTs ~600 bp each, gene g on rank g mod %d (%d ESTs in all)"
-                                    % (synth.CONFIGS["C4"]["genes"], genes[0][2], world, total_est)),
+            "scaling": "weak" if wl != "C4" else "strong", "vs_baseline": None, "dtype": "u8/int32", "data": "synthetic",
+            "config": {"workload": {"C3": "C3: 200 kb genomic x %d ESTs ~600 bp, 3%% errors, per GPU" % n_est,
+                                    "C2": "C2: 50 kb genomic x %d ESTs ~500 bp, 1%% errors, per GPU" % n_est,
+                                    "C5": "C5: 1 Mb genomic x %d reads of 150 bp, 1%% errors, per GPU (BASELINE.json configs[4] = 8 such shares)" % n_est,
+                                    "C4": "C4: %d genes x 200 kb, %d ESTs ~600 bp each, gene g on rank g mod %d (%d ESTs in all)"
+                                          % (args.genes or synth.CONFIGS["C4"]["genes"], genes[0][2], world, total_est)}[wl],
                        "stages": "whole est-fact hot path per step: GPU pairings over the device index + host MEG/"
                                  "embeddings/filters/refinement (%d threads, fibres) with all DPs batched on the GPU"
                                  % st.threads,
-                       "ests_per_gpu": n_est, "aligned_per_gpu": int(sum(x.aligned for x in stats[-1])),
+                       "ests_per_gpu": n_est, "aligned_per_gpu": n_aligned,
                        "dp_jobs_per_step": int(sum(x.dp_jobs for x in stats[-1])),
                        "dp_batches_per_step": int(sum(x.dp_batches for x in stats[-1])),
                        "parallelism": "est-shard x%d" % world},
@@ -282,16 +303,23 @@ def main():
         # the text the LAST TIMED step left on rank 0 against the reference's checksum for the very same
         # batch (tools/make_bench_md5.py ran the reference object code on it in the build container)
         gold_path = os.path.join(ROOT, "tests", "golden", "bench_md5.json")
-        if args.workload == "C3" and os.path.exists(gold_path):
-            gold = json.load(open(gold_path)).get("C3:%d:seed%d" % (n_est, genes[0][1]))
-            if gold:
-                same = gold["raw-multifasta-out.txt"] == out["timed_output_md5"]
-                out["timed_output"] = {"ests": n_est, "md5": out["timed_output_md5"], "reference_md5": gold["raw-multifasta-out.txt"],
-                                       "identical_to_reference": same}
-                if not same:
-                    raise SystemExit("bench: the timed step's raw-multifasta-out differs from the reference's (md5 %s vs %s)"
-                                     % (out["timed_output_md5"], gold["raw-multifasta-out.txt"]))
-        if world == 1 and args.workload == "C3" and not args.no_oneshot:
+        if os.path.exists(gold_path):
+            # every gene of this rank whose batch has a committed checksum (C4: gene 0 = one GPU's share)
+            table = json.load(open(gold_path))
+            checked = []
+            for (name, seed, n), sess in zip(genes, sessions):
+                gold = table.get("%s:%d:seed%d" % (name, sess.n_ests(), seed))
+                if not gold:
+                    continue
+                md5 = hashlib.md5(sess.records()).hexdigest()
+                checked.append({"batch": "%s:%d:seed%d" % (name, sess.n_ests(), seed), "md5": md5,
+                                "reference_md5": gold["raw-multifasta-out.txt"], "identical_to_reference": md5 == gold["raw-multifasta-out.txt"]})
+                if md5 != gold["raw-multifasta-out.txt"]:
+                    raise SystemExit("bench: the timed step's raw-multifasta-out of %s differs from the reference's (md5 %s vs %s)"
+                                     % (checked[-1]["batch"], md5, gold["raw-multifasta-out.txt"]))
+            if checked:
+                out["timed_output"] = dict(checked[0], ests=n_est, batches_checked=len(checked))
+        if world == 1 and wl != "C4" and not args.no_oneshot:
             # the way the pipeline driver uses est-fact (dist-scripts/pintron.py:878-884): one process per
             # gene, process start -> the six files on disk.  Outside the timed steps; the resident
             # sessions above keep their HBM.
@@ -310,7 +338,7 @@ def main():
             ach = dom["algo_bytes"] / (dom["ms"] * 1e-3) / 1e9 if dom["ms"] and dom["algo_bytes"] else None
             out["roofline"] = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": ach / HBM_PEAK_GBS if ach else None,
-                               "traffic": pmc_traffic(name, n_est / max(dom["launches"], 1)),
+                               "traffic": pmc_traffic(name, n_est / max(dom["launches"], 1), wl),
                                "avg_launch_ms": per_launch_ms, "launches_per_step": dom["launches"],
                                "algo_bytes_per_launch": dom["algo_bytes"] / max(dom["launches"], 1)}
             # integer DP: the arithmetic bound is VALU issue, not MFMA.  Chip peak = 256 CU x 4 SIMD x 32
@@ -326,9 +354,10 @@ def main():
                                # cells (reference loop bounds) per second of this kernel's own stream time
                                "Gcells_s": round(k["cells"] / (k["ms"] * 1e-3) / 1e9, 1) if k["ms"] and k["cells"] else None}
                               for n, k in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"])]
-        if world == 1 and not args.no_cpu and args.workload == "C3":
+        if world == 1 and not args.no_cpu:
             # bounded sample of the same workload: reference CPU est-fact vs this code, byte for byte
-            sample = synth.make("C3", n_est=CPU_SAMPLE, seed=synth.CONFIGS["C3"]["seed"] + rank)
+            cpu_n = min(CPU_SAMPLE_OF[wl], n_est)
+            sample = synth.make(wl, n_est=cpu_n, seed=genes[0][1])
             sdir_ref = tempfile.mkdtemp(prefix="pintron_bench_ref_")
             sdir_gpu = tempfile.mkdtemp(prefix="pintron_bench_gpu_")
             synth.write_files(sample, sdir_ref)
@@ -342,16 +371,22 @@ def main():
                 ref = open(os.path.join(sdir_ref, "raw-multifasta-out.txt"), "rb").read()
                 if got != ref:
                     raise SystemExit("bench: GPU est-fact output differs from the reference CPU est-fact on the sample")
-                out["cpu_baseline"] = {"value": CPU_SAMPLE / cpu_s, "unit": "ESTs/s", "cores": 1, "kind": "reference",
-                                       "sample": "first-seed C3 sample of %d ESTs through oracle/_ref/est-fact-core "
-                                                 "(%.1f s); output byte-identical to this code's" % (CPU_SAMPLE, cpu_s)}
+                # counted like `value`: ESTs the reference aligned (its processed-ests.txt) per second
+                ref_aligned = open(os.path.join(sdir_ref, "processed-ests.txt"), "rb").read().count(b">")
+                frac = ref_aligned / max(cpu_n, 1)
+                out["cpu_baseline"] = {"value": ref_aligned / cpu_s, "unit": "aligned ESTs/s", "input_ests_per_s": cpu_n / cpu_s,
+                                       "cores": 1, "kind": "reference",
+                                       "sample": "first-seed %s sample of %d ESTs (%d aligned) through oracle/_ref/est-fact-core "
+                                                 "(%.1f s, its suffix-tree build included); output byte-identical to this code's"
+                                                 % (wl, cpu_n, ref_aligned, cpu_s)}
                 n_proc = usable_cores()
-                wall_all = cpu_reference_all_cores(n_proc, synth.CONFIGS["C3"]["seed"]) if n_proc > 1 else None
+                wall_all = cpu_reference_all_cores(n_proc, synth.CONFIGS[wl]["seed"], wl, cpu_n) if n_proc > 1 else None
                 if wall_all:
                     out["cpu_baseline"]["all_cores"] = {
-                        "value": n_proc * CPU_SAMPLE / wall_all, "unit": "ESTs/s", "cores": n_proc,
-                        "sample": "%d reference processes side by side, %d ESTs each (%.1f s)" % (n_proc, CPU_SAMPLE, wall_all)}
-                out["parity"] = {"sample_ests": CPU_SAMPLE, "raw_multifasta_md5": hashlib.md5(ref).hexdigest(), "identical": True}
+                        "value": frac * n_proc * cpu_n / wall_all, "unit": "aligned ESTs/s (aligned share of the first sample assumed)",
+                        "input_ests_per_s": n_proc * cpu_n / wall_all, "cores": n_proc,
+                        "sample": "%d reference processes side by side, %d ESTs each (%.1f s)" % (n_proc, cpu_n, wall_all)}
+                out["parity"] = {"sample_ests": cpu_n, "raw_multifasta_md5": hashlib.md5(ref).hexdigest(), "identical": True}
             shutil.rmtree(sdir_ref, ignore_errors=True)
             shutil.rmtree(sdir_gpu, ignore_errors=True)
         print(json.dumps(out), flush=True)

@@ -49,6 +49,18 @@ int pgpu_set_timing(pgpu_ctx* ctx, int enabled);
  * that alone is worth 10-14 % (the per-EST logic is memory-latency bound and the batches cross
  * PCIe on that socket). */
 int pgpu_device_numa_node(pgpu_ctx* ctx);
+/* Profiler ranges (roctx): the library wraps the kernel groups of every plan ("dp_batch", "lcf",
+ * "pairings", "meg", "index build") and the host program its phases ("est-fact step", "prefetch chunk k")
+ * so that `rocprofv3 --marker-trace` shows them.  The reference has five wall-clock timers
+ * (src/main-est-fact.c:95-99) and nothing per routine; SURVEY.md section 5 asks for both.  The roctx library is
+ * loaded on first use and only when PGPU_MARKERS=1 or a rocprofiler tool is in the process; otherwise the
+ * calls are two loads and a branch. */
+void pgpu_range_push(const char* name);
+void pgpu_range_pop(void);
+/* identity of the loaded library: compiler, target and an FNV-1a hash of the code object bundle's build
+ * stamp (__DATE__ __TIME__ + the compiler version) -- what smoke() prints so that a record can tell which
+ * binary ran */
+const char* pgpu_build_info(void);
 
 /* ------------------------------------------------------------------------------------------ */
 /* genomic index -- replaces lst_stree_new (stree_src/lst_stree.c:816) + preprocess_text /     */
@@ -169,6 +181,10 @@ int pgpu_comm_init(pgpu_ctx* ctx, int rank, int world, const pgpu_comm_id* id, p
  * rank.  recv/recv_cap: rank 0 only, receives sum(counts) bytes.  Collective: all ranks call it. */
 int pgpu_gather(pgpu_ctx* ctx, pgpu_comm* comm, const void* send, uint64_t send_bytes,
                 void* recv, uint64_t recv_cap, uint64_t* counts);
+/* fixed-size all-gather: every rank contributes `bytes` bytes (host memory) and receives world x bytes
+ * in rank order.  est-fact --gpus=N uses it once per run for the ranks' status word and output sizes:
+ * a rank that failed is seen by all before any payload moves. */
+int pgpu_allgather(pgpu_ctx* ctx, pgpu_comm* comm, const void* send, uint64_t bytes, void* recv);
 int pgpu_comm_destroy(pgpu_ctx* ctx, pgpu_comm* comm);
 
 /* ------------------------------------------------------------------------------------------ */

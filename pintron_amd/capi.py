@@ -49,7 +49,8 @@ EXPORTS = [
     "pgpu_pairing_plan_destroy",
     "pgpu_pairing_plan_run_meg", "pgpu_pairing_plan_meg_bytes", "pgpu_pairing_plan_fetch_meg",
     "pgpu_pairing_plan_meg_ms", "pgpu_host_alloc", "pgpu_host_free",
-    "pgpu_comm_unique_id", "pgpu_comm_init", "pgpu_gather", "pgpu_comm_destroy",
+    "pgpu_comm_unique_id", "pgpu_comm_init", "pgpu_gather", "pgpu_allgather", "pgpu_comm_destroy",
+    "pgpu_range_push", "pgpu_range_pop", "pgpu_build_info",
     "pgpu_dp_plan_create", "pgpu_dp_plan_create_parts", "pgpu_dp_plan_launch", "pgpu_dp_plan_sync",
     "pgpu_dp_plan_string_bytes", "pgpu_dp_plan_fetch", "pgpu_dp_plan_destroy",
     "pgpu_dp_plan_results_to_device",
@@ -80,6 +81,11 @@ def lib():
         L.pgpu_set_timing.argtypes = [vp, C.c_int]
         L.pgpu_last_error.argtypes = [vp]
         L.pgpu_last_error.restype = C.c_char_p
+        L.pgpu_build_info.restype = C.c_char_p
+        L.pgpu_range_push.argtypes = [C.c_char_p]
+        L.pgpu_range_push.restype = None
+        L.pgpu_range_pop.restype = None
+        L.pgpu_allgather.argtypes = [vp, vp, vp, u64, vp]
         L.pgpu_index_build.argtypes = [vp, C.c_char_p, sz, C.POINTER(vp)]
         L.pgpu_index_destroy.argtypes = [vp, vp]
         L.pgpu_index_save.argtypes = [vp, vp, C.c_char_p, C.c_char_p]

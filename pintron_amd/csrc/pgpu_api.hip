@@ -151,6 +151,45 @@ int pgpu_ctx_fail(pgpu_ctx* ctx, int code, const char* msg) { return set_err(ctx
 
 extern "C" int pgpu_abi_version(void) { return 1; }
 
+// ---- profiler ranges --------------------------------------------------------------------------------
+#include <dlfcn.h>
+namespace {
+struct Roctx { int state = 0; int (*push)(const char*) = nullptr; int (*pop)() = nullptr; };   // state: 0 untried, 1 on, -1 off
+Roctx g_roctx;
+bool roctx_ready() {
+  if (g_roctx.state) return g_roctx.state > 0;
+  bool want = false;
+  { const char* m = getenv("PGPU_MARKERS"); if (m) want = m[0] != '0'; else {
+      const char* t = getenv("ROCP_TOOL_LIBRARIES"); const char* pl = getenv("LD_PRELOAD");
+      want = (t && t[0]) || (pl && strstr(pl, "rocprofiler")); } }
+  if (want) {
+    void* so = nullptr;
+    for (const char* n : { "librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so" })
+      if ((so = dlopen(n, RTLD_NOW | RTLD_GLOBAL)) != nullptr) break;
+    if (so) {
+      *(void**)(&g_roctx.push) = dlsym(so, "roctxRangePushA");
+      *(void**)(&g_roctx.pop) = dlsym(so, "roctxRangePop");
+    }
+  }
+  g_roctx.state = (g_roctx.push && g_roctx.pop) ? 1 : -1;
+  return g_roctx.state > 0;
+}
+}  // namespace
+extern "C" void pgpu_range_push(const char* name) { if (roctx_ready()) g_roctx.push(name ? name : ""); }
+extern "C" void pgpu_range_pop(void) { if (roctx_ready()) g_roctx.pop(); }
+
+extern "C" const char* pgpu_build_info(void) {
+  static char info[256];
+  if (!info[0]) {
+    const char* stamp = __DATE__ " " __TIME__ " " __VERSION__;
+    unsigned long long h = 1469598103934665603ull;
+    for (const char* c = stamp; *c; ++c) { h ^= (unsigned char)*c; h *= 1099511628211ull; }
+    snprintf(info, sizeof info, "libpintron_gpu abi %d, gfx950, built %s %s, hip %d.%d.%d, stamp %016llx", pgpu_abi_version(), __DATE__,
+             __TIME__, HIP_VERSION_MAJOR, HIP_VERSION_MINOR, HIP_VERSION_PATCH, h);
+  }
+  return info;
+}
+
 extern "C" int pgpu_init(int device, pgpu_ctx** out) {
   if (!out) return PGPU_EINVAL;
   *out = nullptr;
@@ -597,6 +636,7 @@ extern "C" int pgpu_dp_plan_create_parts(pgpu_ctx* ctx, const pgpu_index* idx, c
 extern "C" int pgpu_dp_plan_launch(pgpu_ctx* ctx, pgpu_dp_plan* p) {
   if (!ctx || !p) return set_err(ctx, PGPU_EINVAL, "bad argument");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  p->synced = false; p->lcf_decoded = false;       // a relaunch downloads anew: the image holds raw keys again
   // Launch order: the groups are independent, and the host needs a few microseconds per launch, so
   // the long poles go first (one-job-per-workgroup sweeps with many rows, then the alignments with
   // their tracebacks, ...) and the thousands of tiny edit distances last.  A traceback group
@@ -664,6 +704,8 @@ extern "C" int pgpu_dp_plan_launch(pgpu_ctx* ctx, pgpu_dp_plan* p) {
       hipStream_t st = lane_of[oi] >= 0 ? ctx->aux[lane_of[oi]] : ctx->stream;
       if (g.ev0) HIP_TRY(ctx, hipEventRecord(g.ev0, st));
       g.launched = true;
+      pgpu_range_push(g.name.c_str());
+      struct PopAtExit { ~PopAtExit() { pgpu_range_pop(); } } pop_at_exit;
       switch (g.family) {
         case KF_COUNT:
           if (p->batch) {

@@ -17,6 +17,7 @@
 //                 per position: occurrences above the threshold, sort by t, filter (a);
 //                 filter (b) against the previous position; compaction into (p,t,l) triples
 #include <algorithm>
+#include <unistd.h>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -522,8 +523,21 @@ done:
 // ---- the index on disk: a gene is usually processed many times (parameter studies, re-runs of the
 // pipeline), the index depends on the genomic sequence alone ------------------------------------
 namespace {
-struct IndexFileHeader { char magic[8]; uint32_t version, ktab; uint64_t len, hash; };
+// version 2: + checksum of the payload (a file whose header is right and whose tables are not -- torn by
+// concurrent writers, truncated and padded, bit rot -- must not reach the device: an out-of-range
+// suffix-array entry is an out-of-bounds read in every pairing kernel)
+struct IndexFileHeader { char magic[8]; uint32_t version, ktab; uint64_t len, hash, payload_hash; };
 const char INDEX_MAGIC[8] = { 'P', 'G', 'P', 'U', 'I', 'D', 'X', '1' };
+constexpr uint32_t INDEX_VERSION = 2;
+// word-wise FNV-style mix of the payload (1 Mb genomic = 9 MB of tables: a byte-wise loop would cost
+// more than rebuilding the index)
+uint64_t words_hash(const uint32_t* w, size_t n) {
+  uint64_t h0 = 1469598103934665603ull, h1 = 0x9e3779b97f4a7c15ull;
+  size_t i = 0;
+  for (; i + 1 < n; i += 2) { h0 = (h0 ^ w[i]) * 1099511628211ull; h1 = (h1 ^ w[i + 1]) * 0x100000001b3ull; }
+  if (i < n) h0 = (h0 ^ w[i]) * 1099511628211ull;
+  return h0 ^ (h1 * 0xff51afd7ed558ccdull) ^ (uint64_t)n;
+}
 uint64_t fnv1a64(const void* p, size_t n) {
   const unsigned char* b = (const unsigned char*)p;
   uint64_t h = 1469598103934665603ull;
@@ -545,11 +559,17 @@ extern "C" int pgpu_index_save(pgpu_ctx* ctx, const pgpu_index* idx, const char*
       hipStreamSynchronize(st) != hipSuccess)
     return pgpu_ctx_fail(ctx, PGPU_EDEVICE, "index download failed");
   IndexFileHeader h;
-  memcpy(h.magic, INDEX_MAGIC, 8); h.version = 1; h.ktab = KTAB; h.len = n; h.hash = fnv1a64(genomic, n);
-  // written under a temporary name and renamed: a concurrent reader sees the whole file or none
-  std::string tmp = std::string(path) + ".tmp";
-  FILE* f = fopen(tmp.c_str(), "wb");
-  if (!f) return pgpu_ctx_fail(ctx, PGPU_EINVAL, "cannot create the index file");
+  memcpy(h.magic, INDEX_MAGIC, 8); h.version = INDEX_VERSION; h.ktab = KTAB; h.len = n; h.hash = fnv1a64(genomic, n);
+  h.payload_hash = words_hash(host.data(), host.size());
+  // written under a temporary name of its OWN (several ranks, or several est-fact processes on the same
+  // gene, may miss the cache and save at the same time) and renamed: a reader sees a whole file or none
+  char tmpl[4200];
+  if (snprintf(tmpl, sizeof tmpl, "%s.tmp.XXXXXX", path) >= (int)sizeof tmpl) return pgpu_ctx_fail(ctx, PGPU_EINVAL, "index path too long");
+  const int fd = mkstemp(tmpl);
+  if (fd < 0) return pgpu_ctx_fail(ctx, PGPU_EINVAL, "cannot create the index file");
+  std::string tmp = tmpl;
+  FILE* f = fdopen(fd, "wb");
+  if (!f) { close(fd); remove(tmp.c_str()); return pgpu_ctx_fail(ctx, PGPU_EINVAL, "cannot create the index file"); }
   const bool ok = fwrite(&h, sizeof h, 1, f) == 1 && fwrite(host.data(), 4, host.size(), f) == host.size();
   if (fclose(f) != 0 || !ok || rename(tmp.c_str(), path) != 0) { remove(tmp.c_str()); return pgpu_ctx_fail(ctx, PGPU_EDEVICE, "writing the index file failed"); }
   return PGPU_OK;
@@ -565,10 +585,15 @@ extern "C" int pgpu_index_load(pgpu_ctx* ctx, const char* path, const char* geno
   IndexFileHeader h;
   const size_t words = 2 * len + 1 + 2 * (size_t)KTAB_ENTRIES;
   std::vector<uint32_t> host;
-  bool ok = fread(&h, sizeof h, 1, f) == 1 && memcmp(h.magic, INDEX_MAGIC, 8) == 0 && h.version == 1 && h.ktab == KTAB &&
+  bool ok = fread(&h, sizeof h, 1, f) == 1 && memcmp(h.magic, INDEX_MAGIC, 8) == 0 && h.version == INDEX_VERSION && h.ktab == KTAB &&
             h.len == len && h.hash == fnv1a64(genomic, len);
   if (ok) { host.resize(words); ok = fread(host.data(), 4, words, f) == words && fgetc(f) == EOF; }
   fclose(f);
+  if (ok) ok = h.payload_hash == words_hash(host.data(), words);
+  // belt and braces: nothing that indexes the sequence or the suffix array may point outside
+  for (size_t i = 0; ok && i < len; ++i) ok = host[i] < len;                                   // suffix array
+  for (size_t i = 0; ok && i <= len; ++i) ok = host[len + i] <= len;                           // LCP
+  for (size_t i = 0; ok && i < 2 * (size_t)KTAB_ENTRIES; ++i) ok = host[2 * len + 1 + i] <= len;   // k-mer intervals
   if (!ok) return PGPU_EINVAL;
   pgpu_index* idx = new (std::nothrow) pgpu_index();
   if (!idx) return pgpu_ctx_fail(ctx, PGPU_ENOMEM, "out of host memory");
@@ -724,6 +749,8 @@ extern "C" int pgpu_pairing_plan_run(pgpu_ctx* ctx, pgpu_pairing_plan* p, const 
   p->n_cand = p->n_out = 0;
   p->have_pairs = false;
   if (p->n_pat == 0) return PGPU_OK;
+  pgpu_range_push("pairings");
+  struct PopAtExit { ~PopAtExit() { pgpu_range_pop(); } } pop_at_exit;
   if (p->ev[0]) TRY_HIP(hipEventRecord(p->ev[0], st));
   hipLaunchKernelGGL(pair_locate_kernel, pgrid, pblk, 0, st, ix->d_gen, n, ix->d_sa, ix->d_klo, ix->d_khi, p->d_pats, p->d_pat_off, prm, p->d_lo, p->d_hi, p->d_a);
   if (p->ev[1]) TRY_HIP(hipEventRecord(p->ev[1], st));
@@ -780,6 +807,8 @@ extern "C" int pgpu_pairing_plan_run_meg(pgpu_ctx* ctx, pgpu_pairing_plan* p, co
   int rc = PGPU_OK;
   hipStream_t st = pgpu_ctx_stream(ctx);
   const uint32_t np = (uint32_t)p->n_pat;
+  pgpu_range_push("meg");
+  struct PopAtExit { ~PopAtExit() { pgpu_range_pop(); } } pop_at_exit;
   if (!p->d_meg_scratch) {
     NEED(p->d_meg_scratch = plan_alloc<uint8_t>(p, 16, pgpu_meg_scratch_bytes(np)));
     NEED(p->d_meg_info = plan_alloc<uint8_t>(p, 17, (size_t)np * 16));

@@ -195,12 +195,13 @@ static int classify_uncached(const ef_seq* gs, int start, int end);
  * immutable for the whole run). */
 int ef_classify_intron(const ef_seq* gs, int start, int end) {
   const char* gen = gs->seq;
-  typedef struct { const char* gen; int start, end, type; } slot;
+  typedef struct { const char* gen; unsigned epoch; int start, end, type; } slot;
   static _Thread_local slot memo[1024];
+  const unsigned ep = ef_genomic_epoch_now();       /* (address, epoch): see ef_genomic_len */
   slot* m = &memo[((uint32_t)start * 2654435761u ^ (uint32_t)end * 40503u) >> 7 & 1023u];
-  if (m->gen == gen && m->start == start && m->end == end) return m->type;
+  if (m->gen == gen && m->epoch == ep && m->start == start && m->end == end) return m->type;
   const int type = classify_uncached(gs, start, end);
-  m->gen = gen; m->start = start; m->end = end; m->type = type;
+  m->gen = gen; m->epoch = ep; m->start = start; m->end = end; m->type = type;
   return type;
 }
 

@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <unistd.h>
+#include <time.h>
 
 #include "estfact.h"
 
@@ -228,6 +229,7 @@ void ef_free_inputs(ef_inputs* in) {
   for (size_t k = 0; k < in->n; ++k) ef_seq_free(in->list[k]);
   free(in->list);
   ef_seq_free(in->gen);
+  ef_genomic_epoch_bump();                   /* its address may come back with another gene behind it */
 }
 
 int ef_open_outputs(ef_outputs* o) {
@@ -257,16 +259,66 @@ void ef_close_outputs(ef_outputs* o) {
   fclose(o->fmeg.f); fclose(o->fpmeg.f); fclose(o->ftmeg.f); fclose(o->fintronic.f);
 }
 
+/* What the reference leaves on stderr when it ends (src/main-est-fact.c:321-335 + resource_usage_log,
+ * src/util.c:184-208): its five timers, "End", user / system time and memory, in its own line format
+ * (include/log.h: "* INFO (function        @ file:line ) message  ").  dist-scripts/pintron.py appends
+ * est-fact's stderr to the pipeline log and people read these lines there.  The timers keep the
+ * reference's names; what they cover here:
+ *   Suffix Tree   GPU runtime start-up + construction (or load) of the device index
+ *   Algorithm     pairings + MEGs of all sequences on the device (the prefetch stage's wall time)
+ *   Compositions  the per-EST pipeline (embeddings, DP batches, refinement) on the worker threads
+ *   IO            reading genomic.txt / ests.txt + writing the output files
+ *   Total         process start to files on disk */
+#include <sys/resource.h>
+static void ref_info(const char* func, const char* file, int line, const char* msg) {
+  char fn[17];
+  const size_t l = strlen(func);
+  for (size_t i = 0; i < 16; ++i) fn[i] = i < l ? func[i] : ' ';
+  if (l + 2 >= 16) fn[15] = fn[14] = '.';
+  fn[16] = '\0';
+  const size_t fl = strlen(file);
+  fprintf(stderr, "* INFO (%s@%20.20s:%-4d) %s  \n", fn, fl > 20 ? file + (fl - 20) : file, line, msg);
+}
+void ef_log_reference_timers(double suffix_tree_s, double algorithm_s, double compositions_s, double io_s, double total_s) {
+  if (getenv("PINTRON_NO_TIMER_LOG")) return;
+  static const char* names[5] = { "Suffix Tree", "Algorithm", "Compositions", "IO", "Total" };
+  const double v[5] = { suffix_tree_s, algorithm_s, compositions_s, io_s, total_s };
+  char msg[160];
+  for (int k = 0; k < 5; ++k) {
+    snprintf(msg, sizeof msg, "@Timer %-22s. Time elapsed: %15llu microsec", names[k], (unsigned long long)(v[k] > 0 ? v[k] * 1e6 : 0));
+    ref_info("main", "src/main-est-fact.c", 321 + k, msg);
+  }
+  ref_info("main", "src/main-est-fact.c", 335, "End");
+  struct rusage ru;
+  if (getrusage(RUSAGE_SELF, &ru) == 0) {
+    snprintf(msg, sizeof msg, "User time:   %10lds %7ldmicrosec.", (long)ru.ru_utime.tv_sec, (long)ru.ru_utime.tv_usec);
+    ref_info("resource_usage_log", "src/util.c", 187, msg);
+    snprintf(msg, sizeof msg, "System time: %10lds %7ldmicrosec.", (long)ru.ru_stime.tv_sec, (long)ru.ru_stime.tv_usec);
+    ref_info("resource_usage_log", "src/util.c", 188, msg);
+    unsigned size = 0;
+    FILE* pf = fopen("/proc/self/statm", "r");
+    if (pf && fscanf(pf, "%u", &size) == 1) snprintf(msg, sizeof msg, "Mem. used:   %10uKB", size);
+    else snprintf(msg, sizeof msg, "Mem. used:         NaN KB");
+    if (pf) fclose(pf);
+    ref_info("resource_usage_log", "src/util.c", 199, msg);
+  }
+}
+
+static double wall_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+
 /* main of est-fact (src/main-est-fact.c:90-339), one EST after the other, with the backend
  * supplied by the caller */
 int ef_run(int argc, char** argv, ef_backend* (*open_backend)(const ef_seq* gen), void (*close_backend)(ef_backend*)) {
   ef_inputs in;
+  const double t_start = wall_now();
   int rc = ef_load_inputs(argc, argv, &in);
   if (rc) return rc;
   ef_outputs out;
   if (ef_open_outputs(&out)) return 1;
+  const double t_loaded = wall_now();
   ef_backend* be = open_backend(in.gen);
   if (!be) { fprintf(stderr, "* FATAL cannot initialise the compute backend (no MI355X / library)\n"); return 1; }
+  const double t_index = wall_now();
   /* per-EST loop (:249-291) */
   bool reversed = false;
   for (size_t k = 0; k < in.n; ++k) {
@@ -284,8 +336,11 @@ int ef_run(int argc, char** argv, ef_backend* (*open_backend)(const ef_seq* gen)
     }
     ef_est_free(fe);
   }
+  const double t_done = wall_now();
   close_backend(be);
   ef_close_outputs(&out);
   ef_free_inputs(&in);
+  /* one EST after the other: pairings and compositions are not timed apart here */
+  ef_log_reference_timers(t_index - t_loaded, 0.0, t_done - t_index, (t_loaded - t_start) + (wall_now() - t_done), wall_now() - t_start);
   return 0;
 }

@@ -6,11 +6,40 @@
  *   - direct:  one C-ABI call per request (ef_gpu_open / ef_gpu_close); simple, used by the tests;
  *   - batched: requests of many EST fibres are collected and submitted together (ef_sched.c).
  */
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 
 #include "estfact.h"
 #include "ef_gpu.h"
+
+/* ---- PINTRON_DP_TRACE=<file>: every answered request with its answer ---------------------------------
+ * A debugging aid for parity hunts: tools/replay_dp_trace.py runs the recorded requests through the CPU
+ * oracle and names the answers that differ, which tells "a kernel gave a wrong answer" from "the host
+ * logic / the scheduler went wrong".  Record (little endian): u32 magic 'DPT1', u32 unit, i32 kind,
+ * u32 la, lb, p0, p1, p2, tail, i32 v[6], u32 n0, n1, then a[la], b[lb + min(tail, 2)], s0[n0], s1[n1]. */
+static FILE* trace_file;
+static pthread_mutex_t trace_mu = PTHREAD_MUTEX_INITIALIZER;
+static pthread_once_t trace_once = PTHREAD_ONCE_INIT;
+static void trace_open(void) {
+  const char* path = getenv("PINTRON_DP_TRACE");
+  if (path && path[0]) trace_file = fopen(path, "wb");
+}
+int ef_dp_trace_enabled(void) { pthread_once(&trace_once, trace_open); return trace_file != NULL; }
+void ef_dp_trace(const ef_dp_req* q, const ef_dp_res* r, uint32_t unit) {
+  if (!ef_dp_trace_enabled()) return;
+  const uint32_t tail = q->tail > 2 ? 2 : q->tail;
+  const uint32_t n0 = r->s0 ? (uint32_t)strlen(r->s0) : 0, n1 = r->s1 ? (uint32_t)strlen(r->s1) : 0;
+  const uint32_t head[9] = { 0x31545044u, unit, (uint32_t)q->kind, (uint32_t)q->la, (uint32_t)q->lb, q->p0, q->p1, q->p2, q->tail };
+  const uint32_t lens[2] = { n0, n1 };
+  pthread_mutex_lock(&trace_mu);
+  fwrite(head, 4, 9, trace_file); fwrite(r->v, 4, 6, trace_file); fwrite(lens, 4, 2, trace_file);
+  fwrite(q->a, 1, q->la, trace_file); fwrite(q->b, 1, q->lb + tail, trace_file);
+  if (n0) fwrite(r->s0, 1, n0, trace_file);
+  if (n1) fwrite(r->s1, 1, n1, trace_file);
+  pthread_mutex_unlock(&trace_mu);
+}
+void ef_dp_trace_flush(void) { if (trace_file) { pthread_mutex_lock(&trace_mu); fflush(trace_file); pthread_mutex_unlock(&trace_mu); } }
 
 int ef_gpu_device_from_env(void) {
   const char* d = getenv("PINTRON_GPU_DEVICE");
@@ -104,7 +133,9 @@ static int direct_dp(void* self, const ef_dp_req* q, ef_dp_res* res) {
   const int rc = pgpu_dp_batch(d->ctx, d->idx, d->jb.jobs, 1, d->jb.arena, d->jb.arena_len, &r, d->strings, d->strings_cap, &used);
   if (rc != PGPU_OK) { fprintf(stderr, "* FATAL pgpu_dp_batch: %s\n", pgpu_last_error(d->ctx)); return -1; }
   if (r.status != PGPU_OK) { fprintf(stderr, "* FATAL DP job of kind %d and size %zu x %zu exceeds the device limits\n", q->kind, q->la, q->lb); return -1; }
-  return ef_decode_result(q->kind, &r, d->strings, res);
+  const int drc = ef_decode_result(q->kind, &r, d->strings, res);
+  if (drc == 0) ef_dp_trace(q, res, 0);
+  return drc;
 }
 
 static int direct_dp_many(void* self, const ef_dp_req* reqs, ef_dp_res* res, size_t n) {
@@ -120,7 +151,7 @@ static int direct_dp_many(void* self, const ef_dp_req* reqs, ef_dp_res* res, siz
   if (rc != PGPU_OK) fprintf(stderr, "* FATAL pgpu_dp_batch: %s\n", pgpu_last_error(d->ctx));
   for (size_t k = 0; k < n && rc == PGPU_OK; ++k) {
     if (r[k].status != PGPU_OK) { fprintf(stderr, "* FATAL DP job of kind %d and size %zu x %zu exceeds the device limits\n", reqs[k].kind, reqs[k].la, reqs[k].lb); rc = -1; }
-    else rc = ef_decode_result(reqs[k].kind, &r[k], d->strings, &res[k]);
+    else { rc = ef_decode_result(reqs[k].kind, &r[k], d->strings, &res[k]); if (rc == PGPU_OK) ef_dp_trace(&reqs[k], &res[k], 0); }
   }
   free(r);
   return rc == PGPU_OK ? 0 : -1;

@@ -58,7 +58,9 @@ void ef_seq_free(ef_seq* s) {
 /* 6-mer index of the (final) genomic working sequence: one counting sort over the sequence */
 #define EF_KMER 6
 static int kmer_base(char c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : -1; }
+unsigned ef_genomic_epoch = 1;
 void ef_seq_index_kmers(ef_seq* gen) {
+  ef_genomic_epoch_bump();                   /* a new genomic sequence is about to be used */
   const size_t n = strlen(gen->seq);
   free(gen->kmer_first); free(gen->kmer_pos); free(gen->bps_memo);
   gen->bps_memo = (unsigned char*)calloc(n + 2, 1);

@@ -541,6 +541,7 @@ static void* service_main(void* arg) {
     pgpu_dp_plan* plan = NULL;
     const double t_a = now_s();
     me->phase_s[1] += t_a - t_idle - 0;        /* (includes the idle wait; corrected below) */
+    pgpu_range_push("dp batch (create, launch, sync, fetch)");
     int rc = pgpu_dp_plan_create_parts(me->ctx, sh->idx, parts, (size_t)nreq, &plan);
     const double t_b = now_s();
     if (rc == PGPU_OK) rc = pgpu_dp_plan_launch(me->ctx, plan);
@@ -565,6 +566,7 @@ static void* service_main(void* arg) {
       }
     }
     if (plan) pgpu_dp_plan_destroy(me->ctx, plan);
+    pgpu_range_pop();
     me->phase_s[5] += now_s() - t_d;
     if (rc != PGPU_OK) fprintf(stderr, "* FATAL DP batch failed: %s\n", pgpu_last_error(me->ctx));
     me->stats.dp_batches++; me->stats.dp_jobs += nj;
@@ -614,6 +616,7 @@ static int collect_dp(worker* w, lane* ln) {
   }
   ln->posted = false;
   const int rc = rq->rc;
+  const bool tracing = ef_dp_trace_enabled() != 0;
   if (rc == PGPU_OK) {
     size_t j = rq->base;
     for (size_t i = 0; i < ln->n_inflight; ++i) {
@@ -625,6 +628,7 @@ static int collect_dp(worker* w, lane* ln) {
           fprintf(stderr, "* FATAL DP job of kind %d (%zu x %zu) exceeds the device limits\n", f->reqs[k].kind, f->reqs[k].la, f->reqs[k].lb);
           f->rc = drc;
         }
+        else if (tracing) ef_dp_trace(&f->reqs[k], &f->ress[k], (uint32_t)f->unit);
       }
       f->state = F_RUNNABLE;
     }
@@ -834,7 +838,8 @@ static void bind_to_numa_node(int node) {
   cpu_set_t want;
   CPU_ZERO(&want);
   const char* lws = getenv("LOCAL_WORLD_SIZE");
-  const bool several_ranks = lws && atoi(lws) > 1;
+  /* PINTRON_SMT=1: every hardware thread of the node, as when several ranks share it (tools/sweep_threads.sh) */
+  const bool several_ranks = (lws && atoi(lws) > 1) || env_flag("PINTRON_SMT");
   int lo, hi, n = 0;                         /* "a-b,c,d-e" */
   for (;;) {
     if (fscanf(f, "%d", &lo) != 1) break;
@@ -932,7 +937,8 @@ static void* gpu_boot_main(void* arg) {
       if (b->idx_rc == PGPU_OK) { boot_service_contexts(b); return NULL; }
     }
     b->idx_rc = pgpu_index_build(b->ctx, b->gen, b->gen_len, &b->idx);
-    if (b->idx_rc == PGPU_OK && cache && cache[0] && pgpu_index_save(b->ctx, b->idx, b->gen, path) != PGPU_OK)
+    /* of a sharded run only rank 0 saves (all ranks built the same index) */
+    if (b->idx_rc == PGPU_OK && cache && cache[0] && ef_shard_rank == 0 && pgpu_index_save(b->ctx, b->idx, b->gen, path) != PGPU_OK)
       fprintf(stderr, "* WARN the index could not be saved to %s\n", path);
     if (b->idx_rc == PGPU_OK) boot_service_contexts(b);
   }
@@ -1077,6 +1083,9 @@ static void* prefetch_main(void* arg) {
   shared* sh = &s->sh;
   pgpu_pairing_params prm = { s->in.cfg.min_factor_len, 0, s->in.cfg.min_string_depth_rate };
   for (int c = 0; c < sh->n_pre; ++c) {
+    char rname[48];
+    snprintf(rname, sizeof rname, "prefetch chunk %d (pairings + MEGs)", c);
+    pgpu_range_push(rname);
     /* first step: the chunk's sequences go to the device here, chunk after chunk beside the workers
      * that already factorize the chunks before (they stay resident for the steps that follow) */
     int prc = s->pplan[c] ? PGPU_OK : make_pattern_plan(s, c);
@@ -1119,6 +1128,7 @@ static void* prefetch_main(void* arg) {
     else sh->ready_entries = sh->pre_lo[c + 1];
     pthread_cond_broadcast(&sh->ready_cv);
     pthread_mutex_unlock(&sh->mu);
+    pgpu_range_pop();
     if (prc != PGPU_OK) break;
   }
   s->pre_wall = now_s() - s->pre_t0;
@@ -1136,6 +1146,7 @@ static run_mark run_mark_now(void) {
 int ef_session_step(ef_session* s, ef_sched_stats* stats_out) {
   shared* sh = &s->sh;
   const double t0 = now_s();
+  pgpu_range_push("est-fact step");
   const bool step_rusage = getenv("PINTRON_STEP_RUSAGE") != NULL;
   run_mark ru0; if (step_rusage) ru0 = run_mark_now();
   free_unit_buffers(sh, false);
@@ -1222,6 +1233,8 @@ int ef_session_step(ef_session* s, ef_sched_stats* stats_out) {
   st.load_s = s->load_s; st.index_s = s->index_s; st.prefetch_s = s->pre_wall; st.workers_s = now_s() - t1;
   for (size_t u = 0; u < sh->n_units; ++u) if (sh->units[u].len[1]) ++st.aligned;
   if (stats_out) *stats_out = st;
+  ef_dp_trace_flush();
+  pgpu_range_pop();
   free(ws); free(th);
   if (step_rusage) {
     const run_mark ru1 = run_mark_now();
@@ -1349,6 +1362,7 @@ int ef_run_batched_stats(int argc, char** argv, ef_sched_stats* stats_out) {
    * exit (ef_leave_without_cleanup, set by the est-fact program) does not take the session apart
    * (200 000 sequences, fibre stacks, device pools: 0.3 s): the caller ends it with _exit. */
   if (!ef_leave_without_cleanup) ef_session_close(s);
+  ef_log_reference_timers(st.index_s, st.prefetch_s, st.workers_s, st.load_s + (m3.wall - m2.wall), now_s() - m0.wall);
   if (getenv("PINTRON_VERBOSE")) {
     fprintf(stderr, "* run: open %.3fs step %.3fs write %.3fs close %.3fs\n", m1.wall - m0.wall, m2.wall - m1.wall, m3.wall - m2.wall, now_s() - m3.wall);
     fprintf(stderr, "* cpu (all threads): open user %.2fs sys %.2fs, %ld page faults; step user %.2fs sys %.2fs, %ld page faults; write user %.2fs sys %.2fs\n",

@@ -76,9 +76,17 @@ typedef struct {
 /* length of the genomic sequence: strlen() over 200 kb costs microseconds and the refinement code
  * asks for it several times per intron, so the last answer is kept per thread.  Only for the
  * genomic string, which is immutable for the whole run. */
+/* Per-thread caches keyed on the genomic string's ADDRESS are only good while that genomic lives: a
+ * process that runs several genes one after the other (est-fact --genes, direct mode) gets the next
+ * gene's buffer at the same address from malloc.  Every load and every release of a genomic sequence
+ * moves this epoch on, and a cache entry is valid for the epoch it was made in. */
+extern unsigned ef_genomic_epoch;
+static inline unsigned ef_genomic_epoch_now(void) { return __atomic_load_n(&ef_genomic_epoch, __ATOMIC_ACQUIRE); }
+static inline void ef_genomic_epoch_bump(void) { __atomic_add_fetch(&ef_genomic_epoch, 1u, __ATOMIC_ACQ_REL); }
 static inline size_t ef_genomic_len(const char* gen) {
-  static _Thread_local const char* last; static _Thread_local size_t last_len;
-  if (last != gen) { last_len = strlen(gen); last = gen; }
+  static _Thread_local const char* last; static _Thread_local size_t last_len; static _Thread_local unsigned last_epoch;
+  const unsigned ep = ef_genomic_epoch_now();
+  if (last != gen || last_epoch != ep) { last_len = strlen(gen); last = gen; last_epoch = ep; }
   return last_len;
 }
 
@@ -328,6 +336,8 @@ void ef_classify_init(void);     /* loads the PWM tables once (call before threa
  * computed once per gene (a few threads, milliseconds) instead of once per candidate intron */
 void ef_classify_prepare(ef_seq* gen);
 
+/* the reference's closing stderr lines: five timers, "End", resource usage (ef_estfact.c) */
+void ef_log_reference_timers(double suffix_tree_s, double algorithm_s, double compositions_s, double io_s, double total_s);
 /* the whole est-fact process (src/main-est-fact.c:90-339); the caller supplies the backend */
 int ef_run(int argc, char** argv, ef_backend* (*open_backend)(const ef_seq* gen), void (*close_backend)(ef_backend*));
 

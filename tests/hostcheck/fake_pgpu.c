@@ -221,6 +221,43 @@ int pgpu_gather(pgpu_ctx* ctx, pgpu_comm* c, const void* send, uint64_t send_byt
   return rc;
 }
 
+/* fixed-size all-gather over the same "wire": a gather to a scratch buffer on every rank */
+int pgpu_allgather(pgpu_ctx* ctx, pgpu_comm* c, const void* send, uint64_t bytes, void* recv) {
+  (void)ctx;
+  const char* dir = getenv("TMPDIR") ? getenv("TMPDIR") : "/tmp";
+  char path[512], tmp[520];
+  const unsigned seq = c->seq++;
+  if (seq >= 2) { snprintf(path, sizeof path, "%s/pgpu-fake-%s-%u-seen-%d", dir, c->tag, seq - 2, c->rank); unlink(path); }
+  snprintf(path, sizeof path, "%s/pgpu-fake-%s-%u-%d", dir, c->tag, seq, c->rank);
+  snprintf(tmp, sizeof tmp, "%s.tmp", path);
+  FILE* f = fopen(tmp, "wb");
+  if (!f) return PGPU_EDEVICE;
+  if (bytes) fwrite(send, 1, bytes, f);
+  fclose(f);
+  rename(tmp, path);
+  for (int r = 0; r < c->world; ++r) {
+    snprintf(path, sizeof path, "%s/pgpu-fake-%s-%u-%d", dir, c->tag, seq, r);
+    FILE* g = NULL;
+    for (int tries = 0; tries < 30000 && !g; ++tries) { g = fopen(path, "rb"); if (!g) { struct timespec ts = { 0, 2000000 }; nanosleep(&ts, NULL); } }
+    if (!g) return PGPU_EDEVICE;
+    const int bad = bytes && fread((char*)recv + (size_t)r * bytes, 1, bytes, g) != bytes;
+    fclose(g);
+    if (bad) return PGPU_EDEVICE;
+  }
+  snprintf(path, sizeof path, "%s/pgpu-fake-%s-%u-seen-%d", dir, c->tag, seq, c->rank);
+  f = fopen(path, "wb"); if (f) fclose(f);
+  for (int r = 0; r < c->world; ++r) {
+    snprintf(path, sizeof path, "%s/pgpu-fake-%s-%u-seen-%d", dir, c->tag, seq, r);
+    for (int tries = 0; tries < 30000 && access(path, F_OK) != 0; ++tries) { struct timespec ts = { 0, 2000000 }; nanosleep(&ts, NULL); }
+  }
+  snprintf(path, sizeof path, "%s/pgpu-fake-%s-%u-%d", dir, c->tag, seq, c->rank);
+  unlink(path);
+  return PGPU_OK;
+}
+
+void pgpu_range_push(const char* name) { (void)name; }
+void pgpu_range_pop(void) { }
+const char* pgpu_build_info(void) { return "CPU stand-in of the C-ABI (tests/hostcheck/fake_pgpu.c)"; }
 int pgpu_host_alloc(pgpu_ctx* ctx, size_t bytes, void** out) { (void)ctx; *out = malloc(bytes ? bytes : 16); return *out ? PGPU_OK : PGPU_ENOMEM; }
 int pgpu_host_free(pgpu_ctx* ctx, void* q) { (void)ctx; free(q); return PGPU_OK; }
 int pgpu_pairings(pgpu_ctx* ctx, const pgpu_index* idx, const char* patterns, const uint64_t* off, size_t n, const pgpu_pairing_params* prm,

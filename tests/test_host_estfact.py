@@ -195,9 +195,11 @@ def test_work_budget_replaces_the_timeout(bins, tmp_path):
 
 def test_c_program_shards_one_gene_over_ranks(bins, tmp_path):
     """`est-fact --gpus=N` (pintron_amd/host/ef_multi.c): the program starts the other ranks itself,
-    each factorizes its range of the ESTs, rank 0 gathers the text of the six files through
-    pgpu_gather and writes what a single process writes.  Here over the CPU stand-in of the C-ABI,
-    whose gather goes through files; on the GPU box the same flow runs over RCCL."""
+    each factorizes its range of the ESTs, rank 0 gathers the factorization records and the processed
+    ESTs through pgpu_gather (ONE payload per rank, after an all-gather of status + sizes) and writes
+    what a single process writes; the MEG side files are written in place by every rank.  Here over the
+    CPU stand-in of the C-ABI, whose exchanges go through files; on the GPU box the same flow runs
+    over RCCL."""
     from pintron_amd import synth
     w = synth.make("C2", n_est=240, seed=9)
     one, many, envd = tmp_path / "one", tmp_path / "many", tmp_path / "env"
@@ -211,6 +213,34 @@ def test_c_program_shards_one_gene_over_ranks(bins, tmp_path):
         assert filecmp.cmp(one / f, many / f, shallow=False), f
         assert filecmp.cmp(one / f, envd / f, shallow=False), f
     assert os.path.getsize(one / "raw-multifasta-out.txt") > 10000
+    # PINTRON_SHARD_DIAGNOSTICS=0: the two files the pipeline reads, no MEG side files
+    nod = tmp_path / "nodiag"
+    synth.write_files(w, str(nod))
+    subprocess.run([bins["estfact_sched_check"], "--gpus=2"], cwd=nod, env=dict(e, PINTRON_SHARD_DIAGNOSTICS="0"), check=True,
+                   stderr=subprocess.DEVNULL)
+    for f in FILES[:2]:
+        assert filecmp.cmp(one / f, nod / f, shallow=False), f
+    assert not os.path.exists(nod / "megs.txt")
+    assert not [p for p in os.listdir(tmp_path) if p.startswith(".pintron-comm-id")], "rendezvous files left behind"
+
+
+@pytest.mark.parametrize("fault", ["1:open", "2:step", "1:abort", "0:step", "0:open"])
+def test_c_program_a_failing_rank_ends_all_ranks(bins, tmp_path, fault):
+    """A rank that cannot open its session, whose step fails, or that dies outright (abort) must not
+    leave its peers blocked in an exchange: every rank ends, est-fact exits non-zero, within seconds
+    (health markers before the communicator, status word in the first exchange, the parent's
+    watchdog; pintron_amd/host/ef_multi.c)."""
+    import time
+    from pintron_amd import synth
+    synth.write_files(synth.make("C2", n_est=90, seed=9), str(tmp_path))
+    e = dict(os.environ, TMPDIR=str(tmp_path), PINTRON_THREADS="2", PINTRON_FAULT_INJECT=fault)
+    t0 = time.time()
+    r = subprocess.run([bins["estfact_sched_check"], "--gpus=3"], cwd=tmp_path, env=e, stderr=subprocess.PIPE, text=True, timeout=60)
+    took = time.time() - t0
+    assert r.returncode != 0 and took < 10, (r.returncode, took, r.stderr[-1500:])
+    time.sleep(0.3)
+    left = subprocess.run(["pgrep", "-c", "-f", str(tmp_path)], capture_output=True, text=True).stdout.strip()
+    assert left in ("", "0"), "ranks left running: " + left
 
 
 def test_c_program_runs_many_genes(bins, tmp_path):
@@ -277,3 +307,24 @@ def test_region_start_copies_match_compiled_reference(bins, tmp_path):
         run(bins[which], my_dir, env)
         for f in FILES:
             assert filecmp.cmp(my_dir / f, ref_dir / f, shallow=False), (which, f)
+
+
+def test_closing_stderr_lines_have_the_reference_format(bins, tmp_path):
+    """The reference ends with its five timers, "End" and the resource usage on stderr
+    (src/main-est-fact.c:321-335, src/util.c:184-208; include/log.h gives the line format), and the
+    pipeline driver appends that to its log.  Same lines, same format, here."""
+    import re
+    for f in ("genomic.txt", "ests.txt"):
+        shutil.copy(os.path.join(GOLD, f), tmp_path)
+    r = subprocess.run([bins["estfact_sched_check"]], cwd=tmp_path, env=dict(os.environ, PINTRON_THREADS="2"),
+                       stderr=subprocess.PIPE, text=True, check=True)
+    tail = r.stderr.splitlines()[-9:]
+    names = ["Suffix Tree", "Algorithm", "Compositions", "IO", "Total"]
+    for k, nm in enumerate(names):
+        assert re.fullmatch(r"\* INFO \(main            @ src/main-est-fact.c:%d \) @Timer %-22s\. Time elapsed: +\d+ microsec  " % (321 + k, nm),
+                            tail[k]), tail[k]
+        assert len(tail[k].split("Time elapsed: ")[1]) == len("%15d microsec  " % 0)
+    assert tail[5] == "* INFO (main            @ src/main-est-fact.c:335 ) End  "
+    assert re.fullmatch(r"\* INFO \(resource_usage\.\.@          src/util.c:187 \) User time:   +\d+s +\d+microsec\.  ", tail[6]), tail[6]
+    assert re.fullmatch(r"\* INFO \(resource_usage\.\.@          src/util.c:188 \) System time: +\d+s +\d+microsec\.  ", tail[7]), tail[7]
+    assert re.fullmatch(r"\* INFO \(resource_usage\.\.@          src/util.c:199 \) Mem\. used: +\d+KB  ", tail[8]), tail[8]

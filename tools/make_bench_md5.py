@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Build container: the reference's raw-multifasta-out.txt for the EXACT batch bench.py times at
-N = 1 (C3: 200 kb x 100 000 ESTs, seed 3), as md5 -> tests/golden/bench_md5.json.
+"""Build container: the reference's raw-multifasta-out.txt for the EXACT batches bench.py times at
+N = 1 (C3: 200 kb x 100 000 ESTs, seed 3; C2 in full; one gene of C4; one GPU's eighth of C5), as md5 ->
+tests/golden/bench_md5.json.
 
 The reference est-fact is one process per gene; ESTs are independent given the genomic sequence, so
 the batch is cut into chunks of whole ESTs, oracle/_ref/est-fact-core (reference object code) runs on
@@ -51,18 +52,28 @@ def reference_text(w, chunks, workers):
     return out
 
 
+# the per-GPU batches bench.py times (bench.py: PER_GPU): C2 in full, C3, one gene of C4, one GPU's eighth of C5
+DEFAULT_N = {"C2": 1_000, "C3": 100_000, "C4": 62_500, "C5": 250_000}
+
+
 def main():
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else synth.CONFIGS["C3"]["n_est"]
-    seed = synth.CONFIGS["C3"]["seed"]
+    """make_bench_md5.py [WORKLOAD [N [SEED]]]  (a bare number = C3 with that many ESTs, as before)"""
+    args = sys.argv[1:]
+    name = "C3"
+    if args and args[0] in synth.CONFIGS:
+        name = args.pop(0)
+    n = int(args[0]) if args else DEFAULT_N[name]
+    seed = int(args[1]) if len(args) > 1 else synth.CONFIGS[name]["seed"]
     t0 = time.time()
-    w = synth.make("C3", n_est=n, seed=seed)
-    texts = reference_text(w, chunks=64, workers=max(1, (os.cpu_count() or 2) - 1))
+    w = synth.make(name, n_est=n, seed=seed)
+    texts = reference_text(w, chunks=min(64, max(1, n // 200)), workers=max(1, (os.cpu_count() or 2) - 1))
     path = os.path.join(ROOT, "tests", "golden", "bench_md5.json")
     data = json.load(open(path)) if os.path.exists(path) else {}
-    data["C3:%d:seed%d" % (n, seed)] = {f: hashlib.md5(t).hexdigest() for f, t in texts.items()}
-    data["C3:%d:seed%d" % (n, seed)]["aligned"] = texts["processed-ests.txt"].count(b">")
+    key = "%s:%d:seed%d" % (name, n, seed)
+    data[key] = {f: hashlib.md5(t).hexdigest() for f, t in texts.items()}
+    data[key]["aligned"] = texts["processed-ests.txt"].count(b">")
     json.dump(data, open(path, "w"), indent=1, sort_keys=True)
-    print("C3 x %d (seed %d): %s  [%.0f s]" % (n, seed, data["C3:%d:seed%d" % (n, seed)], time.time() - t0))
+    print("%s x %d (seed %d): %s  [%.0f s wall]" % (name, n, seed, data[key], time.time() - t0))
 
 
 if __name__ == "__main__":

@@ -9,7 +9,7 @@ export PMC_ESTS=$N
 mkdir -p gpurun_out
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/pmc_$C
-  rocprofv3 --pmc $C --output-format csv -d gpurun_out/pmc_$C -o pmc -- python3 bench.py --steps 1 --warmup 0 --no-cpu --ests $N > gpurun_out/pmc_$C.json 2> gpurun_out/pmc_$C.err || { tail -5 gpurun_out/pmc_$C.err; exit 1; }
+  rocprofv3 --pmc $C --output-format csv -d gpurun_out/pmc_$C -o pmc -- python3 bench.py --steps 1 --warmup 0 --no-cpu --no-oneshot --ests $N > gpurun_out/pmc_$C.json 2> gpurun_out/pmc_$C.err || { tail -5 gpurun_out/pmc_$C.err; exit 1; }
 done
 python3 - <<'PY'
 import csv, glob, json, collections
