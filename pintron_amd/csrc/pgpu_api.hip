@@ -48,6 +48,7 @@ struct pgpu_ctx {
   // the naps cost latency).  PGPU_WAIT=<us> sets the nap, 0 = blocking-sync event, -1 = spin.
   hipEvent_t ev_done = nullptr;
   long wait_poll_us = 20;
+  int poison = -1;           // PGPU_POISON=<0..255>: fill strings + workspace of every DP plan with that byte first
   // pinned staging for the device->host result copies (pageable copies block and spin inside HIP)
   void* pin[2] = {nullptr, nullptr};
   size_t pin_cap[2] = {0, 0};
@@ -215,6 +216,7 @@ extern "C" int pgpu_init(int device, pgpu_ctx** out) {
     if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete ctx; return PGPU_EDEVICE; }
   { const char* f = getenv("PGPU_FANOUT"); ctx->fanout = !(f && f[0] == '0'); }
   { const char* f = getenv("PGPU_WAIT"); if (f) ctx->wait_poll_us = atol(f); }
+  { const char* f = getenv("PGPU_POISON"); if (f && f[0]) ctx->poison = atoi(f) & 255; }
   { const char* f = getenv("PGPU_PACK"); if (f && atoi(f) == 0) ctx->packed = false; }
   { const char* f = getenv("PGPU_MERGED"); if (f && atoi(f) >= 0 && atoi(f) <= 2) ctx->merged = atoi(f); }
   { const char* f = getenv("PGPU_STREAMS"); const int v = f ? atoi(f) : 0; if (v >= 1 && v <= pgpu_ctx::NAUX) { ctx->n_aux = v; ctx->packed = false; } }
@@ -629,6 +631,12 @@ extern "C" int pgpu_dp_plan_create_parts(pgpu_ctx* ctx, const pgpu_index* idx, c
   if (n_jobs) memcpy(p->h_up + off_results, p->prefill.data(), n_jobs * sizeof(DevResult));
   const hipError_t e = hipMemcpyAsync(p->d_base, p->h_up, p->up_bytes, hipMemcpyHostToDevice, ctx->stream);
   if (e != hipSuccess) { plan_free(p); return set_err(ctx, PGPU_EDEVICE, "upload failed: %s", hipGetErrorString(e)); }
+  if (ctx->poison >= 0) {
+    // debugging aid (PGPU_POISON=<byte>): what the kernels are going to write -- strings, traceback workspace --
+    // starts from a known pattern instead of whatever the previous batch left there; an answer that changes
+    // with the pattern comes from a read of memory nothing wrote (tools/stress_parity.py --poison)
+    if (hipMemsetAsync(p->d_base + off_strs, ctx->poison, total - off_strs, ctx->stream) != hipSuccess) { plan_free(p); return set_err(ctx, PGPU_EDEVICE, "poison fill failed"); }
+  }
   *out = p;
   return PGPU_OK;
 }

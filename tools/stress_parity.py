@@ -71,6 +71,9 @@ def keep_failure(out, tag, run_dir, ref_dir, env, stderr, want, got, trace):
     return report
 
 
+POISON = []
+
+
 def stress(kind, runs_per_env, out, n_c3, matrix, log):
     work = tempfile.mkdtemp(prefix="pintron_stress_%s_" % kind)
     ref_dir, run_dir = os.path.join(work, "ref"), os.path.join(work, "run")
@@ -90,6 +93,9 @@ def stress(kind, runs_per_env, out, n_c3, matrix, log):
                 if os.path.exists(p):
                     os.remove(p)
             e = dict(os.environ, PINTRON_VERBOSE="1", **env)
+            if POISON:
+                e["PGPU_POISON"] = POISON[n_runs % len(POISON)]
+                env = dict(env, PGPU_POISON=e["PGPU_POISON"])
             trace = None
             if k % 2 == 1:
                 trace = os.path.join(work, "trace.bin")
@@ -115,8 +121,13 @@ def main():
     ap.add_argument("--c3-ests", type=int, default=2000)
     ap.add_argument("--envs", type=int, default=len(MATRIX), help="use the first N environments of the matrix")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "stress"))
+    ap.add_argument("--poison", default=None, help="comma-separated PGPU_POISON bytes cycled over the runs (e.g. 255,165,1): the "
+                    "DP plans' strings and traceback workspace start from that pattern -- an answer that depends on it is a read of "
+                    "memory nothing wrote")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
+    if args.poison:
+        POISON.extend(args.poison.split(","))
     logf = open(os.path.join(args.out, "stress.log"), "a")
 
     def log(msg):
