@@ -48,6 +48,7 @@ struct pgpu_ctx {
   // the naps cost latency).  PGPU_WAIT=<us> sets the nap, 0 = blocking-sync event, -1 = spin.
   hipEvent_t ev_done = nullptr;
   long wait_poll_us = 20;
+  bool lcf_sa = true;        // longest common factors of genomic prefixes from the suffix array (PGPU_LCF_SA=0: always the DP kernel)
   int poison = -1;           // PGPU_POISON=<0..255>: fill strings + workspace of every DP plan with that byte first
   // pinned staging for the device->host result copies (pageable copies block and spin inside HIP)
   void* pin[2] = {nullptr, nullptr};
@@ -216,6 +217,7 @@ extern "C" int pgpu_init(int device, pgpu_ctx** out) {
     if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete ctx; return PGPU_EDEVICE; }
   { const char* f = getenv("PGPU_FANOUT"); ctx->fanout = !(f && f[0] == '0'); }
   { const char* f = getenv("PGPU_WAIT"); if (f) ctx->wait_poll_us = atol(f); }
+  { const char* f = getenv("PGPU_LCF_SA"); if (f && f[0] == '0') ctx->lcf_sa = false; }
   { const char* f = getenv("PGPU_POISON"); if (f && f[0]) ctx->poison = atoi(f) & 255; }
   { const char* f = getenv("PGPU_PACK"); if (f && atoi(f) == 0) ctx->packed = false; }
   { const char* f = getenv("PGPU_MERGED"); if (f && atoi(f) >= 0 && atoi(f) <= 2) ctx->merged = atoi(f); }
@@ -298,7 +300,8 @@ struct pgpu_dp_plan {
   uint8_t* h_up = nullptr; uint8_t* h_down = nullptr;
   size_t up_bytes = 0, off_results = 0, down_bytes = 0;
   // merged launch (wave_jobs_kernel): segments = the common row classes of the wave-per-job families
-  int n_segs = 0, seg_family[6] = {0}, seg_start[6] = {0}, seg_count[6] = {0};
+  int n_segs = 0, seg_family[MAX_WAVE_SEGS] = {0}, seg_start[MAX_WAVE_SEGS] = {0}, seg_count[MAX_WAVE_SEGS] = {0};
+  LcfIndexView lcf_ix{};       // the index view the suffix-array LCF jobs search (one index per plan)
   int merged_group = -1;       // index of the pseudo group that carries its timing and accounting
   // ... and, with the batch kernel, the one-job-per-workgroup BORDERS / AFFIX jobs
   bool batch = false;
@@ -351,6 +354,8 @@ extern "C" int pgpu_dp_plan_create_parts(pgpu_ctx* ctx, const pgpu_index* idx, c
 
   const uint8_t* d_gen = idx ? pgpu_index_genomic(idx) : nullptr;
   const size_t gen_len = idx ? pgpu_index_length(idx) : 0;
+  p->lcf_ix = pgpu_index_lcf_view(idx);
+  const bool lcf_sa = ctx->lcf_sa && idx && p->lcf_ix.focc && p->lcf_ix.rmq;
   p->owner = ctx;
   p->pooled = pgpu_ctx_pool_acquire(ctx, 0);
 
@@ -398,9 +403,22 @@ extern "C" int pgpu_dp_plan_create_parts(pgpu_ctx* ctx, const pgpu_index* idx, c
         k.size = (2ull * ub + 1 >= n) ? (uint64_t)la * lb : (uint64_t)m * (2ull * ub + 1);
         break;
       }
-      case PGPU_DP_LCF:
+      case PGPU_DP_LCF: {
         if (lb > 65535u || la >= (1u << 28)) continue;
-        k.family = KF_LCF; k.R = 0; k.size = (uint64_t)la * lb; break;
+        k.family = KF_LCF; k.R = 0; k.size = (uint64_t)la * lb;
+        // the small-exon search's question -- a prefix of the genomic sequence against a few dozen EST
+        // characters -- is answered from the suffix array when exact matching is all there is to it: both
+        // strings upper-case ACGT (no N wildcard can fire) and s2 short enough for one lane per start
+        if (lcf_sa && ag && !bg && in.a_off == 0 && la <= p->lcf_ix.first_bad && lb <= 64u) {
+          const unsigned char* b = (const unsigned char*)parts[part_i].arena + in.b_off;
+          bool acgt = true;
+          for (uint32_t q = 0; q < lb && acgt; ++q) acgt = b[q] == 'A' || b[q] == 'C' || b[q] == 'G' || b[q] == 'T';
+          if (acgt) k.family = KF_LCFSA;
+        }
+        // two short strings: one wave (a lane per diagonal) instead of a workgroup and an atomic per job
+        if (k.family == KF_LCF && ctx->lcf_sa && (uint64_t)la * lb <= 16384u && la + lb <= 4096u) k.family = KF_LCFW;
+        break;
+      }
       case PGPU_DP_BORDERS:
         // only the first and the last t_win = min(len_p + max_errs, len_t) characters of t are swept
         // (src/refine.c:117-121): t may be a whole intron of any length the index can hold
@@ -430,7 +448,7 @@ extern "C" int pgpu_dp_plan_create_parts(pgpu_ctx* ctx, const pgpu_index* idx, c
       const uint32_t mag = 63u - (uint32_t)__builtin_clzll(k.size | 1ull);  // floor(log2(size)), 0..63
       return ((uint32_t)k.family << 10) | ((7u - rcls) << 6) | (63u - mag);   // long jobs first
     };
-    constexpr uint32_t NKEYS = 8u << 10;
+    constexpr uint32_t NKEYS = (uint32_t)KF_COUNT << 10;
     std::vector<uint32_t> start(NKEYS + 1, 0);
     std::vector<uint32_t> kk(v.size());
     for (size_t q = 0; q < v.size(); ++q) { kk[q] = key_of(v[q]); ++start[kk[q] + 1]; }
@@ -465,7 +483,7 @@ extern "C" int pgpu_dp_plan_create_parts(pgpu_ctx* ctx, const pgpu_index* idx, c
     } else if (k.family == KF_LCF) {
       ++nkeys;
       p->lcf_out.push_back(k.j.out_idx);
-    }
+    }                                           // (KF_LCFSA: no workspace, the wave writes its result itself)
     ws = (ws + 15) & ~(size_t)15;
   }
   p->ws_bytes = ws; p->strs_bytes = strs; p->n_keys = nkeys; p->n_dev_jobs = v.size();
@@ -496,6 +514,9 @@ extern "C" int pgpu_dp_plan_create_parts(pgpu_ctx* ctx, const pgpu_index* idx, c
       if (k.family == KF_ALIGN) job_bytes += la * lb + 3 * (la + lb);     // + directions read back, two strings
       if (k.family == KF_GAP) job_bytes += 3 * la * lb + 3 * (la + lb);
       if (k.family == KF_BORDERS) job_bytes += 2 * 8 * la;
+      // suffix-array search: s2, and per lane about eight table probes, a few suffix-array / sequence probes of the
+      // bisection and the range minima, and the characters of one direct comparison
+      if (k.family == KF_LCFSA) job_bytes = lb + 64u * 96u;
       g.cells += job_cells; g.algo_bytes += job_bytes;
       g.max_rows = std::max(g.max_rows, (uint32_t)la);
       if (k.R >= (k.family == KF_GAP ? 8u : 32u)) { ++g.n_big; g.cells_big += job_cells; g.algo_big += job_bytes; }   // (the slow GAP / BORDERS groups ignore it)
@@ -509,7 +530,7 @@ extern "C" int pgpu_dp_plan_create_parts(pgpu_ctx* ctx, const pgpu_index* idx, c
     g.count = j - i;
     char nm[64];
     static const char* fam[] = {"lev_wave<ALIGN>", "gap_wave", "lev_wave<ED>", "lev_wave<KBAND>", "lcf",
-                                "borders_coop", "affix_coop"};
+                                "borders_coop", "affix_coop", "lcf_sa", "lcf_small"};
     if (g.family == KF_BORDERS && g.R == 1) snprintf(nm, sizeof nm, "lev_wave<BORDERS,R=1>");
     else if (g.family == KF_AFFIX && g.R == 1) snprintf(nm, sizeof nm, "lev_wave<AFFIX,R=1>");
     else if (g.family == KF_AFFIX && g.R == (int)ROW_CLASS_STRIPS) snprintf(nm, sizeof nm, "lev_wave<AFFIX,strips>");
@@ -527,14 +548,14 @@ extern "C" int pgpu_dp_plan_create_parts(pgpu_ctx* ctx, const pgpu_index* idx, c
   if (ctx->merged) {
     // the common row classes of the wave-per-job families run in one launch (wave_jobs_kernel); the
     // groups keep their BIG part (first n_big jobs).  Long-running families first.
-    static const int order_fam[6] = { KF_ALIGN, KF_GAP, KF_KBAND, KF_BORDERS, KF_AFFIX, KF_ED };
+    static const int order_fam[8] = { KF_ALIGN, KF_GAP, KF_KBAND, KF_BORDERS, KF_AFFIX, KF_LCFSA, KF_LCFW, KF_ED };
     Group m{};
     m.family = KF_COUNT; m.kind = PGPU_DP_ALIGN; m.name = "wave_jobs";
     for (int f : order_fam)
       for (auto& g : p->groups) {
         if (g.family != f || g.traceback) continue;
         const bool wave_family = (f == KF_BORDERS || f == KF_AFFIX) ? g.R == 1 : g.R == 0;
-        if (!wave_family || p->n_segs >= 6) continue;
+        if (!wave_family || p->n_segs >= MAX_WAVE_SEGS) continue;
         const size_t big = (f == KF_BORDERS || f == KF_AFFIX) ? 0 : g.n_big;
         if (g.count <= big) continue;
         p->seg_family[p->n_segs] = f; p->seg_start[p->n_segs] = (int)(g.first + big); p->seg_count[p->n_segs] = (int)(g.count - big);
@@ -668,6 +689,7 @@ extern "C" int pgpu_dp_plan_launch(pgpu_ctx* ctx, pgpu_dp_plan* p) {
         case KF_ALIGN: return 5000;
         case KF_GAP: return 4000;
         case KF_LCF: return 3000;
+        case KF_LCFSA: case KF_LCFW: return 2500;
         case KF_KBAND: return 2000;
         default: return 1000;
       }
@@ -718,10 +740,10 @@ extern "C" int pgpu_dp_plan_launch(pgpu_ctx* ctx, pgpu_dp_plan* p) {
         case KF_COUNT:
           if (p->batch) {
             if (!launch_dp_batch(p->d_jobs, p->n_segs, p->seg_family, p->seg_start, p->seg_count, p->bc_start, p->bc_count,
-                                 p->bc_max_rows, p->ac_start, p->ac_count, p->d_results, p->d_ws, p->d_strs, st))
+                                 p->bc_max_rows, p->ac_start, p->ac_count, p->d_results, p->d_ws, p->d_strs, p->lcf_ix, st))
               return set_err(ctx, PGPU_EDEVICE, "batch launch: LDS budget exceeded");
           } else {
-            launch_wave_jobs(p->d_jobs, p->n_segs, p->seg_family, p->seg_start, p->seg_count, p->d_results, p->d_ws, p->d_strs, st);
+            launch_wave_jobs(p->d_jobs, p->n_segs, p->seg_family, p->seg_start, p->seg_count, p->d_results, p->d_ws, p->d_strs, p->lcf_ix, st);
           }
           break;
         case KF_ALIGN: case KF_ED: case KF_BORDERS: case KF_AFFIX: case KF_KBAND:
@@ -733,6 +755,11 @@ extern "C" int pgpu_dp_plan_launch(pgpu_ctx* ctx, pgpu_dp_plan* p) {
         case KF_LCF:
           launch_lcf(jobs, n, g.max_chunks, g.max_l2, p->d_keys + key_of[gi], st);
           break;
+        case KF_LCFSA: case KF_LCFW: {       // a launch of their own only with PGPU_MERGED=0
+          const int fam1 = g.family, start1 = (int)g.first, count1 = n;
+          launch_wave_jobs(p->d_jobs, 1, &fam1, &start1, &count1, p->d_results, p->d_ws, p->d_strs, p->lcf_ix, st);
+          break;
+        }
         default: break;
       }
       if (g.ev1) HIP_TRY(ctx, hipEventRecord(g.ev1, st));

@@ -303,11 +303,18 @@ __device__ __forceinline__ void lev_sweep(const Operand rows, const uint32_t nr,
   uint32_t out = 0;                     // (value of the strip's last row) | (column char << 24)
   constexpr uint32_t EB = R <= 4 ? 1u : R / 4;
 
-  for (uint32_t s0 = 0; s0 < steps; s0 += 64) {
+  // the column characters of chunk c+1 are requested while chunk c is swept (the load would otherwise sit
+  // at the head of every chunk's dependent chain: ~1 us of L2/HBM latency per 64 steps)
+  auto feed_of = [&](const uint32_t s0) -> uint32_t {
     const uint32_t jc = s0 + lane;      // column jc+1 enters lane 0 at step jc
     uint32_t top = jc + 1u;             // M[0][jc+1]
     if constexpr (BAND) { if (top > band_k) top = BAND_INF; }
-    uint32_t feed = top | ((jc < nc ? cols.at(jc) : PAD_COL) << 24);
+    return top | ((jc < nc ? cols.at(jc) : PAD_COL) << 24);
+  };
+  uint32_t feed_next = feed_of(0);
+  for (uint32_t s0 = 0; s0 < steps; s0 += 64) {
+    uint32_t feed = feed_next;
+    feed_next = feed_of(s0 + 64u);
     const uint32_t tmax = (min(64u, steps - s0) + 7u) & ~7u;   // whole groups of 8; steps past the end touch no cell
     for (uint32_t t0 = 0; t0 < tmax; t0 += 8) {
 #pragma unroll
@@ -780,6 +787,7 @@ __device__ __forceinline__ void lev_sweep_coop(const Operand rows, const uint32_
   // No per-step LDS access, scalar round trip or branch on the wave number.  A wave's first cell
   // lies in chunk w; it looks at the array one chunk earlier for the step before its first.
   uint32_t hout = 0, prev = 0;
+  uint32_t feed_next = (lane + 1u) | ((lane < nc ? cols.at(lane) : PAD_COL) << 24);   // wave 0: columns of chunk 0
   uint32_t* hand_in = hand + (w > 0 ? (w - 1) * 128u : 0u);
   uint32_t* hand_out = hand + (w + 1 < (uint32_t)COOP_W ? w : 0u) * 128u;
 
@@ -791,8 +799,9 @@ __device__ __forceinline__ void lev_sweep_coop(const Operand rows, const uint32_
       const uint32_t tmax = (min(64u, steps - s0) + 7u) & ~7u;   // whole groups of 8; steps past the end touch no cell
       uint32_t feed;
       if (w == 0) {
-        const uint32_t jc = s0 + lane;                       // column jc+1 enters lane 0 at step jc
-        feed = (jc + 1u) | ((jc < nc ? cols.at(jc) : PAD_COL) << 24);
+        feed = feed_next;                                    // requested one chunk ago (see lev_sweep)
+        const uint32_t jn = s0 + 64u + lane;
+        feed_next = (jn + 1u) | ((jn < nc ? cols.at(jn) : PAD_COL) << 24);
       } else {
         // the producer ran the same tmax steps on this chunk: its step t is in lane 64-tmax+t, the
         // last step of the chunk before in lane 63-tmax -- or, after a full chunk, in lane 63 of
@@ -1078,9 +1087,11 @@ __device__ __forceinline__ void gap_wave_body(const DevJob& job, DevResult* res,
     uint8_t* dirs = ws + job.ws_off;
     // per 64-step chunk the column characters sit in `feed` (lane t = step t), which moves one lane
     // down per step: lane 0 always holds the current one (see lev_sweep)
+    uint32_t feed_next = lane < m ? job.b[lane] : PAD_COL;        // requested one chunk ahead (see lev_sweep)
     for (uint32_t s0 = 0; s0 < steps; s0 += 64) {
-      const uint32_t jc = s0 + lane;
-      uint32_t feed = jc < m ? job.b[jc] : PAD_COL;
+      uint32_t feed = feed_next;
+      const uint32_t jn = s0 + 64u + lane;
+      feed_next = jn < m ? job.b[jn] : PAD_COL;
       const uint32_t tmax = (min(64u, steps - s0) + 7u) & ~7u;   // whole groups of 8; steps past the end touch no cell
       for (uint32_t t0 = 0; t0 < tmax; t0 += 8) {
 #pragma unroll
@@ -1267,6 +1278,148 @@ __device__ __forceinline__ void gap_traceback_wave(const DevJob& job, DevResult*
 }
 
 // ---------------------------------------------------------------------------------------------
+// find_longest_common_factor_dp (src/factorization-refinement.c:255-316) from the suffix array.
+// The small-exon search asks for the longest common factor of the WHOLE genomic prefix T[0..G) and at most
+// 46 characters of the EST (:532): 46 x G cells per call in the reference (and in lcf_kernel), two calls per
+// EST -- 9 M cells each on a 200 kb gene, 46 M on a 1 Mb one.  With the index resident the question is
+// 64 pattern searches: lane i2 looks for the longest prefix of s2[i2..] that occurs in T and ENDS before G,
+//   l <= 8     first_occ_l[code] <= G - l          (a table of first occurrences per l-mer: one probe per l,
+//                                                   all eight independent of each other)
+//   l  > 8     the interval of the 8-mer in the suffix array, narrowed one character at a time by bisection
+//              (a handful of suffixes on a gene-sized sequence); "some occurrence ends before G" is
+//              min(SA[lo..hi)) <= G - l, a range minimum read off a sparse table; as soon as one suffix is
+//              left the rest is a direct comparison of the two strings.
+// "Valid at l + 1" implies "valid at l", so a lane stops at its first failure.  The reference keeps the FIRST
+// maximum in (i1, i2) scan order = the longest factor with the smallest start in T, then in s2: every lane
+// carries the smallest start of its best length and the wave agrees on (max length, min start, min lane).
+// Only exact matching is expressed this way: the library sends a job here when T[0..G) and s2 consist of
+// upper-case A, C, G, T alone (no N wildcard can fire: Ns_ALWAYS_MATCH_FOR_LCS, :74), and to lcf_kernel otherwise.
+// ---------------------------------------------------------------------------------------------
+// find_longest_common_factor_dp of two SHORT strings (the exon ends the small-exon search compares,
+// src/factorization-refinement.c:690-718: at most 23 x 23 cells; nine jobs in ten of a C3 batch): one wave,
+// lane = diagonal, in rounds of 64 diagonals; N wildcard and first-maximum rule as in lcf_kernel (same key).
+// These used to get a workgroup, an atomic and a host-side decode each, in a launch of their own.
+__device__ __forceinline__ unsigned long long lcf_key(uint32_t len, uint32_t occ1, uint32_t occ2);
+__device__ __noinline__ void lcf_small_wave_body(const DevJob& job, DevResult* res, const uint32_t lane) {
+  const uint32_t l1 = job.la, l2 = job.lb;
+  const uint8_t* __restrict__ s1 = job.a; const uint8_t* __restrict__ s2 = job.b;
+  unsigned long long best = 0;
+  if (l1 != 0 && l2 != 0) {
+    const uint32_t ndiag = l1 + l2 - 1;
+    for (uint32_t dg0 = 0; dg0 < ndiag; dg0 += 64) {
+      const uint32_t dg = dg0 + lane;
+      if (dg < ndiag) {
+        // cells of this diagonal: i2 from max(0, l2-1-dg), i1 = i2 + dg - (l2-1)
+        const uint32_t i2_lo = dg < l2 - 1 ? l2 - 1 - dg : 0;
+        const int32_t shift = (int32_t)dg - (int32_t)(l2 - 1);
+        uint32_t i2_hi = l2;
+        if ((int32_t)l1 - shift < (int32_t)i2_hi) i2_hi = (uint32_t)((int32_t)l1 - shift);
+        uint32_t run = 0, brun = 0, bend = 0;
+        for (uint32_t i2 = i2_lo; i2 < i2_hi; ++i2) {
+          const uint32_t c1 = s1[(int32_t)i2 + shift], c2 = s2[i2];
+          run = (c1 == c2 || is_n(c1) || is_n(c2)) ? run + 1 : 0;
+          if (run > brun) { brun = run; bend = i2; }
+        }
+        if (brun > 0) {
+          const uint32_t occ2 = bend + 1 - brun;
+          const unsigned long long key = lcf_key(brun, (uint32_t)((int32_t)occ2 + shift), occ2);
+          best = key > best ? key : best;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) { const unsigned long long x = __shfl_xor(best, o); best = x > best ? x : best; }
+  if (lane == 0) {
+    res->status = 0;
+    res->v[0] = (int32_t)(best >> 44);
+    res->v[1] = best ? (int32_t)(0x0FFFFFFFu - (uint32_t)((best >> 16) & 0x0FFFFFFFu)) : 0;
+    res->v[2] = best ? (int32_t)(0xFFFFu - (uint32_t)(best & 0xFFFFu)) : 0;
+  }
+}
+
+__device__ __forceinline__ uint32_t lcfsa_rmq(const LcfIndexView& ix, uint32_t lo, uint32_t hi) {   // min(sa[lo..hi)), hi > lo
+  const uint32_t len = hi - lo;
+  const uint32_t j = 31u - (uint32_t)__builtin_clz(len);
+  const uint32_t* lv = j == 0 ? ix.sa : ix.rmq + (size_t)(j - 1) * ix.n;
+  return min(lv[lo], lv[hi - (1u << j)]);
+}
+
+__device__ __noinline__ void lcfsa_wave_body(const DevJob& job, DevResult* res, const LcfIndexView& ix, const uint32_t lane) {
+  const uint32_t G = job.la, l2 = job.lb;
+  const uint8_t* __restrict__ s2 = job.b;
+  const uint8_t* __restrict__ T = ix.T;
+  uint32_t best = 0, bt = 0;
+  if (lane < l2) {
+    const uint32_t i2 = lane, r = l2 - i2, lim = min(r, 8u);
+    uint32_t fo[8], code = 0, off = 0, width = 4;
+#pragma unroll
+    for (uint32_t l = 1; l <= 8; ++l) {                      // eight independent probes
+      fo[l - 1] = 0xFFFFFFFFu;
+      if (l <= lim) {
+        const int b = base_code(s2[i2 + l - 1]);
+        code = code * 4u + (uint32_t)(b < 0 ? 0 : b);
+        fo[l - 1] = ix.focc[off + code];
+      }
+      off += width; width *= 4u;
+    }
+    bool ok = true;
+#pragma unroll
+    for (uint32_t l = 1; l <= 8; ++l) {
+      if (ok && l <= lim && l <= G && fo[l - 1] <= G - l) { best = l; bt = fo[l - 1]; }
+      else ok = false;
+    }
+    if (best == 8 && r > 8) {
+      uint32_t lo = ix.klo[code], hi = ix.khi[code], l = 8;
+      while (l < r && hi > lo) {
+        if (hi - lo == 1) {
+          // one suffix left: lengths l+1 .. min(lcp, G - t) are valid with this start
+          const uint32_t t = ix.sa[lo], cap = min(r, G - t);
+          uint32_t m = l;
+          while (m < cap) {
+            // eight characters of each side per round trip
+            uint32_t eq = 0;
+#pragma unroll
+            for (uint32_t q = 0; q < 8; ++q) {
+              const bool in = m + q < cap;
+              const uint32_t a = in ? T[t + m + q] : 0u, b = in ? s2[i2 + m + q] : 1u;
+              eq |= (a == b ? 1u : 0u) << q;
+            }
+            const uint32_t run = (uint32_t)__builtin_ctz(~eq);      // matching characters from m on (at most 8)
+            m += run;
+            if (run < 8) break;
+          }
+          if (m > best) { best = m; bt = t; }
+          break;
+        }
+        const uint32_t c = s2[i2 + l];
+        // suffixes of [lo, hi) share l characters and are ordered by the next one (the end of T first)
+        uint32_t a = lo, z = hi;
+        while (a < z) { const uint32_t mid = (a + z) >> 1, p = ix.sa[mid] + l; const uint32_t ch = p < ix.n ? T[p] : 0u; if (ch < c) a = mid + 1; else z = mid; }
+        const uint32_t nlo = a;
+        z = hi;
+        while (a < z) { const uint32_t mid = (a + z) >> 1, p = ix.sa[mid] + l; const uint32_t ch = p < ix.n ? T[p] : 0u; if (ch <= c) a = mid + 1; else z = mid; }
+        lo = nlo; hi = a;
+        if (lo == hi) break;
+        ++l;
+        const uint32_t mt = lcfsa_rmq(ix, lo, hi);
+        if (l <= G && mt <= G - l) { best = l; bt = mt; } else break;
+      }
+    }
+  }
+  // the wave's answer: longest, then smallest start in T, then smallest start in s2 (= lane)
+  unsigned long long key = best ? ((unsigned long long)best << 40) | ((unsigned long long)(0x0FFFFFFFu - bt) << 8) | (63u - lane) : 0ull;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) { const unsigned long long x = __shfl_xor(key, o); key = x > key ? x : key; }
+  if (lane == 0) {
+    res->status = 0;
+    res->v[0] = (int32_t)(key >> 40);
+    res->v[1] = key ? (int32_t)(0x0FFFFFFFu - (uint32_t)((key >> 8) & 0x0FFFFFFFu)) : 0;
+    res->v[2] = key ? (int32_t)(63u - (uint32_t)(key & 63u)) : 0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // ONE launch for every wave-per-job family of a batch.  A merged batch used to cost eleven launches
 // dealt onto four hardware queues, and the kernels of a queue run one after the other: the batch
 // took the SUM of its families' long poles per queue.  Here every wave of the grid looks its job up
@@ -1276,7 +1429,7 @@ __device__ __forceinline__ void gap_traceback_wave(const DevJob& job, DevResult*
 // its longest job.  The rare large row classes (BIG instances, a few hundred registers per lane) and
 // the one-job-per-workgroup kernels keep launches of their own.
 // ---------------------------------------------------------------------------------------------
-struct WaveSegs { int n; int start[6]; int count[6]; int family[6]; };
+struct WaveSegs { int n; int start[MAX_WAVE_SEGS]; int count[MAX_WAVE_SEGS]; int family[MAX_WAVE_SEGS]; };
 
 constexpr size_t WAVE_JOBS_LDS = 4 * (size_t)TB_WIN_BYTES + 4 * (size_t)TB_PATH + 4 * 4 * 65 * sizeof(uint32_t);
 
@@ -1284,7 +1437,7 @@ constexpr size_t WAVE_JOBS_LDS = 4 * (size_t)TB_WIN_BYTES + 4 * (size_t)TB_PATH 
 __device__ __forceinline__ void wave_jobs_body(const int block, const int wave, const uint32_t lane,
                                                const DevJob* __restrict__ jobs, const WaveSegs& segs,
                                                DevResult* __restrict__ results, uint8_t* __restrict__ ws,
-                                               uint8_t* __restrict__ strs, uint8_t* smem) {
+                                               uint8_t* __restrict__ strs, uint8_t* smem, const LcfIndexView& ix) {
   uint8_t* s_win = smem + (size_t)wave * TB_WIN_BYTES;
   uint8_t* s_path = smem + 4 * (size_t)TB_WIN_BYTES + (size_t)wave * TB_PATH;
   uint32_t* s_borders = reinterpret_cast<uint32_t*>(smem + 4 * (size_t)TB_WIN_BYTES + 4 * (size_t)TB_PATH) + wave * (4 * 65);
@@ -1315,16 +1468,18 @@ __device__ __forceinline__ void wave_jobs_body(const int block, const int wave, 
     case KF_ED:      lev_any_dispatch<MODE_ED, false>(job, res, ws, lane); break;
     case KF_BORDERS: lev_wave_body<1, MODE_BORDERS>(job, res, ws, lane, s_borders); break;
     case KF_AFFIX:   lev_wave_body<1, MODE_AFFIX>(job, res, ws, lane); break;
+    case KF_LCFSA:   lcfsa_wave_body(job, res, ix, lane); break;
+    case KF_LCFW:    lcf_small_wave_body(job, res, lane); break;
     default: break;
   }
 }
 
 __global__ __launch_bounds__(256)
 void wave_jobs_kernel(const DevJob* __restrict__ jobs, const WaveSegs segs, DevResult* __restrict__ results,
-                      uint8_t* __restrict__ ws, uint8_t* __restrict__ strs) {
+                      uint8_t* __restrict__ ws, uint8_t* __restrict__ strs, const LcfIndexView ix) {
   __shared__ __attribute__((aligned(16))) uint8_t smem[WAVE_JOBS_LDS];
   const int wave = (int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  wave_jobs_body((int)blockIdx.x, wave, threadIdx.x & 63u, jobs, segs, results, ws, strs, smem);
+  wave_jobs_body((int)blockIdx.x, wave, threadIdx.x & 63u, jobs, segs, results, ws, strs, smem, ix);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1335,7 +1490,7 @@ void wave_jobs_kernel(const DevJob* __restrict__ jobs, const WaveSegs segs, DevR
 // The roles with four waves let the upper four end at once (s_barrier only waits for the waves of
 // a workgroup that have not ended).  All roles share the dynamic LDS.
 // ---------------------------------------------------------------------------------------------
-struct BatchDesc { WaveSegs segs; int wave_blocks; int bc_start, bc_count, ac_start, ac_count; };
+struct BatchDesc { WaveSegs segs; int wave_blocks; int bc_start, bc_count, ac_start, ac_count; LcfIndexView ix; };
 
 __global__ __launch_bounds__(512)
 void dp_batch_kernel(const DevJob* __restrict__ jobs, const BatchDesc d, DevResult* __restrict__ results,
@@ -1358,7 +1513,7 @@ void dp_batch_kernel(const DevJob* __restrict__ jobs, const BatchDesc d, DevResu
   }
   b -= d.ac_count;
   const int wave = (int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  wave_jobs_body(b, wave, threadIdx.x & 63u, jobs, d.segs, results, ws, strs, batch_lds);
+  wave_jobs_body(b, wave, threadIdx.x & 63u, jobs, d.segs, results, ws, strs, batch_lds, d.ix);
 }
 constexpr size_t AFFIX_COOP_LDS = (COOP_W - 1) * 128 * sizeof(uint32_t) + COOP_W * 5 * sizeof(uint32_t);
 
@@ -1635,17 +1790,17 @@ void launch_lev(int family, int R, uint32_t max_rows, const DevJob* jobs, int nj
 
 // segments: (family, first job, count) of the jobs the merged kernel runs, long poles first
 void launch_wave_jobs(const DevJob* jobs, int n_segs, const int* family, const int* start, const int* count,
-                      DevResult* res, uint8_t* ws, uint8_t* strs, hipStream_t st) {
+                      DevResult* res, uint8_t* ws, uint8_t* strs, const LcfIndexView& ix, hipStream_t st) {
   WaveSegs sg;
   sg.n = 0;
   int total = 0;
-  for (int k = 0; k < n_segs && sg.n < 6; ++k) {
+  for (int k = 0; k < n_segs && sg.n < MAX_WAVE_SEGS; ++k) {
     if (count[k] <= 0) continue;
     sg.family[sg.n] = family[k]; sg.start[sg.n] = start[k]; sg.count[sg.n] = count[k]; ++sg.n;
     total += count[k];
   }
   if (total == 0) return;
-  hipLaunchKernelGGL(wave_jobs_kernel, dim3((total + 3) / 4), dim3(256), 0, st, jobs, sg, res, ws, strs);
+  hipLaunchKernelGGL(wave_jobs_kernel, dim3((total + 3) / 4), dim3(256), 0, st, jobs, sg, res, ws, strs, ix);
 }
 
 void launch_gap_slow(const DevJob* jobs, int njobs, DevResult* res, uint8_t* ws, uint8_t* strs, hipStream_t st) {
@@ -1683,11 +1838,12 @@ size_t dp_batch_lds_bytes(bool wave_jobs, int bc_count, uint32_t bc_max_rows, in
 
 bool launch_dp_batch(const DevJob* jobs, int n_segs, const int* family, const int* start, const int* count,
                      int bc_start, int bc_count, uint32_t bc_max_rows, int ac_start, int ac_count,
-                     DevResult* res, uint8_t* ws, uint8_t* strs, hipStream_t st) {
+                     DevResult* res, uint8_t* ws, uint8_t* strs, const LcfIndexView& ix, hipStream_t st) {
   BatchDesc d;
+  d.ix = ix;
   d.segs.n = 0;
   int total = 0;
-  for (int k = 0; k < n_segs && d.segs.n < 6; ++k) {
+  for (int k = 0; k < n_segs && d.segs.n < MAX_WAVE_SEGS; ++k) {
     if (count[k] <= 0) continue;
     d.segs.family[d.segs.n] = family[k]; d.segs.start[d.segs.n] = start[k]; d.segs.count[d.segs.n] = count[k]; ++d.segs.n;
     total += count[k];

@@ -8,6 +8,20 @@
 const uint8_t* pgpu_index_genomic(const pgpu_index* idx);   // device pointer
 size_t pgpu_index_length(const pgpu_index* idx);
 
+// What the suffix-array form of find_longest_common_factor_dp needs (pgpu_dp_kernels.hip: lcfsa_wave_body):
+//   focc   first occurrence of every upper-case ACGT l-mer, l = 1..8 (table l at offset (4^l - 4) / 3;
+//          0xFFFFFFFF: the l-mer does not occur)
+//   rmq    sparse table of range minima over the suffix array: level j >= 1 at (j-1) * n holds
+//          min(sa[k .. k + 2^j)) for k + 2^j <= n; level 0 is the suffix array itself
+//   first_bad  position of the first character of the sequence that is not an upper-case A, C, G or T
+//          (n when there is none): prefixes up to there can be searched with exact matching alone
+struct LcfIndexView {
+  const uint8_t* T; const uint32_t* sa; const uint32_t* klo; const uint32_t* khi; const uint32_t* focc; const uint32_t* rmq;
+  uint32_t n, levels, first_bad;
+};
+LcfIndexView pgpu_index_lcf_view(const pgpu_index* idx);
+constexpr uint32_t LCF_FOCC_ENTRIES = 87380;      // 4 + 16 + ... + 4^8
+
 // context helpers implemented in pgpu_api.hip
 hipStream_t pgpu_ctx_stream(pgpu_ctx* ctx);
 // makes the context's device current on the calling thread (HIP's current device is per thread:

@@ -47,7 +47,19 @@ struct pgpu_index {
   uint8_t* d_key = nullptr;          // 256 entries
   uint32_t sigma = 0;
   size_t len = 0;
+  // derived tables for the suffix-array longest-common-factor search (LcfIndexView, pgpu_index.h); made
+  // after every build and load, not kept in the index file
+  uint32_t* d_focc = nullptr;
+  uint32_t* d_rmq = nullptr;
+  uint32_t rmq_levels = 0, first_bad = 0;
 };
+
+LcfIndexView pgpu_index_lcf_view(const pgpu_index* idx) {
+  LcfIndexView v{};
+  if (idx) { v.T = idx->d_gen; v.sa = idx->d_sa; v.klo = idx->d_klo; v.khi = idx->d_khi; v.focc = idx->d_focc; v.rmq = idx->d_rmq;
+             v.n = (uint32_t)idx->len; v.levels = idx->rmq_levels; v.first_bad = idx->first_bad; }
+  return v;
+}
 
 const uint8_t* pgpu_index_genomic(const pgpu_index* idx) { return idx->d_gen; }
 size_t pgpu_index_length(const pgpu_index* idx) { return idx->len; }
@@ -126,6 +138,25 @@ __global__ void kmer_table_kernel(const uint8_t* __restrict__ T, uint32_t n, con
   const int next = k + 1 < n ? kmer_code(T + sa[k + 1], n - sa[k + 1]) : -1;
   if (prev != c) klo[c] = k;
   if (next != c) khi[c] = k + 1;
+}
+
+// first occurrence of every l-mer (l = 1..8) that starts at t: tables zero-based at (4^l - 4) / 3
+__global__ void first_occ_kernel(const uint8_t* __restrict__ T, uint32_t n, uint32_t* __restrict__ focc) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  uint32_t code = 0, off = 0, width = 4;
+  for (uint32_t l = 1; l <= 8 && t + l <= n; ++l) {
+    const int b = kmer_base(T[t + l - 1]);
+    if (b < 0) break;
+    code = code * 4 + (uint32_t)b;
+    atomicMin(&focc[off + code], t);
+    off += width; width *= 4;
+  }
+}
+// one level of the sparse table: out[k] = min(in[k], in[k + half]) for k + 2 * half <= n
+__global__ void rmq_level_kernel(const uint32_t* __restrict__ in, uint32_t n, uint32_t half, uint32_t* __restrict__ out) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k + 2 * half <= n) out[k] = min(in[k], in[k + half]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -430,6 +461,30 @@ static hipError_t upload_keys(pgpu_index* idx, const char* genomic, size_t len, 
   return hipStreamSynchronize(st);           // `key` is a local
 }
 
+// tables derived from (sequence, suffix array): see LcfIndexView
+static hipError_t build_lcf_tables(pgpu_index* idx, const char* genomic, hipStream_t st) {
+  const uint32_t n = (uint32_t)idx->len;
+  uint32_t fb = n;
+  for (uint32_t i = 0; i < n; ++i) { const char c = genomic[i]; if (c != 'A' && c != 'C' && c != 'G' && c != 'T') { fb = i; break; } }
+  idx->first_bad = fb;
+  hipError_t e = hipMalloc((void**)&idx->d_focc, LCF_FOCC_ENTRIES * sizeof(uint32_t));
+  if (e != hipSuccess) return e;
+  e = hipMemsetAsync(idx->d_focc, 0xFF, LCF_FOCC_ENTRIES * sizeof(uint32_t), st);
+  if (e != hipSuccess) return e;
+  uint32_t levels = 0;
+  while (n >= 2 && (2u << levels) <= n) ++levels;              // levels j = 1..levels with 2^j <= n
+  idx->rmq_levels = levels;
+  e = hipMalloc((void**)&idx->d_rmq, ((size_t)(levels ? levels : 1) * (n ? n : 1)) * sizeof(uint32_t));
+  if (e != hipSuccess) return e;
+  if (n == 0) return hipSuccess;
+  const dim3 blk(256), grd((n + 255) / 256);
+  hipLaunchKernelGGL(first_occ_kernel, grd, blk, 0, st, idx->d_gen, n, idx->d_focc);
+  for (uint32_t j = 1; j <= levels; ++j)
+    hipLaunchKernelGGL(rmq_level_kernel, grd, blk, 0, st, j == 1 ? idx->d_sa : idx->d_rmq + (size_t)(j - 2) * n, n, 1u << (j - 1),
+                       idx->d_rmq + (size_t)(j - 1) * n);
+  return hipGetLastError();
+}
+
 #define TRY_HIP(call)                                                                        \
   do {                                                                                       \
     hipError_t e_ = (call);                                                                  \
@@ -509,13 +564,14 @@ extern "C" int pgpu_index_build(pgpu_ctx* ctx, const char* genomic, size_t len, 
   TRY_HIP(hipMemsetAsync(idx->d_klo, 0, KTAB_ENTRIES * sizeof(uint32_t), st));
   TRY_HIP(hipMemsetAsync(idx->d_khi, 0, KTAB_ENTRIES * sizeof(uint32_t), st));
   if (n > 0) hipLaunchKernelGGL(kmer_table_kernel, grd, blk, 0, st, idx->d_gen, n, idx->d_sa, idx->d_klo, idx->d_khi);
+  TRY_HIP(build_lcf_tables(idx, genomic, st));
   TRY_HIP(hipStreamSynchronize(st));
   TRY_HIP(hipGetLastError());
 done:
   hipFree(rank); hipFree(sa2); hipFree(flags); hipFree(newrank); hipFree(keys); hipFree(keys2); hipFree(tmp);
   for (uint32_t* q : round_ranks) hipFree(q);
   hipFree(d_round_ptrs);
-  if (rc != PGPU_OK) { hipFree(idx->d_gen); hipFree(idx->d_sa); hipFree(idx->d_lcp); hipFree(idx->d_klo); hipFree(idx->d_khi); hipFree(idx->d_key); delete idx; return rc; }
+  if (rc != PGPU_OK) { hipFree(idx->d_gen); hipFree(idx->d_sa); hipFree(idx->d_lcp); hipFree(idx->d_klo); hipFree(idx->d_khi); hipFree(idx->d_key); hipFree(idx->d_focc); hipFree(idx->d_rmq); delete idx; return rc; }
   *out = idx;
   return PGPU_OK;
 }
@@ -611,9 +667,10 @@ extern "C" int pgpu_index_load(pgpu_ctx* ctx, const char* path, const char* geno
   TRY_HIP(hipMemcpyAsync(idx->d_lcp, host.data() + n, ((size_t)n + 1) * 4, hipMemcpyHostToDevice, st));
   TRY_HIP(hipMemcpyAsync(idx->d_klo, host.data() + 2 * (size_t)n + 1, KTAB_ENTRIES * 4, hipMemcpyHostToDevice, st));
   TRY_HIP(hipMemcpyAsync(idx->d_khi, host.data() + 2 * (size_t)n + 1 + KTAB_ENTRIES, KTAB_ENTRIES * 4, hipMemcpyHostToDevice, st));
+  TRY_HIP(build_lcf_tables(idx, genomic, st));
   TRY_HIP(hipStreamSynchronize(st));
 done:
-  if (rc != PGPU_OK) { hipFree(idx->d_gen); hipFree(idx->d_sa); hipFree(idx->d_lcp); hipFree(idx->d_klo); hipFree(idx->d_khi); hipFree(idx->d_key); delete idx; return rc; }
+  if (rc != PGPU_OK) { hipFree(idx->d_gen); hipFree(idx->d_sa); hipFree(idx->d_lcp); hipFree(idx->d_klo); hipFree(idx->d_khi); hipFree(idx->d_key); hipFree(idx->d_focc); hipFree(idx->d_rmq); delete idx; return rc; }
   *out = idx;
   return PGPU_OK;
 }
@@ -623,6 +680,7 @@ extern "C" int pgpu_index_destroy(pgpu_ctx* ctx, pgpu_index* idx) {
   if (pgpu_ctx_bind(ctx) != PGPU_OK) return PGPU_EDEVICE;
   hipStreamSynchronize(pgpu_ctx_stream(ctx));
   hipFree(idx->d_gen); hipFree(idx->d_sa); hipFree(idx->d_lcp); hipFree(idx->d_klo); hipFree(idx->d_khi); hipFree(idx->d_key);
+  hipFree(idx->d_focc); hipFree(idx->d_rmq);
   delete idx;
   return PGPU_OK;
 }

@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include "../../include/pintron_gpu.h"
+#include "pgpu_index.h"
 
 // Job descriptor as the kernels see it: operand pointers already resolved to HBM addresses.
 struct DevJob {
@@ -23,7 +24,10 @@ using DevResult = pgpu_dp_result;
 
 // kernel families (one launch group per family and row class)
 enum KernelFamily {
-  KF_ALIGN = 0, KF_GAP, KF_ED, KF_KBAND, KF_LCF, KF_BORDERS, KF_AFFIX, KF_COUNT
+  KF_ALIGN = 0, KF_GAP, KF_ED, KF_KBAND, KF_LCF, KF_BORDERS, KF_AFFIX,
+  KF_LCFSA,            // find_longest_common_factor_dp answered from the suffix array (one wave per job; see lcfsa_wave_body)
+  KF_LCFW,             // ... of two short strings (the small-exon search's exon ends): one wave per job, a lane per diagonal
+  KF_COUNT
 };
 
 // launchers (pgpu_dp_kernels.hip)
@@ -31,13 +35,14 @@ void launch_lev(int mode_family, int R, uint32_t max_rows, const DevJob* jobs, i
                 uint8_t* ws, uint8_t* strs, hipStream_t st);     // ALIGN: matrix + traceback
 void launch_gap(const DevJob* jobs, int njobs, int n_big, DevResult* res, uint8_t* ws, uint8_t* strs, hipStream_t st);   // + traceback
 void launch_gap_slow(const DevJob* jobs, int njobs, DevResult* res, uint8_t* ws, uint8_t* strs, hipStream_t st);   // beyond 2048 rows
+constexpr int MAX_WAVE_SEGS = 8;
 void launch_wave_jobs(const DevJob* jobs, int n_segs, const int* family, const int* start, const int* count,
-                      DevResult* res, uint8_t* ws, uint8_t* strs, hipStream_t st);   // every wave-per-job family in one launch
+                      DevResult* res, uint8_t* ws, uint8_t* strs, const LcfIndexView& ix, hipStream_t st);   // every wave-per-job family in one launch
 // one launch for the one-job-per-workgroup sweeps and the wave-per-job families of a batch; returns
 // false (nothing launched) when the largest BORDERS pattern needs more LDS than a workgroup may share
 bool launch_dp_batch(const DevJob* jobs, int n_segs, const int* family, const int* start, const int* count,
                      int bc_start, int bc_count, uint32_t bc_max_rows, int ac_start, int ac_count,
-                     DevResult* res, uint8_t* ws, uint8_t* strs, hipStream_t st);
+                     DevResult* res, uint8_t* ws, uint8_t* strs, const LcfIndexView& ix, hipStream_t st);
 size_t dp_batch_lds_bytes(bool wave_jobs, int bc_count, uint32_t bc_max_rows, int ac_count);
 // keys: one zeroed entry per job, (length << 44) | (2^28-1 - occ1) << 16 | (2^16-1 - occ2) of the best run; 0: none
 void launch_lcf(const DevJob* jobs, int njobs, uint32_t max_chunks, uint32_t max_l2,

@@ -17,9 +17,9 @@ typedef struct { int p, t, l; } ptl;     /* pairing inside an embedding */
 /* strlen(real_substring(index, length, s)) for index >= 0 without the copy: the substring read in
  * place ends at the terminator like the copy would */
 static size_t view_len(const char* s, int index, int length) {
-  size_t n = 0;
-  while ((int)n < length && s[index + n] != '\0') ++n;
-  return n;
+  if (length <= 0) return 0;
+  const char* z = (const char*)memchr(s + index, 0, (size_t)length);     /* vectorised: this runs twice per exon */
+  return z ? (size_t)(z - (s + index)) : (size_t)length;
 }
 
 char* ef_real_substring(int index, int length, const char* s) {     /* src/util.c:138-158 */
@@ -416,19 +416,31 @@ static double dust_score(const char* s, int start, int end) {
   int want = end - start + 1;
   if (start < 0) { want += start; start = 0; }          /* real_substring clamps a negative index */
   if (want < 0) want = 0;
-  const char* sub = s + start;
-  size_t len = 0;
-  while (len < (size_t)want && sub[len] != '\0') ++len;
+  const unsigned char* sub = (const unsigned char*)s + start;
+  const unsigned char* z = want ? (const unsigned char*)memchr(sub, 0, (size_t)want) : NULL;
+  const size_t len = z ? (size_t)(z - sub) : (size_t)want;
   double r = 0.0;
   if ((int)len > 2) {
-    int freq[17] = {0}, running = 0;
-    int x = base_index((unsigned char)sub[0]);
-    for (int i = 0; i < (int)len - 1; ++i) {
-      const int y = base_index((unsigned char)sub[i + 1]);
-      const int k = (x < 0 || y < 0) ? 16 : 4 * x + y;
-      running += freq[k]; ++freq[k];
-      x = y;
+    /* the reference adds, per dinucleotide, the number of times it has been seen before
+     * (src/exon-complexity.c:50-78): the sum over the dinucleotides of f (f - 1) / 2 for their final counts f.
+     * Counting first takes the add chain through the table out of the loop; four tables (positions mod 4)
+     * keep a run of one dinucleotide from serialising on a single counter.  The sum is an integer, so the
+     * double arithmetic that follows sees the same value as the reference's running total. */
+    unsigned f4[4][18];
+    memset(f4, 0, sizeof f4);
+    const int m = (int)len - 1;                        /* dinucleotides */
+    int x = base_index(sub[0]), i = 0;
+    for (; i + 4 <= m; i += 4) {
+      const int y0 = base_index(sub[i + 1]), y1 = base_index(sub[i + 2]), y2 = base_index(sub[i + 3]), y3 = base_index(sub[i + 4]);
+      ++f4[0][(x < 0 || y0 < 0) ? 16 : 4 * x + y0];
+      ++f4[1][(y0 < 0 || y1 < 0) ? 16 : 4 * y0 + y1];
+      ++f4[2][(y1 < 0 || y2 < 0) ? 16 : 4 * y1 + y2];
+      ++f4[3][(y2 < 0 || y3 < 0) ? 16 : 4 * y2 + y3];
+      x = y3;
     }
+    for (; i < m; ++i) { const int y = base_index(sub[i + 1]); ++f4[0][(x < 0 || y < 0) ? 16 : 4 * x + y]; x = y; }
+    long long running = 0;
+    for (int k = 0; k < 17; ++k) { const long long f = (long long)f4[0][k] + f4[1][k] + f4[2][k] + f4[3][k]; running += f * (f - 1) / 2; }
     const double dust = (10.0 * (double)running) / ((double)(len - 2));
     r = dust / len;
   }

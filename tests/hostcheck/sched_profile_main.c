@@ -18,6 +18,7 @@ int main(int argc, char** argv) {
   const int passes = argc > 1 ? atoi(argv[1]) : 3;
   setenv("PINTRON_FAKE_CACHE", "1", 1);
   char* av[2] = { (char*)"est-fact", NULL };
+  if (moncontrol) moncontrol(0);            /* loading and the per-gene tables are not the steady state */
   ef_session* s = ef_session_open(1, av);
   if (!s) return 1;
   for (int p = 0; p < passes; ++p) {

@@ -291,3 +291,62 @@ def test_results_to_device_and_launch_modes(gpu_ctx, O):
         finally:
             del os.environ["PGPU_MERGED"]
         assert out == base, "PGPU_MERGED=%s differs" % mode
+
+
+@pytest.mark.parametrize("merged", ["2", "1", "0"])
+def test_lcf_from_the_suffix_array(O, merged, monkeypatch):
+    """find_longest_common_factor_dp of a genomic PREFIX against at most 64 EST characters, answered from
+    the resident suffix array (lcfsa_wave_body) instead of the 46 x |prefix| matrix: same length, same first
+    maximum (smallest start in the genomic, then in the EST) as the oracle on random sequences, planted
+    factors, repeats (microsatellites, duplicated blocks: many suffixes share the pattern, so the range
+    minima decide), tiny alphabets, prefixes that cut an occurrence, empty operands -- and the jobs that do
+    not qualify (an N on either side, more than 64 characters, a prefix beyond the first non-ACGT character)
+    still get the matrix kernel's answer.  In every launch mode of the library."""
+    import pintron_amd.capi as capi
+    monkeypatch.setenv("PGPU_MERGED", merged)
+    rng = random.Random(77 + int(merged))
+
+    def genome(kind, n):
+        if kind == "random":
+            return D.rand_seq(rng, n)
+        if kind == "binary":
+            return bytes(rng.choice(b"AC") for _ in range(n))
+        if kind == "repeats":
+            g = bytearray(D.rand_seq(rng, n))
+            unit = D.rand_seq(rng, rng.randint(2, 5))
+            for _ in range(max(1, n // 4000)):
+                p = rng.randint(0, max(0, n - 400)); k = rng.randint(30, 300)
+                g[p:p + k] = (unit * (k // len(unit) + 1))[:k]
+            blk = bytes(g[n // 3:n // 3 + 200])
+            for _ in range(6):
+                p = rng.randint(0, max(0, n - 200)); g[p:p + len(blk)] = blk[: n - p]
+            return bytes(g[:n])
+        raise ValueError(kind)
+
+    with capi.Context(0) as ctx:
+        for kind, n in (("random", 200_000), ("repeats", 60_000), ("binary", 3_000), ("random", 9), ("random", 1)):
+            gen = genome(kind, n)
+            mixed = gen if n < 50_000 else gen[: n - 5000] + b"N" + gen[n - 4999:]      # first non-ACGT at n - 5000
+            idx = capi.Index(ctx, mixed)
+            try:
+                jl = capi.JobList()
+                cases = []
+                for it in range(260 if n >= 3000 else 60):
+                    G = rng.choice([0, 1, 7, 8, 9, n, n // 2, rng.randint(0, n), rng.randint(0, n)])
+                    if it % 9 == 0 and n >= 50_000:
+                        G = rng.randint(n - 5000, n)                     # beyond the N: the matrix kernel
+                    l2 = rng.choice([0, 1, 5, 8, 9, 23, 46, 46, 46, 64, 65, rng.randint(0, 64)])
+                    s2 = bytearray(D.rand_seq(rng, l2, 0.02 if it % 7 == 0 else 0.0))
+                    if l2 >= 4 and G >= 4 and rng.random() < 0.7:       # plant a factor of the prefix (sometimes cut by G)
+                        k = rng.randint(2, min(l2, 40, G))
+                        p = rng.randint(max(0, G - 60), G - 1) if rng.random() < 0.3 else rng.randint(0, G - 1)
+                        k = min(k, n - p)
+                        q = rng.randint(0, l2 - k)
+                        s2[q:q + k] = mixed[p:p + k]
+                    cases.append(D.Case(D.LCF, mixed[:G], bytes(s2)))
+                    jl.add(capi.LCF, mixed[:G], bytes(s2), a_gen_off=0)
+                out = capi.run_jobs(ctx, jl, idx)
+                bad = [(len(c.a), c.b, got, c.expected(O)) for c, got in zip(cases, out) if not D.check_case(c, got, O)]
+                assert not bad, (kind, n, len(bad), bad[0])
+            finally:
+                idx.close()
