@@ -47,7 +47,9 @@ struct pgpu_ctx {
   // a blocking-sync event by 5-7 % whole-program (the interrupt path costs more host time than
   // the naps cost latency).  PGPU_WAIT=<us> sets the nap, 0 = blocking-sync event, -1 = spin.
   hipEvent_t ev_done = nullptr;
+  hipEvent_t ev_wait = nullptr;      // pgpu_ctx_wait (pairing / MEG stages)
   long wait_poll_us = 20;
+  bool align_coop = true;    // ALIGN with 65 .. 4096 rows on four waves (PGPU_ALIGN_COOP=0: one wave, as before)
   bool lcf_sa = true;        // longest common factors of genomic prefixes from the suffix array (PGPU_LCF_SA=0: always the DP kernel)
   int poison = -1;           // PGPU_POISON=<0..255>: fill strings + workspace of every DP plan with that byte first
   // pinned staging for the device->host result copies (pageable copies block and spin inside HIP)
@@ -145,6 +147,18 @@ static int set_err(pgpu_ctx* ctx, int code, const char* fmt, ...) {
   } while (0)
 
 hipStream_t pgpu_ctx_stream(pgpu_ctx* ctx) { return ctx->stream; }
+hipError_t pgpu_ctx_wait(pgpu_ctx* ctx) {
+  if (ctx->wait_poll_us <= 0) return hipStreamSynchronize(ctx->stream);
+  hipError_t e = hipEventRecord(ctx->ev_wait, ctx->stream);
+  if (e != hipSuccess) return e;
+  // the kernels behind these waits run for milliseconds: naps five times the DP plans' (100 us by default)
+  const struct timespec ts = {0, ctx->wait_poll_us * 5000L};
+  for (;;) {
+    e = hipEventQuery(ctx->ev_wait);
+    if (e != hipErrorNotReady) return e;
+    nanosleep(&ts, nullptr);
+  }
+}
 int pgpu_ctx_bind(pgpu_ctx* ctx) {
   const hipError_t e = hipSetDevice(ctx->device);
   return e == hipSuccess ? PGPU_OK : set_err(ctx, PGPU_EDEVICE, "hipSetDevice(%d) failed: %s", ctx->device, hipGetErrorString(e));
@@ -213,10 +227,12 @@ extern "C" int pgpu_init(int device, pgpu_ctx** out) {
     if (hipStreamCreateWithFlags(&a, hipStreamNonBlocking) != hipSuccess) { delete ctx; return PGPU_EDEVICE; }
   if (hipEventCreateWithFlags(&ctx->ev_upload, hipEventDisableTiming) != hipSuccess) { delete ctx; return PGPU_EDEVICE; }
   if (hipEventCreateWithFlags(&ctx->ev_done, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) { delete ctx; return PGPU_EDEVICE; }
+  if (hipEventCreateWithFlags(&ctx->ev_wait, hipEventDisableTiming) != hipSuccess) { delete ctx; return PGPU_EDEVICE; }
   for (auto& e : ctx->ev_aux)
     if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete ctx; return PGPU_EDEVICE; }
   { const char* f = getenv("PGPU_FANOUT"); ctx->fanout = !(f && f[0] == '0'); }
   { const char* f = getenv("PGPU_WAIT"); if (f) ctx->wait_poll_us = atol(f); }
+  { const char* f = getenv("PGPU_ALIGN_COOP"); if (f && f[0] == '0') ctx->align_coop = false; }
   { const char* f = getenv("PGPU_LCF_SA"); if (f && f[0] == '0') ctx->lcf_sa = false; }
   { const char* f = getenv("PGPU_POISON"); if (f && f[0]) ctx->poison = atoi(f) & 255; }
   { const char* f = getenv("PGPU_PACK"); if (f && atoi(f) == 0) ctx->packed = false; }
@@ -234,6 +250,7 @@ extern "C" int pgpu_destroy(pgpu_ctx* ctx) {
   for (auto& a : ctx->aux) if (a) { hipStreamSynchronize(a); hipStreamDestroy(a); }
   if (ctx->ev_upload) hipEventDestroy(ctx->ev_upload);
   if (ctx->ev_done) hipEventDestroy(ctx->ev_done);
+  if (ctx->ev_wait) hipEventDestroy(ctx->ev_wait);
   for (auto& e : ctx->ev_aux) if (e) hipEventDestroy(e);
   for (auto& e : ctx->ev_pool) if (e) hipEventDestroy(e);
   for (auto& q : ctx->pin) if (q) hipHostFree(q);
@@ -305,7 +322,7 @@ struct pgpu_dp_plan {
   int merged_group = -1;       // index of the pseudo group that carries its timing and accounting
   // ... and, with the batch kernel, the one-job-per-workgroup BORDERS / AFFIX jobs
   bool batch = false;
-  int bc_start = 0, bc_count = 0, ac_start = 0, ac_count = 0;
+  int bc_start = 0, bc_count = 0, ac_start = 0, ac_count = 0, lc_start = 0, lc_count = 0;   // BORDERS / AFFIX / ALIGN on several waves
   uint32_t bc_max_rows = 0;
   // LCF: the kernel leaves one 64-bit key per job directly in front of the results; they come back in the
   // same copy and sync turns them into results (lcf_out[k] = caller index of the job of key k)
@@ -356,6 +373,7 @@ extern "C" int pgpu_dp_plan_create_parts(pgpu_ctx* ctx, const pgpu_index* idx, c
   const size_t gen_len = idx ? pgpu_index_length(idx) : 0;
   p->lcf_ix = pgpu_index_lcf_view(idx);
   const bool lcf_sa = ctx->lcf_sa && idx && p->lcf_ix.focc && p->lcf_ix.rmq;
+  const bool align_coop = ctx->align_coop;
   p->owner = ctx;
   p->pooled = pgpu_ctx_pool_acquire(ctx, 0);
 
@@ -474,6 +492,9 @@ extern "C" int pgpu_dp_plan_create_parts(pgpu_ctx* ctx, const pgpu_index* idx, c
         ws += (size_t)((la + 4095u) / 4096u) * ((size_t)lb + 64) * 64 * align_entry_bytes(k.R);
         k.j.str_off = strs; strs += 2 * ((size_t)la + lb + 1);
       }
+    } else if (k.family == KF_ALIGN && k.R >= 2 && ctx->align_coop) {   // four waves: [step][256 lanes] entries
+      k.j.ws_off = ws; ws += ((size_t)lb + 256) * 256 * align_coop_entry_bytes(k.R);
+      k.j.str_off = strs; strs += 2 * ((size_t)la + lb + 1);
     } else if (k.family == KF_ALIGN) {
       k.j.ws_off = ws; ws += ((size_t)lb + 64) * 64 * align_entry_bytes(k.R);
       k.j.str_off = strs; strs += 2 * ((size_t)la + lb + 1);
@@ -495,9 +516,9 @@ extern "C" int pgpu_dp_plan_create_parts(pgpu_ctx* ctx, const pgpu_index* idx, c
     size_t j = i;
     // a launch group = a family; BORDERS and AFFIX split into (up to 64 rows: one wave per job),
     // (more rows: one job per workgroup) and, AFFIX only, (beyond 4096 rows: strips)
-    auto variant = [](const Keyed& k) -> int {
+    auto variant = [align_coop](const Keyed& k) -> int {
       if (k.family == KF_GAP) return k.R == ROW_CLASS_STRIPS ? (int)ROW_CLASS_STRIPS : 0;
-      if (k.family != KF_BORDERS && k.family != KF_AFFIX) return 0;
+      if (k.family != KF_BORDERS && k.family != KF_AFFIX && !(k.family == KF_ALIGN && align_coop)) return 0;
       return k.R == 1 ? 1 : (k.R == ROW_CLASS_STRIPS ? (int)ROW_CLASS_STRIPS : 0);
     };
     Group g{};
@@ -506,7 +527,9 @@ extern "C" int pgpu_dp_plan_create_parts(pgpu_ctx* ctx, const pgpu_index* idx, c
            (g.family != KF_LCF || j - i < 65535)) {
       const Keyed& k = v[j];
       const uint64_t la = k.j.la, lb = k.j.lb;
-      const uint64_t job_cells = (k.family == KF_GAP ? 3 : (k.family == KF_BORDERS ? 2 : 1)) * cells_of(k);
+      // cells = what the kernels compute (the roofline's numerator).  The suffix-array search computes none of the
+      // 46 x |prefix| cells the reference's loop bounds give for these jobs: they are left out rather than credited
+      const uint64_t job_cells = k.family == KF_LCFSA ? 0 : (k.family == KF_GAP ? 3 : (k.family == KF_BORDERS ? 2 : 1)) * cells_of(k);
       // algorithmic HBM bytes: operands once; 1 B/cell of directions for
       // ALIGN, 3 B/cell for GAP; 8 B per row when row minima are produced
       // (BORDERS touches the first and the last t_win characters of t only)
@@ -536,6 +559,8 @@ extern "C" int pgpu_dp_plan_create_parts(pgpu_ctx* ctx, const pgpu_index* idx, c
     else if (g.family == KF_AFFIX && g.R == (int)ROW_CLASS_STRIPS) snprintf(nm, sizeof nm, "lev_wave<AFFIX,strips>");
     else if (g.family == KF_BORDERS && g.R == (int)ROW_CLASS_STRIPS) snprintf(nm, sizeof nm, "borders_slow");
     else if (g.family == KF_GAP && g.R == (int)ROW_CLASS_STRIPS) snprintf(nm, sizeof nm, "gap_slow");
+    else if (g.family == KF_ALIGN && align_coop && g.R == 0) snprintf(nm, sizeof nm, "align_coop");
+    else if (g.family == KF_ALIGN && align_coop && g.R == (int)ROW_CLASS_STRIPS) snprintf(nm, sizeof nm, "lev_wave<ALIGN,strips>");
     else snprintf(nm, sizeof nm, "%s", fam[g.family]);
     g.name = nm;
     p->groups.push_back(g);
@@ -554,9 +579,10 @@ extern "C" int pgpu_dp_plan_create_parts(pgpu_ctx* ctx, const pgpu_index* idx, c
     for (int f : order_fam)
       for (auto& g : p->groups) {
         if (g.family != f || g.traceback) continue;
-        const bool wave_family = (f == KF_BORDERS || f == KF_AFFIX) ? g.R == 1 : g.R == 0;
+        const bool split = f == KF_BORDERS || f == KF_AFFIX || (f == KF_ALIGN && align_coop);   // one wave up to 64 rows, several above
+        const bool wave_family = split ? g.R == 1 : g.R == 0;
         if (!wave_family || p->n_segs >= MAX_WAVE_SEGS) continue;
-        const size_t big = (f == KF_BORDERS || f == KF_AFFIX) ? 0 : g.n_big;
+        const size_t big = split ? 0 : g.n_big;
         if (g.count <= big) continue;
         p->seg_family[p->n_segs] = f; p->seg_start[p->n_segs] = (int)(g.first + big); p->seg_count[p->n_segs] = (int)(g.count - big);
         ++p->n_segs;
@@ -569,10 +595,12 @@ extern "C" int pgpu_dp_plan_create_parts(pgpu_ctx* ctx, const pgpu_index* idx, c
       // needs more LDS than the roles may share
       for (auto& g : p->groups) {
         if (g.traceback || g.R != 0 || g.count == 0 || g.count > 0x3fffffffu) continue;
-        if (g.family == KF_BORDERS && dp_batch_lds_bytes(true, 1, g.max_rows, 1) <= 64 * 1024) {
+        if (g.family == KF_BORDERS && dp_batch_lds_bytes(true, 1, g.max_rows, 1, 1) <= 64 * 1024) {
           p->bc_start = (int)g.first; p->bc_count = (int)g.count; p->bc_max_rows = g.max_rows;
         } else if (g.family == KF_AFFIX) {
           p->ac_start = (int)g.first; p->ac_count = (int)g.count;
+        } else if (g.family == KF_ALIGN && align_coop) {
+          p->lc_start = (int)g.first; p->lc_count = (int)g.count;
         } else continue;
         m.count += g.count; m.cells += g.cells; m.algo_bytes += g.algo_bytes;
         g.in_merged = true; g.count = 0; g.cells = 0; g.algo_bytes = 0;
@@ -686,7 +714,7 @@ extern "C" int pgpu_dp_plan_launch(pgpu_ctx* ctx, pgpu_dp_plan* p) {
       switch (g.family) {
         case KF_COUNT: return p->batch ? 20000 : 9000;    // the merged launch: behind the one-job-per-workgroup poles it does not hold
         case KF_BORDERS: case KF_AFFIX: return g.R == 1 ? 150 : 10000 + (long)g.max_rows;
-        case KF_ALIGN: return 5000;
+        case KF_ALIGN: if (g.name == "align_coop") return 9000 + (long)g.max_rows; return 5000;
         case KF_GAP: return 4000;
         case KF_LCF: return 3000;
         case KF_LCFSA: case KF_LCFW: return 2500;
@@ -740,7 +768,7 @@ extern "C" int pgpu_dp_plan_launch(pgpu_ctx* ctx, pgpu_dp_plan* p) {
         case KF_COUNT:
           if (p->batch) {
             if (!launch_dp_batch(p->d_jobs, p->n_segs, p->seg_family, p->seg_start, p->seg_count, p->bc_start, p->bc_count,
-                                 p->bc_max_rows, p->ac_start, p->ac_count, p->d_results, p->d_ws, p->d_strs, p->lcf_ix, st))
+                                 p->bc_max_rows, p->ac_start, p->ac_count, p->lc_start, p->lc_count, p->d_results, p->d_ws, p->d_strs, p->lcf_ix, st))
               return set_err(ctx, PGPU_EDEVICE, "batch launch: LDS budget exceeded");
           } else {
             launch_wave_jobs(p->d_jobs, p->n_segs, p->seg_family, p->seg_start, p->seg_count, p->d_results, p->d_ws, p->d_strs, p->lcf_ix, st);

@@ -752,13 +752,14 @@ void lev_any_kernel(const DevJob* __restrict__ jobs, int njobs, DevResult* __res
 // travel with the wavefront, so only wave 0 reads them from memory.
 constexpr int COOP_W = 4;
 
-template <int R, bool ROWMIN, bool AFFIX, bool ASMALL = false>
+template <int R, bool ROWMIN, bool AFFIX, bool ASMALL = false, bool WILD = false, bool DIRS = false>
 __device__ __forceinline__ void lev_sweep_coop(const Operand rows, const uint32_t nr,
                                                const Operand cols, const uint32_t nc,
                                                const uint32_t w, const uint32_t lane,
                                                uint32_t* hand,        // [COOP_W-1][2][64] of this sweep
                                                uint32_t (&cur)[R], uint32_t (&minv)[R],
-                                               uint32_t (&minpos)[R], AffixBest& best) {
+                                               uint32_t (&minpos)[R], AffixBest& best,
+                                               uint8_t* dir_ws = nullptr) {   // DIRS: [step][256 lanes] entries
   uint32_t rc[R];
   const uint32_t gl = w * 64u + lane;   // lane index within the job (w is wave-uniform)
   const uint32_t row0 = gl * R;
@@ -824,11 +825,24 @@ __device__ __forceinline__ void lev_sweep_coop(const Operand rows, const uint32_
             const uint32_t in_val = in & 0xFFFFFFu;
             uint32_t up = in_val;
             uint32_t diag = diag_in;
+            const bool ch_n = WILD && is_n(ch);
+            DirPack<R> dp;
+            if constexpr (DIRS) dp.clear();
 #pragma unroll
             for (int r = 0; r < R; ++r) {
               const uint32_t left = cur[r];
-              uint32_t v = diag + (rc[r] == ch ? 0u : 1u);
-              v = min(v, min(up + 1, left + 1));
+              bool match = rc[r] == ch;
+              if constexpr (WILD) match = match || ch_n || is_n(rc[r]);
+              uint32_t v = diag + (match ? 0u : 1u);
+              if constexpr (DIRS) {
+                // ComputeAlignMatrix tie-break: diagonal, then up (dir 1), then left (dir 2), strict >
+                uint32_t d = 0;
+                if (v > up + 1) { v = up + 1; d = 1; }
+                if (v > left + 1) { v = left + 1; d = 2; }
+                dp.set(r, d);
+              } else {
+                v = min(v, min(up + 1, left + 1));
+              }
               if constexpr (ROWMIN) {
                 if (minv[r] > v) { minv[r] = v; minpos[r] = j; }
               }
@@ -839,6 +853,7 @@ __device__ __forceinline__ void lev_sweep_coop(const Operand rows, const uint32_
             }
             diag_in = in_val;
             out = up | (ch << 24);
+            if constexpr (DIRS) dp.store(dir_ws + ((size_t)s * (64u * COOP_W) + gl) * (R <= 4 ? 1u : R / 4));
           }
           hout = wave_shl1_last(out, hout);
         }
@@ -1063,6 +1078,139 @@ __device__ __forceinline__ void align_traceback_wave(const DevJob& job, DevResul
     res->str[0] = job.str_off + pos;
     res->str[1] = job.str_off + cap + pos;
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ComputeAlignMatrix + TracebackAlignment (src/compute-alignments.c:85-207) for more than 64 rows: the sweep
+// on the four waves of a workgroup (lev_sweep_coop with the N wildcard and the direction stream), the
+// traceback by wave 0.  One wave needs rows/64 cells per step in a dependent chain (a 250-row exon: four
+// cells per lane and step, 125 us); 256 lanes take one.  Directions are stored step-major over 256 lanes,
+// [step][lane], 2 bits per row of the lane; the walk only ever needs the lanes at and below its own within a
+// run of steps, so it stages a band of 64 lanes x (8192 / (64 x entry bytes)) steps in LDS.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t align_coop_rows_per_lane(uint32_t r_class) { return r_class <= 4u ? 1u : r_class / 4u; }
+
+__device__ __forceinline__ void align_traceback_coop(const DevJob& job, DevResult* res, const uint8_t* __restrict__ ws,
+                                                     uint8_t* __restrict__ strs, const uint32_t lane,
+                                                     uint8_t* win, uint8_t* path) {
+  const uint32_t n = job.la, m = job.lb, cap = n + m + 1;
+  uint8_t* ea = strs + job.str_off;
+  uint8_t* ga = ea + cap;
+  const uint32_t R = align_coop_rows_per_lane(job.r_class), EB = R <= 4 ? 1u : R / 4;
+  const uint32_t lgR = 31u - (uint32_t)__builtin_clz(R);
+  const uint32_t WS = TB_WIN_BYTES / (64u * EB);           // sweep steps per window (band of 64 lanes)
+  const uint8_t* dirs = ws + job.ws_off;
+  const uint32_t LT = 64u * COOP_W;                        // lanes of the sweep
+  uint32_t i = n, j = m, k = 0, np = 0;
+  uint32_t i0 = n, j0 = m, pos = cap - 1;
+  if (lane == 0) { ea[pos] = 0; ga[pos] = 0; }
+  uint32_t s_lo = 1u, s_hi = 0u, g_lo = 0u;                // empty window
+  while (i > 0 && j > 0) {
+    const uint32_t gl = (i - 1) >> lgR, r = (i - 1) & (R - 1), s = (j - 1) + gl;
+    if (s < s_lo || s > s_hi || gl < g_lo || gl >= g_lo + 64u) {
+      // steps (s - WS, s], lanes [g_lo, g_lo + 64) with g_lo a multiple of 16 at least 32 below gl
+      s_hi = s; s_lo = s + 1 >= WS ? s + 1 - WS : 0;
+      g_lo = (gl & ~15u) >= 48u ? (gl & ~15u) - 48u : 0u;
+      const uint32_t row16 = 4u * EB;                      // 16-byte pieces per step row of the band
+      const uint32_t total16 = (s_hi - s_lo + 1) * row16;
+      for (uint32_t e = lane; e < total16; e += 64u) {
+        const uint32_t row = e / row16, c16 = e % row16;
+        *reinterpret_cast<uint4*>(win + (size_t)e * 16u) =
+            *reinterpret_cast<const uint4*>(dirs + ((size_t)(s_lo + row) * LT + g_lo) * EB + c16 * 16u);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    uint32_t d = (win[((s - s_lo) * 64u + (gl - g_lo)) * EB + (r >> 2)] >> (2u * (r & 3u))) & 3u;
+    d = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
+    if (lane == 0) path[np] = (uint8_t)d;
+    ++np;
+    if (d == 0)      { --i; --j; }
+    else if (d == 1) { --i; }
+    else             { --j; }
+    if (np == TB_PATH) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      tb_flush(path, np, job.a, job.b, i0, j0, pos, ea, ga, lane);
+      pos -= np; k += np; np = 0; i0 = i; j0 = j;
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  tb_flush(path, np, job.a, job.b, i0, j0, pos, ea, ga, lane);
+  pos -= np; k += np;
+  for (uint32_t q = lane; q < i; q += 64) { ea[pos - 1 - q] = job.a[i - 1 - q]; ga[pos - 1 - q] = '-'; }
+  pos -= i; k += i;
+  for (uint32_t q = lane; q < j; q += 64) { ea[pos - 1 - q] = '-'; ga[pos - 1 - q] = job.b[j - 1 - q]; }
+  pos -= j; k += j;
+  if (lane == 0) {
+    res->v[1] = (int32_t)k;
+    res->str[0] = job.str_off + pos;
+    res->str[1] = job.str_off + cap + pos;
+  }
+}
+
+// one job on the first four waves of a workgroup; smem: hand-off (3 x 128 words), then the traceback's
+// window (TB_WIN_BYTES, 16-aligned) and path (TB_PATH)
+constexpr size_t ALIGN_COOP_LDS = (COOP_W - 1) * 128 * sizeof(uint32_t) + TB_WIN_BYTES + TB_PATH;
+template <int R>
+__device__ __forceinline__ void align_coop_body(const DevJob& job, DevResult* res, uint8_t* __restrict__ ws,
+                                                uint8_t* __restrict__ strs, uint8_t* smem) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  uint32_t* hand = reinterpret_cast<uint32_t*>(smem);
+  uint8_t* win = smem + (COOP_W - 1) * 128 * sizeof(uint32_t);
+  uint8_t* path = win + TB_WIN_BYTES;
+  const uint32_t n = job.la, m = job.lb;
+  // identity alignment, score 0 (compute-alignments.c:48-58)
+  bool same = n == m;
+  if (same) for (uint32_t q = threadIdx.x; q < n; q += 64u * COOP_W) same = same && job.a[q] == job.b[q];
+  if (__syncthreads_and(same ? 1 : 0)) {
+    if (w != 0) return;
+    if (lane == 0) { res->status = 0; res->v[0] = 0; res->v[1] = (int32_t)n; res->v[5] = 1; }
+    own_stores_visible();
+    align_traceback_wave(job, res, ws, strs, lane, win, path);      // its identity branch
+    return;
+  }
+  uint32_t cur[R], minv[R], minpos[R];
+  AffixBest best = AFFIX_NONE;
+  const Operand rows{job.a, 0, false}, cols{job.b, 0, false};
+  lev_sweep_coop<R, false, false, false, true, true>(rows, n, cols, m, w, lane, hand, cur, minv, minpos, best, ws + job.ws_off);
+  if (n == 0 || m == 0) { if (threadIdx.x == 0) { res->status = 0; res->v[0] = (int32_t)(n + m); res->v[5] = 0; } }
+  else {
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      if ((w * 64u + lane) * R + r + 1 == n) { res->status = 0; res->v[0] = (int32_t)cur[r]; res->v[5] = 0; }
+  }
+  // the four waves' directions (and the score) have to be visible to wave 0
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __syncthreads();
+  if (w != 0) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  align_traceback_coop(job, res, ws, strs, lane, win, path);
+}
+
+__device__ __forceinline__ void align_coop_dispatch(const DevJob& job, DevResult* res, uint8_t* __restrict__ ws,
+                                                    uint8_t* __restrict__ strs, uint8_t* smem) {
+  switch (job.r_class) {                 // rows per lane of the 256-lane sweep = class / COOP_W
+    case 2: case 4: align_coop_body<1>(job, res, ws, strs, smem); break;
+    case 8:  align_coop_body<2>(job, res, ws, strs, smem); break;
+    case 16: align_coop_body<4>(job, res, ws, strs, smem); break;
+    case 32: align_coop_body<8>(job, res, ws, strs, smem); break;
+    default: align_coop_body<16>(job, res, ws, strs, smem); break;
+  }
+}
+
+__global__ __launch_bounds__(256)
+void align_coop_any_kernel(const DevJob* __restrict__ jobs, int njobs, DevResult* __restrict__ results,
+                           uint8_t* __restrict__ ws, uint8_t* __restrict__ strs) {
+  __shared__ __attribute__((aligned(16))) uint8_t smem[ALIGN_COOP_LDS];
+  const DevJob job = jobs[blockIdx.x];
+  align_coop_dispatch(job, &results[job.out_idx], ws, strs, smem);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1300,7 +1448,7 @@ __device__ __forceinline__ void gap_traceback_wave(const DevJob& job, DevResult*
 // lane = diagonal, in rounds of 64 diagonals; N wildcard and first-maximum rule as in lcf_kernel (same key).
 // These used to get a workgroup, an atomic and a host-side decode each, in a launch of their own.
 __device__ __forceinline__ unsigned long long lcf_key(uint32_t len, uint32_t occ1, uint32_t occ2);
-__device__ __noinline__ void lcf_small_wave_body(const DevJob& job, DevResult* res, const uint32_t lane) {
+__device__ __forceinline__ void lcf_small_wave_body(const DevJob& job, DevResult* res, const uint32_t lane) {
   const uint32_t l1 = job.la, l2 = job.lb;
   const uint8_t* __restrict__ s1 = job.a; const uint8_t* __restrict__ s2 = job.b;
   unsigned long long best = 0;
@@ -1345,7 +1493,7 @@ __device__ __forceinline__ uint32_t lcfsa_rmq(const LcfIndexView& ix, uint32_t l
   return min(lv[lo], lv[hi - (1u << j)]);
 }
 
-__device__ __noinline__ void lcfsa_wave_body(const DevJob& job, DevResult* res, const LcfIndexView& ix, const uint32_t lane) {
+__device__ __forceinline__ void lcfsa_wave_body(const DevJob& job, DevResult* res, const LcfIndexView& ix, const uint32_t lane) {
   const uint32_t G = job.la, l2 = job.lb;
   const uint8_t* __restrict__ s2 = job.b;
   const uint8_t* __restrict__ T = ix.T;
@@ -1490,7 +1638,7 @@ void wave_jobs_kernel(const DevJob* __restrict__ jobs, const WaveSegs segs, DevR
 // The roles with four waves let the upper four end at once (s_barrier only waits for the waves of
 // a workgroup that have not ended).  All roles share the dynamic LDS.
 // ---------------------------------------------------------------------------------------------
-struct BatchDesc { WaveSegs segs; int wave_blocks; int bc_start, bc_count, ac_start, ac_count; LcfIndexView ix; };
+struct BatchDesc { WaveSegs segs; int wave_blocks; int bc_start, bc_count, ac_start, ac_count, lc_start, lc_count; LcfIndexView ix; };
 
 __global__ __launch_bounds__(512)
 void dp_batch_kernel(const DevJob* __restrict__ jobs, const BatchDesc d, DevResult* __restrict__ results,
@@ -1512,6 +1660,12 @@ void dp_batch_kernel(const DevJob* __restrict__ jobs, const BatchDesc d, DevResu
     return;
   }
   b -= d.ac_count;
+  if (b < d.lc_count) {
+    const DevJob job = jobs[d.lc_start + b];
+    align_coop_dispatch(job, &results[job.out_idx], ws, strs, batch_lds);
+    return;
+  }
+  b -= d.lc_count;
   const int wave = (int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   wave_jobs_body(b, wave, threadIdx.x & 63u, jobs, d.segs, results, ws, strs, batch_lds, d.ix);
 }
@@ -1766,7 +1920,10 @@ void launch_lev(int family, int R, uint32_t max_rows, const DevJob* jobs, int nj
   const dim3 g4((njobs + 3) / 4), b256(256);
   switch (family) {
     case KF_ED:    launch_lev_any<MODE_ED>(jobs, njobs, n_big, res, ws, strs, st); break;
-    case KF_ALIGN: launch_lev_any<MODE_ALIGN>(jobs, njobs, n_big, res, ws, strs, st); break;
+    case KF_ALIGN:
+      if (R == 0) hipLaunchKernelGGL(align_coop_any_kernel, dim3(njobs), dim3(256), 0, st, jobs, njobs, res, ws, strs);   // 65 .. 4096 rows
+      else launch_lev_any<MODE_ALIGN>(jobs, njobs, n_big, res, ws, strs, st);
+      break;
     case KF_KBAND: launch_lev_any<MODE_KBAND>(jobs, njobs, n_big, res, ws, strs, st); break;
     case KF_BORDERS:
       if (R == 1) {
@@ -1820,7 +1977,12 @@ void launch_lcf(const DevJob* jobs, int njobs, uint32_t max_chunks, uint32_t max
                 unsigned long long* keys, hipStream_t st) {
   if (njobs <= 0) return;
   // grid.y = job (<= 65535 per launch, the caller slices), grid.x strides over diagonal chunks
-  const uint32_t gx = max_chunks < 64u ? (max_chunks ? max_chunks : 1u) : 64u;
+  // ... as many workgroups per job as it takes to fill the chip: after the suffix-array path took the ordinary
+  // jobs, what comes here is a handful of long ones (an N in the EST prefix) -- 64 workgroups each left three
+  // quarters of the CUs idle and made these launches the long pole of their batches
+  uint32_t want = 4096u / (uint32_t)njobs;
+  if (want < 64u) want = 64u;
+  const uint32_t gx = max_chunks < want ? (max_chunks ? max_chunks : 1u) : want;
   // LDS: s2 (rounded to 16) + s1 tile (256 + l2 - 1), sized for the largest l2 of the launch
   const size_t lds = ((max_l2 + 15u) & ~15u) + LCF_BLOCK + max_l2;
   hipLaunchKernelGGL(lcf_kernel, dim3(gx, njobs), dim3(LCF_BLOCK), lds, st, jobs, njobs, keys);
@@ -1828,19 +1990,21 @@ void launch_lcf(const DevJob* jobs, int njobs, uint32_t max_chunks, uint32_t max
 
 constexpr size_t DP_BATCH_MAX_LDS = 64 * 1024;
 
-size_t dp_batch_lds_bytes(bool wave_jobs, int bc_count, uint32_t bc_max_rows, int ac_count) {
+size_t dp_batch_lds_bytes(bool wave_jobs, int bc_count, uint32_t bc_max_rows, int ac_count, int lc_count) {
   size_t lds = 16;
   if (wave_jobs) lds = std::max(lds, WAVE_JOBS_LDS);
   if (ac_count > 0) lds = std::max(lds, AFFIX_COOP_LDS);
+  if (lc_count > 0) lds = std::max(lds, ALIGN_COOP_LDS);
   if (bc_count > 0) lds = std::max(lds, (2 * (COOP_W - 1) * 128 + 4 * ((size_t)bc_max_rows + 1)) * sizeof(uint32_t));
   return lds;
 }
 
 bool launch_dp_batch(const DevJob* jobs, int n_segs, const int* family, const int* start, const int* count,
-                     int bc_start, int bc_count, uint32_t bc_max_rows, int ac_start, int ac_count,
+                     int bc_start, int bc_count, uint32_t bc_max_rows, int ac_start, int ac_count, int lc_start, int lc_count,
                      DevResult* res, uint8_t* ws, uint8_t* strs, const LcfIndexView& ix, hipStream_t st) {
   BatchDesc d;
   d.ix = ix;
+  d.lc_start = lc_start; d.lc_count = lc_count > 0 ? lc_count : 0;
   d.segs.n = 0;
   int total = 0;
   for (int k = 0; k < n_segs && d.segs.n < MAX_WAVE_SEGS; ++k) {
@@ -1851,9 +2015,9 @@ bool launch_dp_batch(const DevJob* jobs, int n_segs, const int* family, const in
   d.wave_blocks = (total + 3) / 4;
   d.bc_start = bc_start; d.bc_count = bc_count > 0 ? bc_count : 0;
   d.ac_start = ac_start; d.ac_count = ac_count > 0 ? ac_count : 0;
-  const int blocks = d.bc_count + d.ac_count + d.wave_blocks;
+  const int blocks = d.bc_count + d.ac_count + d.lc_count + d.wave_blocks;
   if (blocks == 0) return true;
-  const size_t lds = dp_batch_lds_bytes(total > 0, d.bc_count, bc_max_rows, d.ac_count);
+  const size_t lds = dp_batch_lds_bytes(total > 0, d.bc_count, bc_max_rows, d.ac_count, d.lc_count);
   if (lds > DP_BATCH_MAX_LDS) return false;
   hipLaunchKernelGGL(dp_batch_kernel, dim3(blocks), dim3(512), lds, st, jobs, d, res, ws, strs);
   return true;

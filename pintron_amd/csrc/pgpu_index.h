@@ -27,6 +27,10 @@ hipStream_t pgpu_ctx_stream(pgpu_ctx* ctx);
 // makes the context's device current on the calling thread (HIP's current device is per thread:
 // a fresh prefetch or service thread starts on device 0)
 int pgpu_ctx_bind(pgpu_ctx* ctx);
+// waits for everything queued on the context's stream WITHOUT spinning: HIP's own stream synchronisation
+// busy-waits, and the thread that drives the pairing / MEG prefetch would burn a core of the host's CPU quota
+// for the tens of milliseconds per step its kernels run (PGPU_WAIT: the nap in microseconds, as for DP plans)
+hipError_t pgpu_ctx_wait(pgpu_ctx* ctx);
 int pgpu_ctx_fail(pgpu_ctx* ctx, int code, const char* msg);
 bool pgpu_ctx_pool_acquire(pgpu_ctx* ctx, int pool);
 void pgpu_ctx_pool_release(pgpu_ctx* ctx, int pool);

@@ -52,6 +52,10 @@ struct pgpu_index {
   uint32_t* d_focc = nullptr;
   uint32_t* d_rmq = nullptr;
   uint32_t rmq_levels = 0, first_bad = 0;
+  // the sequence at 2 bits per base (16 bases per word) + 1 flag bit per base for "not an upper-case A, C, G, T"
+  // (32 per word): what the pairing kernels compare on (PackedSeq); the bytes stay for the flagged stretches
+  uint32_t* d_code = nullptr;
+  uint32_t* d_bad = nullptr;
 };
 
 LcfIndexView pgpu_index_lcf_view(const pgpu_index* idx) {
@@ -169,32 +173,95 @@ struct PairParams {
   double rate;
 };
 
-// compare suffix t (from character `skip` on) with q[skip..d): -1 / 0 (q[0..d) is a prefix) / +1.
-// The caller guarantees the first `skip` characters are equal.
-__device__ __forceinline__ int cmp_suffix(const uint8_t* __restrict__ T, uint32_t n, uint32_t t,
-                                          const uint8_t* __restrict__ q, uint32_t d, uint32_t skip) {
-  for (uint32_t x = skip; x < d; ++x) {
-    if (t + x >= n) return -1;                      // the suffix ended: it sorts first
-    const uint32_t c = T[t + x], e = q[x];
-    if (c != e) return c < e ? -1 : 1;
+// Sequences at 2 bits per base.  Both the genomic sequence and the patterns are compared sixteen bases per
+// 32-bit word (one XOR and a count of trailing zeros) instead of a byte per load: a maximal pairing is as long
+// as an exon, and pair_locate / pair_count / pair_fill walk it once per occurrence.  A flag bit per base marks
+// what is not an upper-case A, C, G or T (N, the '*' and '#' that mask poly-A/T stretches, lower case): a
+// window that holds a flagged base on either side is compared on the bytes, so the result is byte equality
+// everywhere (an N equals an N, src/max-emb-graph.c compares characters).
+struct PackedSeq { const uint32_t* __restrict__ code; const uint32_t* __restrict__ bad; };
+
+__global__ void pack2_kernel(const uint8_t* __restrict__ src, unsigned long long n, uint32_t* __restrict__ code,
+                             uint32_t* __restrict__ bad, unsigned long long n_bad_words) {
+  const unsigned long long w = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;    // one flag word = 32 bases
+  if (w >= n_bad_words) return;
+  uint32_t c0 = 0, c1 = 0, b = 0;
+  for (uint32_t k = 0; k < 32; ++k) {
+    const unsigned long long p = w * 32 + k;
+    const int x = p < n ? kmer_base(src[p]) : -1;
+    if (x < 0) b |= 1u << k;
+    else if (k < 16) c0 |= (uint32_t)x << (2 * k);
+    else c1 |= (uint32_t)x << (2 * (k - 16));
   }
-  return 0;
+  code[2 * w] = c0; code[2 * w + 1] = c1; bad[w] = b;
+}
+
+__device__ __forceinline__ uint32_t pk_win16(const uint32_t* __restrict__ code, unsigned long long pos) {
+  const unsigned long long w = pos >> 4;
+  const unsigned long long x = ((unsigned long long)code[w + 1] << 32) | code[w];
+  return (uint32_t)(x >> (2u * (uint32_t)(pos & 15u)));
+}
+__device__ __forceinline__ uint32_t pk_bad16(const uint32_t* __restrict__ bad, unsigned long long pos) {
+  const unsigned long long w = pos >> 5;
+  const unsigned long long x = ((unsigned long long)bad[w + 1] << 32) | bad[w];
+  return (uint32_t)(x >> (uint32_t)(pos & 31u)) & 0xFFFFu;
+}
+// number of leading characters on which A[a..] and B[b..] agree, among the first `rem`
+__device__ __forceinline__ uint32_t pk_match(const uint8_t* __restrict__ A, const PackedSeq Ap, unsigned long long a,
+                                             const uint8_t* __restrict__ B, const PackedSeq Bp, unsigned long long b,
+                                             uint32_t rem) {
+  uint32_t l = 0;
+  while (l < rem) {
+    const uint32_t k = rem - l < 16u ? rem - l : 16u;
+    const uint32_t mask = k < 16u ? (1u << k) - 1u : 0xFFFFu;
+    if ((pk_bad16(Ap.bad, a + l) | pk_bad16(Bp.bad, b + l)) & mask) {
+      uint32_t q = 0;
+      while (q < k && A[a + l + q] == B[b + l + q]) ++q;
+      l += q;
+      if (q < k) break;
+      continue;
+    }
+    uint32_t x = pk_win16(Ap.code, a + l) ^ pk_win16(Bp.code, b + l);
+    if (k < 16u) x &= (1u << (2u * k)) - 1u;
+    if (x) { l += (uint32_t)__builtin_ctz(x) >> 1; break; }
+    l += k;
+  }
+  return l;
+}
+
+// what the comparisons of one pattern need: the genomic sequence and the pattern blob, as bytes and packed
+struct CmpCtx {
+  const uint8_t* __restrict__ T; PackedSeq Tp; uint32_t n;
+  const uint8_t* __restrict__ pats; PackedSeq Pp;
+};
+
+// compare suffix t (from character `skip` on) with q[skip..d), q = pats + qabs: -1 / 0 (q[0..d) is a prefix) / +1.
+// The caller guarantees the first `skip` characters are equal.
+__device__ __forceinline__ int cmp_suffix(const CmpCtx& cx, uint32_t t, unsigned long long qabs, uint32_t d, uint32_t skip) {
+  if (skip >= d) return 0;
+  if (t + skip >= cx.n) return -1;                  // the suffix ended: it sorts first
+  const uint32_t avail = cx.n - t - skip, want = d - skip;
+  const uint32_t k = pk_match(cx.T, cx.Tp, (unsigned long long)t + skip, cx.pats, cx.Pp, qabs + skip, avail < want ? avail : want);
+  if (k == want) return 0;
+  if (k == avail) return -1;
+  const uint32_t c = cx.T[t + skip + k], e = cx.pats[qabs + skip + k];
+  return c < e ? -1 : 1;
 }
 
 // [lo,hi) of suffixes in sa[from,to) having q[0..d) as a prefix (all share q[0..skip))
-__device__ void sa_interval(const uint8_t* __restrict__ T, uint32_t n, const uint32_t* __restrict__ sa,
-                            const uint8_t* __restrict__ q, uint32_t d, uint32_t skip,
+__device__ void sa_interval(const CmpCtx& cx, const uint32_t* __restrict__ sa,
+                            unsigned long long qabs, uint32_t d, uint32_t skip,
                             uint32_t from, uint32_t to, uint32_t* lo, uint32_t* hi) {
   uint32_t a = from, b = to;
   while (a < b) {
     const uint32_t mid = a + ((b - a) >> 1);
-    if (cmp_suffix(T, n, sa[mid], q, d, skip) < 0) a = mid + 1; else b = mid;
+    if (cmp_suffix(cx, sa[mid], qabs, d, skip) < 0) a = mid + 1; else b = mid;
   }
   *lo = a;
   b = to;
   while (a < b) {
     const uint32_t mid = a + ((b - a) >> 1);
-    if (cmp_suffix(T, n, sa[mid], q, d, skip) <= 0) a = mid + 1; else b = mid;
+    if (cmp_suffix(cx, sa[mid], qabs, d, skip) <= 0) a = mid + 1; else b = mid;
   }
   *hi = a;
 }
@@ -204,12 +271,12 @@ __device__ __forceinline__ bool prev_excluded(const uint8_t* __restrict__ T, uin
   return i > 0 && t > 0 && T[t - 1] == P[i - 1];     // src/max-emb-graph.c:178-181,195
 }
 
-__device__ __forceinline__ uint32_t extend(const uint8_t* __restrict__ T, uint32_t n, uint32_t t,
-                                           const uint8_t* __restrict__ P, uint32_t m, uint32_t i,
+// length of the match of P[i..m) with T[t..), known to be at least `from` (P = pats + pbase)
+__device__ __forceinline__ uint32_t extend(const CmpCtx& cx, uint32_t t, unsigned long long pbase, uint32_t m, uint32_t i,
                                            uint32_t from) {
-  uint32_t l = from;
-  while (i + l < m && t + l < n && P[i + l] == T[t + l]) ++l;
-  return l;
+  if (i + from >= m || t + from >= cx.n) return from;
+  const uint32_t rp = m - i - from, rt = cx.n - t - from;
+  return from + pk_match(cx.T, cx.Tp, (unsigned long long)t + from, cx.pats, cx.Pp, pbase + i + from, rp < rt ? rp : rt);
 }
 
 // How many times the reference lists the occurrence t == 0 of position i (oracle/pairing_oracle.c
@@ -218,14 +285,15 @@ __device__ __forceinline__ uint32_t extend(const uint8_t* __restrict__ T, uint32
 // -- through the unguarded loop where the child already reported holds an occurrence preceded by
 // that symbol, through the guarded one (key 0, or key 1 next to the preceding symbol's key 0)
 // elsewhere.  *l0 = lcp(P[i..], T[0..]); the result only matters when l0 reaches the threshold.
-__device__ uint32_t zero_copies(const uint8_t* __restrict__ T, uint32_t n, const uint32_t* __restrict__ sa,
+__device__ uint32_t zero_copies(const CmpCtx& cx, unsigned long long pbase, const uint32_t* __restrict__ sa,
                                 const uint8_t* __restrict__ key, uint32_t sigma, const uint8_t* __restrict__ P,
                                 uint32_t m, uint32_t i, uint32_t L, uint32_t lo, uint32_t hi, uint32_t l0) {
+  const uint8_t* __restrict__ T = cx.T;
   unsigned long long present[4] = {0, 0, 0, 0};
   for (uint32_t k = lo; k < hi; ++k) {
     const uint32_t t = sa[k];
     if (t == 0 || prev_excluded(T, t, P, i)) continue;
-    if (extend(T, n, t, P, m, i, L) > l0) { const uint32_t q = key[T[t - 1]]; present[q >> 6] |= 1ull << (q & 63u); }
+    if (extend(cx, t, pbase, m, i, L) > l0) { const uint32_t q = key[T[t - 1]]; present[q >> 6] |= 1ull << (q & 63u); }
   }
   const uint32_t sk = i > 0 ? key[P[i - 1]] : sigma;
   uint32_t copies = 0;
@@ -243,7 +311,8 @@ void pair_locate_kernel(const uint8_t* __restrict__ T, uint32_t n, const uint32_
                         const uint32_t* __restrict__ klo, const uint32_t* __restrict__ khi,
                         const uint8_t* __restrict__ pats, const unsigned long long* __restrict__ pat_off,
                         PairParams prm, uint32_t* __restrict__ lo_out, uint32_t* __restrict__ hi_out,
-                        uint32_t* __restrict__ a_out) {
+                        uint32_t* __restrict__ a_out, const PackedSeq Tp, const PackedSeq Pp) {
+  const CmpCtx cx{T, Tp, n, pats, Pp};
   const unsigned long long base = pat_off[blockIdx.x];
   const uint32_t m = (uint32_t)(pat_off[blockIdx.x + 1] - base);
   const uint8_t* P = pats + base;
@@ -253,14 +322,14 @@ void pair_locate_kernel(const uint8_t* __restrict__ T, uint32_t n, const uint32_
       const int code = prm.L >= KTAB ? kmer_code(P + i, m - i) : -1;
       if (code >= 0) {                              // the k-mer's run, then bisect on characters KTAB..L
         const uint32_t from = klo[code], to = khi[code];
-        if (from < to) sa_interval(T, n, sa, P + i, prm.L, KTAB, from, to, &lo, &hi);
+        if (from < to) sa_interval(cx, sa, base + i, prm.L, KTAB, from, to, &lo, &hi);
       } else {
-        sa_interval(T, n, sa, P + i, prm.L, 0, 0, n, &lo, &hi);
+        sa_interval(cx, sa, base + i, prm.L, 0, 0, n, &lo, &hi);
       }
       for (uint32_t k = lo; k < hi; ++k) {
         const uint32_t t = sa[k];
         if (prev_excluded(T, t, P, i)) continue;
-        const uint32_t l = extend(T, n, t, P, m, i, prm.L);
+        const uint32_t l = extend(cx, t, base, m, i, prm.L);
         A = l > A ? l : A;
       }
     }
@@ -274,7 +343,8 @@ void pair_chain_kernel(const uint8_t* __restrict__ T, uint32_t n, const uint32_t
                        const uint32_t* __restrict__ lcp, const uint8_t* __restrict__ pats,
                        const unsigned long long* __restrict__ pat_off, uint32_t n_pat, PairParams prm,
                        const uint32_t* __restrict__ lo_in, const uint32_t* __restrict__ hi_in,
-                       const uint32_t* __restrict__ a_in, uint32_t* __restrict__ thr_out) {
+                       const uint32_t* __restrict__ a_in, uint32_t* __restrict__ thr_out, const PackedSeq Tp, const PackedSeq Pp) {
+  const CmpCtx cx{T, Tp, n, pats, Pp};
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n_pat) return;
   const unsigned long long base = pat_off[p];
@@ -290,7 +360,7 @@ void pair_chain_kernel(const uint8_t* __restrict__ T, uint32_t n, const uint32_t
     thr_out[base + i] = (uint32_t)thr_d;
     const uint32_t lo = lo_in[base + i], hi = hi_in[base + i];
     uint32_t l2 = lo, h2 = hi;
-    if (hi - lo > 1 && D > prm.L) sa_interval(T, n, sa, P + i, D, prm.L, lo, hi, &l2, &h2);
+    if (hi - lo > 1 && D > prm.L) sa_interval(cx, sa, base + i, D, prm.L, lo, hi, &l2, &h2);
     const uint32_t pl = lcp[l2], ph = lcp[h2];
     const uint32_t par = pl > ph ? pl : ph;
     if (par == 0) { s = 0; continue; }
@@ -311,7 +381,8 @@ void pair_count_kernel(const uint8_t* __restrict__ T, uint32_t n, const uint32_t
                        const uint8_t* __restrict__ key, uint32_t sigma,
                        const uint8_t* __restrict__ pats, const unsigned long long* __restrict__ pat_off,
                        PairParams prm, const uint32_t* __restrict__ lo_in, const uint32_t* __restrict__ hi_in,
-                       const uint32_t* __restrict__ thr_in, uint32_t* __restrict__ cnt_out) {
+                       const uint32_t* __restrict__ thr_in, uint32_t* __restrict__ cnt_out, const PackedSeq Tp, const PackedSeq Pp) {
+  const CmpCtx cx{T, Tp, n, pats, Pp};
   const unsigned long long base = pat_off[blockIdx.x];
   const uint32_t m = (uint32_t)(pat_off[blockIdx.x + 1] - base);
   const uint8_t* P = pats + base;
@@ -323,9 +394,9 @@ void pair_count_kernel(const uint8_t* __restrict__ T, uint32_t n, const uint32_t
       for (uint32_t k = lo; k < hi; ++k) {
         const uint32_t t = sa[k];
         if (prev_excluded(T, t, P, i)) continue;
-        const uint32_t l = extend(T, n, t, P, m, i, prm.L);
+        const uint32_t l = extend(cx, t, base, m, i, prm.L);
         if (l < thr) continue;
-        c += t == 0 ? zero_copies(T, n, sa, key, sigma, P, m, i, prm.L, lo, hi, l) : 1u;
+        c += t == 0 ? zero_copies(cx, base, sa, key, sigma, P, m, i, prm.L, lo, hi, l) : 1u;
       }
     }
     cnt_out[base + i] = c;
@@ -342,7 +413,8 @@ void pair_fill_kernel(const uint8_t* __restrict__ T, uint32_t n, const uint32_t*
                       const uint8_t* __restrict__ pats, const unsigned long long* __restrict__ pat_off,
                       PairParams prm, const uint32_t* __restrict__ lo_in, const uint32_t* __restrict__ hi_in,
                       const uint32_t* __restrict__ thr_in, const unsigned long long* __restrict__ cand_off,
-                      Cand* __restrict__ cand, uint32_t* __restrict__ cnt_a) {
+                      Cand* __restrict__ cand, uint32_t* __restrict__ cnt_a, const PackedSeq Tp, const PackedSeq Pp) {
+  const CmpCtx cx{T, Tp, n, pats, Pp};
   const unsigned long long base = pat_off[blockIdx.x];
   const uint32_t m = (uint32_t)(pat_off[blockIdx.x + 1] - base);
   const uint8_t* P = pats + base;
@@ -355,10 +427,10 @@ void pair_fill_kernel(const uint8_t* __restrict__ T, uint32_t n, const uint32_t*
       for (uint32_t k = lo; k < hi; ++k) {
         const uint32_t t = sa[k];
         if (prev_excluded(T, t, P, i)) continue;
-        const uint32_t l = extend(T, n, t, P, m, i, prm.L);
+        const uint32_t l = extend(cx, t, base, m, i, prm.L);
         if (l < thr) continue;
         // insertion sort by t (distinct, except the copies of t == 0, which stay together in front)
-        const uint32_t copies = t == 0 ? zero_copies(T, n, sa, key, sigma, P, m, i, prm.L, lo, hi, l) : 1u;
+        const uint32_t copies = t == 0 ? zero_copies(cx, base, sa, key, sigma, P, m, i, prm.L, lo, hi, l) : 1u;
         for (uint32_t cpy = 0; cpy < copies; ++cpy) {
           uint32_t q = c++;
           while (q > 0 && slot[q - 1].t > t) { slot[q] = slot[q - 1]; --q; }
@@ -461,9 +533,30 @@ static hipError_t upload_keys(pgpu_index* idx, const char* genomic, size_t len, 
   return hipStreamSynchronize(st);           // `key` is a local
 }
 
+// src[0..n) -> code (2 * ceil(n / 32) words, + 4 of slack the windows may read) and flag words
+static hipError_t pack_sequence(const uint8_t* src, size_t n, uint32_t* code, uint32_t* bad, hipStream_t st) {
+  const size_t bad_words = (n + 31) / 32;
+  hipError_t e = hipMemsetAsync(code + 2 * bad_words, 0, 4 * sizeof(uint32_t), st);
+  if (e != hipSuccess) return e;
+  e = hipMemsetAsync(bad + bad_words, 0xFF, 4 * sizeof(uint32_t), st);
+  if (e != hipSuccess || bad_words == 0) return e;
+  hipLaunchKernelGGL(pack2_kernel, dim3((unsigned)((bad_words + 255) / 256)), dim3(256), 0, st, src, (unsigned long long)n, code, bad,
+                     (unsigned long long)bad_words);
+  return hipGetLastError();
+}
+
 // tables derived from (sequence, suffix array): see LcfIndexView
 static hipError_t build_lcf_tables(pgpu_index* idx, const char* genomic, hipStream_t st) {
   const uint32_t n = (uint32_t)idx->len;
+  {
+    const size_t bad_words = ((size_t)n + 31) / 32;
+    hipError_t pe = hipMalloc((void**)&idx->d_code, (2 * bad_words + 4) * sizeof(uint32_t));
+    if (pe != hipSuccess) return pe;
+    pe = hipMalloc((void**)&idx->d_bad, (bad_words + 4) * sizeof(uint32_t));
+    if (pe != hipSuccess) return pe;
+    pe = pack_sequence(idx->d_gen, n, idx->d_code, idx->d_bad, st);
+    if (pe != hipSuccess) return pe;
+  }
   uint32_t fb = n;
   for (uint32_t i = 0; i < n; ++i) { const char c = genomic[i]; if (c != 'A' && c != 'C' && c != 'G' && c != 'T') { fb = i; break; } }
   idx->first_bad = fb;
@@ -571,7 +664,7 @@ done:
   hipFree(rank); hipFree(sa2); hipFree(flags); hipFree(newrank); hipFree(keys); hipFree(keys2); hipFree(tmp);
   for (uint32_t* q : round_ranks) hipFree(q);
   hipFree(d_round_ptrs);
-  if (rc != PGPU_OK) { hipFree(idx->d_gen); hipFree(idx->d_sa); hipFree(idx->d_lcp); hipFree(idx->d_klo); hipFree(idx->d_khi); hipFree(idx->d_key); hipFree(idx->d_focc); hipFree(idx->d_rmq); delete idx; return rc; }
+  if (rc != PGPU_OK) { hipFree(idx->d_gen); hipFree(idx->d_sa); hipFree(idx->d_lcp); hipFree(idx->d_klo); hipFree(idx->d_khi); hipFree(idx->d_key); hipFree(idx->d_focc); hipFree(idx->d_rmq); hipFree(idx->d_code); hipFree(idx->d_bad); delete idx; return rc; }
   *out = idx;
   return PGPU_OK;
 }
@@ -670,7 +763,7 @@ extern "C" int pgpu_index_load(pgpu_ctx* ctx, const char* path, const char* geno
   TRY_HIP(build_lcf_tables(idx, genomic, st));
   TRY_HIP(hipStreamSynchronize(st));
 done:
-  if (rc != PGPU_OK) { hipFree(idx->d_gen); hipFree(idx->d_sa); hipFree(idx->d_lcp); hipFree(idx->d_klo); hipFree(idx->d_khi); hipFree(idx->d_key); hipFree(idx->d_focc); hipFree(idx->d_rmq); delete idx; return rc; }
+  if (rc != PGPU_OK) { hipFree(idx->d_gen); hipFree(idx->d_sa); hipFree(idx->d_lcp); hipFree(idx->d_klo); hipFree(idx->d_khi); hipFree(idx->d_key); hipFree(idx->d_focc); hipFree(idx->d_rmq); hipFree(idx->d_code); hipFree(idx->d_bad); delete idx; return rc; }
   *out = idx;
   return PGPU_OK;
 }
@@ -680,7 +773,7 @@ extern "C" int pgpu_index_destroy(pgpu_ctx* ctx, pgpu_index* idx) {
   if (pgpu_ctx_bind(ctx) != PGPU_OK) return PGPU_EDEVICE;
   hipStreamSynchronize(pgpu_ctx_stream(ctx));
   hipFree(idx->d_gen); hipFree(idx->d_sa); hipFree(idx->d_lcp); hipFree(idx->d_klo); hipFree(idx->d_khi); hipFree(idx->d_key);
-  hipFree(idx->d_focc); hipFree(idx->d_rmq);
+  hipFree(idx->d_focc); hipFree(idx->d_rmq); hipFree(idx->d_code); hipFree(idx->d_bad);
   delete idx;
   return PGPU_OK;
 }
@@ -704,6 +797,7 @@ struct pgpu_pairing_plan {
   size_t n_pat = 0;
   unsigned long long total_pos = 0;
   uint8_t* d_pats = nullptr;
+  uint32_t *d_pcode = nullptr, *d_pbad = nullptr;     // the patterns at 2 bits per base + flag bits (PackedSeq)
   unsigned long long* d_pat_off = nullptr;
   uint32_t *d_lo = nullptr, *d_hi = nullptr, *d_a = nullptr, *d_thr = nullptr, *d_cnt = nullptr,
            *d_cnt_a = nullptr, *d_cnt_b = nullptr;
@@ -744,7 +838,7 @@ static void pairing_plan_free(pgpu_pairing_plan* p) {
   if (!p) return;
   if (p->pooled) pgpu_ctx_pool_release(p->owner, 1);
   else {
-    hipFree(p->d_pats); hipFree(p->d_pat_off); hipFree(p->d_lo); hipFree(p->d_hi); hipFree(p->d_a);
+    hipFree(p->d_pats); hipFree(p->d_pcode); hipFree(p->d_pbad); hipFree(p->d_pat_off); hipFree(p->d_lo); hipFree(p->d_hi); hipFree(p->d_a);
     hipFree(p->d_thr); hipFree(p->d_cnt); hipFree(p->d_cnt_a); hipFree(p->d_cnt_b);
     hipFree(p->d_cand_off); hipFree(p->d_out_off); hipFree(p->d_out_first); hipFree(p->d_cand);
     hipFree(p->d_keep); hipFree(p->d_out); hipFree(p->d_tmp);
@@ -782,9 +876,15 @@ extern "C" int pgpu_pairing_plan_create(pgpu_ctx* ctx, const pgpu_index* idx, co
   NEED(p->d_out_first = plan_alloc<unsigned long long>(p, 11, n_pat + 1));
   p->tmp_bytes = pgpu_scan_tmp_bytes(std::max(tp, n_pat) + 1);
   NEED(p->d_tmp = plan_alloc<uint8_t>(p, 12, p->tmp_bytes));
+  {
+    const size_t bad_words = (tp + 31) / 32;
+    NEED(p->d_pcode = plan_alloc<uint32_t>(p, 21, 2 * bad_words + 4));
+    NEED(p->d_pbad = plan_alloc<uint32_t>(p, 22, bad_words + 4));
+  }
   if (pgpu_ctx_timing(ctx)) for (auto& e : p->ev) TRY_HIP(hipEventCreate(&e));
   if (tp) TRY_HIP(hipMemcpyAsync(p->d_pats, patterns, tp, hipMemcpyHostToDevice, st));
   TRY_HIP(hipMemcpyAsync(p->d_pat_off, pat_off, (n_pat + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+  TRY_HIP(pack_sequence(p->d_pats, tp, p->d_pcode, p->d_pbad, st));
   TRY_HIP(hipStreamSynchronize(st));
 done:
   if (rc != PGPU_OK) { pairing_plan_free(p); return rc; }
@@ -803,6 +903,7 @@ extern "C" int pgpu_pairing_plan_run(pgpu_ctx* ctx, pgpu_pairing_plan* p, const 
   const uint32_t n = (uint32_t)ix->len;
   const size_t tp = (size_t)p->total_pos;
   const PairParams prm{params->min_factor_len, params->min_string_depth_rate};
+  const PackedSeq Tp{ix->d_code, ix->d_bad}, Pp{p->d_pcode, p->d_pbad};
   const dim3 pgrid((unsigned)(p->n_pat ? p->n_pat : 1)), pblk(64);
   p->n_cand = p->n_out = 0;
   p->have_pairs = false;
@@ -810,17 +911,17 @@ extern "C" int pgpu_pairing_plan_run(pgpu_ctx* ctx, pgpu_pairing_plan* p, const 
   pgpu_range_push("pairings");
   struct PopAtExit { ~PopAtExit() { pgpu_range_pop(); } } pop_at_exit;
   if (p->ev[0]) TRY_HIP(hipEventRecord(p->ev[0], st));
-  hipLaunchKernelGGL(pair_locate_kernel, pgrid, pblk, 0, st, ix->d_gen, n, ix->d_sa, ix->d_klo, ix->d_khi, p->d_pats, p->d_pat_off, prm, p->d_lo, p->d_hi, p->d_a);
+  hipLaunchKernelGGL(pair_locate_kernel, pgrid, pblk, 0, st, ix->d_gen, n, ix->d_sa, ix->d_klo, ix->d_khi, p->d_pats, p->d_pat_off, prm, p->d_lo, p->d_hi, p->d_a, Tp, Pp);
   if (p->ev[1]) TRY_HIP(hipEventRecord(p->ev[1], st));
   hipLaunchKernelGGL(pair_chain_kernel, dim3((unsigned)((p->n_pat + 63) / 64)), pblk, 0, st, ix->d_gen, n, ix->d_sa, ix->d_lcp,
-                     p->d_pats, p->d_pat_off, (uint32_t)p->n_pat, prm, p->d_lo, p->d_hi, p->d_a, p->d_thr);
+                     p->d_pats, p->d_pat_off, (uint32_t)p->n_pat, prm, p->d_lo, p->d_hi, p->d_a, p->d_thr, Tp, Pp);
   if (p->ev[2]) TRY_HIP(hipEventRecord(p->ev[2], st));
-  hipLaunchKernelGGL(pair_count_kernel, pgrid, pblk, 0, st, ix->d_gen, n, ix->d_sa, ix->d_key, ix->sigma, p->d_pats, p->d_pat_off, prm, p->d_lo, p->d_hi, p->d_thr, p->d_cnt);
+  hipLaunchKernelGGL(pair_count_kernel, pgrid, pblk, 0, st, ix->d_gen, n, ix->d_sa, ix->d_key, ix->sigma, p->d_pats, p->d_pat_off, prm, p->d_lo, p->d_hi, p->d_thr, p->d_cnt, Tp, Pp);
   TRY_HIP(hipMemsetAsync(p->d_cnt + tp, 0, sizeof(uint32_t), st));
   pgpu_exclusive_scan_u32(p->d_cnt, p->d_cand_off, tp + 1, p->d_tmp, st);
   if (p->ev[3]) TRY_HIP(hipEventRecord(p->ev[3], st));
   TRY_HIP(hipMemcpyAsync(&p->n_cand, p->d_cand_off + tp, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-  TRY_HIP(hipStreamSynchronize(st));
+  TRY_HIP(pgpu_ctx_wait(ctx));
   if (p->n_cand > p->cand_cap || !p->d_cand) {
     if (!p->pooled) { hipFree(p->d_cand); hipFree(p->d_keep); }
     p->d_cand = nullptr; p->d_keep = nullptr;
@@ -829,14 +930,14 @@ extern "C" int pgpu_pairing_plan_run(pgpu_ctx* ctx, pgpu_pairing_plan* p, const 
     NEED(p->d_keep = plan_alloc<uint8_t>(p, 14, p->cand_cap));
   }
   hipLaunchKernelGGL(pair_fill_kernel, pgrid, pblk, 0, st, ix->d_gen, n, ix->d_sa, ix->d_key, ix->sigma, p->d_pats, p->d_pat_off, prm, p->d_lo, p->d_hi, p->d_thr,
-                     p->d_cand_off, p->d_cand, p->d_cnt_a);
+                     p->d_cand_off, p->d_cand, p->d_cnt_a, Tp, Pp);
   if (p->ev[4]) TRY_HIP(hipEventRecord(p->ev[4], st));
   hipLaunchKernelGGL(pair_cross_kernel, pgrid, pblk, 0, st, p->d_pat_off, p->d_cand_off, p->d_cand, p->d_cnt_a, p->d_keep, p->d_cnt_b);
   TRY_HIP(hipMemsetAsync(p->d_cnt_b + tp, 0, sizeof(uint32_t), st));
   pgpu_exclusive_scan_u32(p->d_cnt_b, p->d_out_off, tp + 1, p->d_tmp, st);
   if (p->ev[5]) TRY_HIP(hipEventRecord(p->ev[5], st));
   TRY_HIP(hipMemcpyAsync(&p->n_out, p->d_out_off + tp, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-  TRY_HIP(hipStreamSynchronize(st));
+  TRY_HIP(pgpu_ctx_wait(ctx));
   if (p->n_out > p->out_cap || !p->d_out) {
     if (!p->pooled) hipFree(p->d_out);
     p->d_out = nullptr;
@@ -846,7 +947,7 @@ extern "C" int pgpu_pairing_plan_run(pgpu_ctx* ctx, pgpu_pairing_plan* p, const 
   hipLaunchKernelGGL(pair_emit_kernel, pgrid, pblk, 0, st, p->d_pat_off, p->d_cand_off, p->d_cand, p->d_cnt_a, p->d_keep, p->d_out_off,
                      p->d_out, p->d_out_first, (uint32_t)p->n_pat, p->total_pos);
   if (p->ev[6]) TRY_HIP(hipEventRecord(p->ev[6], st));
-  TRY_HIP(hipStreamSynchronize(st));
+  TRY_HIP(pgpu_ctx_wait(ctx));
   TRY_HIP(hipGetLastError());
   if (p->ev[0]) for (int k = 0; k < 6; ++k) hipEventElapsedTime(&p->ms[k], p->ev[k], p->ev[k + 1]);
   p->have_pairs = true; p->last_L = params->min_factor_len;
@@ -879,7 +980,7 @@ extern "C" int pgpu_pairing_plan_run_meg(pgpu_ctx* ctx, pgpu_pairing_plan* p, co
   TRY_HIP(hipMemsetAsync(p->d_meg_bytes + np, 0, sizeof(uint32_t), st));
   pgpu_exclusive_scan_u32(p->d_meg_bytes, p->d_meg_off, (size_t)np + 1, p->d_tmp, st);
   TRY_HIP(hipMemcpyAsync(&p->meg_total, p->d_meg_off + np, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-  TRY_HIP(hipStreamSynchronize(st));
+  TRY_HIP(pgpu_ctx_wait(ctx));
   if (p->meg_total > p->meg_cap || !p->d_meg_out) {
     if (!p->pooled) hipFree(p->d_meg_out);
     p->d_meg_out = nullptr;
@@ -888,7 +989,7 @@ extern "C" int pgpu_pairing_plan_run_meg(pgpu_ctx* ctx, pgpu_pairing_plan* p, co
   }
   pgpu_meg_launch_emit(np, p->d_meg_scratch, p->d_meg_info, p->d_meg_off, p->d_meg_out, st);
   if (p->meg_ev[1]) TRY_HIP(hipEventRecord(p->meg_ev[1], st));
-  TRY_HIP(hipStreamSynchronize(st));
+  TRY_HIP(pgpu_ctx_wait(ctx));
   TRY_HIP(hipGetLastError());
   if (p->meg_ev[0]) hipEventElapsedTime(&p->meg_ms, p->meg_ev[0], p->meg_ev[1]);
 done:
@@ -907,7 +1008,7 @@ extern "C" int pgpu_pairing_plan_fetch_meg(pgpu_ctx* ctx, pgpu_pairing_plan* p, 
   if (p->n_pat == 0) { rec_first[0] = 0; return PGPU_OK; }
   if (p->meg_total) TRY_HIP(hipMemcpyAsync(out, p->d_meg_out, (size_t)p->meg_total, hipMemcpyDeviceToHost, st));
   TRY_HIP(hipMemcpyAsync(rec_first, p->d_meg_off, (p->n_pat + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-  TRY_HIP(hipStreamSynchronize(st));
+  TRY_HIP(pgpu_ctx_wait(ctx));
 done:
   return rc;
 }
@@ -939,7 +1040,7 @@ extern "C" int pgpu_pairing_plan_fetch(pgpu_ctx* ctx, pgpu_pairing_plan* p, pgpu
   if (p->n_pat == 0) { out_first[0] = 0; return PGPU_OK; }
   if (p->n_out) TRY_HIP(hipMemcpyAsync(out, p->d_out, (size_t)p->n_out * sizeof(pgpu_pairing), hipMemcpyDeviceToHost, st));
   TRY_HIP(hipMemcpyAsync(out_first, p->d_out_first, (p->n_pat + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-  TRY_HIP(hipStreamSynchronize(st));
+  TRY_HIP(pgpu_ctx_wait(ctx));
 done:
   return rc;
 }

@@ -41,9 +41,12 @@ void launch_wave_jobs(const DevJob* jobs, int n_segs, const int* family, const i
 // one launch for the one-job-per-workgroup sweeps and the wave-per-job families of a batch; returns
 // false (nothing launched) when the largest BORDERS pattern needs more LDS than a workgroup may share
 bool launch_dp_batch(const DevJob* jobs, int n_segs, const int* family, const int* start, const int* count,
-                     int bc_start, int bc_count, uint32_t bc_max_rows, int ac_start, int ac_count,
+                     int bc_start, int bc_count, uint32_t bc_max_rows, int ac_start, int ac_count, int lc_start, int lc_count,
                      DevResult* res, uint8_t* ws, uint8_t* strs, const LcfIndexView& ix, hipStream_t st);
-size_t dp_batch_lds_bytes(bool wave_jobs, int bc_count, uint32_t bc_max_rows, int ac_count);
+size_t dp_batch_lds_bytes(bool wave_jobs, int bc_count, uint32_t bc_max_rows, int ac_count, int lc_count);
+// ALIGN with 65 .. 4096 rows runs on four waves (align_coop_body): rows per lane of the 256-lane sweep, and the
+// bytes of one traceback entry (all rows of one lane in one column)
+static inline uint32_t align_coop_entry_bytes(uint32_t r_class) { const uint32_t R = r_class <= 4 ? 1u : r_class / 4; return R <= 4 ? 1u : R / 4; }
 // keys: one zeroed entry per job, (length << 44) | (2^28-1 - occ1) << 16 | (2^16-1 - occ2) of the best run; 0: none
 void launch_lcf(const DevJob* jobs, int njobs, uint32_t max_chunks, uint32_t max_l2,
                 unsigned long long* keys, hipStream_t st);
