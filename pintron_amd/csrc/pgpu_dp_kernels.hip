@@ -1011,7 +1011,9 @@ __device__ __forceinline__ void tb_flush(const uint8_t* path, uint32_t np, const
 __device__ __forceinline__ void align_traceback_wave(const DevJob& job, DevResult* res, const uint8_t* __restrict__ ws,
                                                      uint8_t* __restrict__ strs, const uint32_t lane,
                                                      uint8_t* win, uint8_t* path) {
-  const uint32_t n = job.la, m = job.lb, cap = n + m + 1;
+  // the walk is wave-uniform: its state has to be uniform for the compiler too (scalar registers and
+  // branches instead of per-lane values under an exec mask: a third of the instructions per step)
+  const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)job.la), m = (uint32_t)__builtin_amdgcn_readfirstlane((int)job.lb), cap = n + m + 1;
   uint8_t* ea = strs + job.str_off;
   uint8_t* ga = ea + cap;
   if (res->v[5] == 1) {                  // identity alignment
@@ -1024,8 +1026,9 @@ __device__ __forceinline__ void align_traceback_wave(const DevJob& job, DevResul
     }
     return;
   }
-  const bool strips = job.r_class == ROW_CLASS_STRIPS;     // more than 4096 rows: strips of 64*64 rows
-  const uint32_t R = strips ? 64u : job.r_class, EB = R <= 4 ? 1u : R / 4;
+  const uint32_t rcls = (uint32_t)__builtin_amdgcn_readfirstlane((int)job.r_class);
+  const bool strips = rcls == ROW_CLASS_STRIPS;            // more than 4096 rows: strips of 64*64 rows
+  const uint32_t R = strips ? 64u : rcls, EB = R <= 4 ? 1u : R / 4;
   const uint32_t lgR = 31u - (uint32_t)__builtin_clz(R);   // R is a power of two
   const uint32_t WS = TB_WIN_BYTES / (64u * EB);           // sweep steps per window
   const uint8_t* dirs = ws + job.ws_off + (strips ? 2 * strip_bnd_bytes(m) : 0);
@@ -1093,10 +1096,10 @@ __device__ __forceinline__ uint32_t align_coop_rows_per_lane(uint32_t r_class) {
 __device__ __forceinline__ void align_traceback_coop(const DevJob& job, DevResult* res, const uint8_t* __restrict__ ws,
                                                      uint8_t* __restrict__ strs, const uint32_t lane,
                                                      uint8_t* win, uint8_t* path) {
-  const uint32_t n = job.la, m = job.lb, cap = n + m + 1;
+  const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)job.la), m = (uint32_t)__builtin_amdgcn_readfirstlane((int)job.lb), cap = n + m + 1;
   uint8_t* ea = strs + job.str_off;
   uint8_t* ga = ea + cap;
-  const uint32_t R = align_coop_rows_per_lane(job.r_class), EB = R <= 4 ? 1u : R / 4;
+  const uint32_t R = align_coop_rows_per_lane((uint32_t)__builtin_amdgcn_readfirstlane((int)job.r_class)), EB = R <= 4 ? 1u : R / 4;
   const uint32_t lgR = 31u - (uint32_t)__builtin_clz(R);
   const uint32_t WS = TB_WIN_BYTES / (64u * EB);           // sweep steps per window (band of 64 lanes)
   const uint8_t* dirs = ws + job.ws_off;
@@ -1351,7 +1354,8 @@ void gap_any_kernel(const DevJob* __restrict__ jobs, int njobs, DevResult* __res
 __device__ __forceinline__ void gap_traceback_wave(const DevJob& job, DevResult* res, const uint8_t* __restrict__ ws,
                                                    uint8_t* __restrict__ strs, const uint32_t lane,
                                                    uint8_t* win, uint8_t* path) {
-  const uint32_t n = job.la, m = job.lb, cap = n + m + 1, R = job.r_class;
+  const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)job.la), m = (uint32_t)__builtin_amdgcn_readfirstlane((int)job.lb), cap = n + m + 1,
+                 R = (uint32_t)__builtin_amdgcn_readfirstlane((int)job.r_class);       // uniform walk state: see align_traceback_wave
   const uint32_t lgR = 31u - (uint32_t)__builtin_clz(R);
   const uint32_t WS = TB_WIN_BYTES / (64u * R);            // 1 B per cell: an entry is R bytes
   uint8_t* ea = strs + job.str_off;

@@ -229,7 +229,7 @@ typedef struct shared {
   ef_inputs* in;
   pgpu_index* idx;
   unit* units; size_t n_units;
-  size_t next_unit;                    /* protected by mu */
+  size_t next_unit;                    /* dealt out with an atomic add (start_fiber) */
   pthread_mutex_t mu;
   size_t max_fibers, stack_size;
   /* pairings of every list entry at the configured (min_factor_len, rate), computed in ONE
@@ -244,7 +244,7 @@ typedef struct shared {
   bool use_meg;
   pgpu_meg_params meg_prm;
   unsigned char* pre_meg[PRE_CHUNKS]; size_t pre_meg_cap[PRE_CHUNKS]; uint64_t* pre_meg_first[PRE_CHUNKS];
-  size_t ready_entries;                       /* entries below this have their pairings (under mu) */
+  size_t ready_entries;                       /* entries below this have their pairings (written under mu with a release store; read without the lock) */
   pthread_cond_t ready_cv;
   bool kernel_timing;
   size_t gen_len;
@@ -405,17 +405,27 @@ static bool start_fiber(worker* w, int li) {
   shared* sh = w->sh;
   lane* ln = &w->lanes[li];
   fiber* f = w->free_fibers;
-  pthread_mutex_lock(&sh->mu);
-  const size_t u = sh->next_unit < sh->n_units ? sh->next_unit++ : (size_t)-1;
-  if (u != (size_t)-1 && sh->n_pre) {          /* the pairings of this unit may still be on their way */
+  /* The units are dealt out with one atomic add: a step over a C5 share hands out 1.5 million units per
+   * second to sixteen workers, and a mutex taken per unit turns into a convoy now and then (the same run
+   * then needs 250 ms instead of 170).  The lock is only taken to wait for the prefetch stage and to draw
+   * from the shared fibre pool (first step). */
+  const size_t u = __atomic_fetch_add(&sh->next_unit, 1, __ATOMIC_RELAXED);
+  if (u >= sh->n_units) return false;
+  if (sh->n_pre) {                             /* the pairings of this unit may still be on their way */
     const size_t last = sh->units[u].first + (sh->units[u].has_sibling ? 1 : 0);
-    while (last >= sh->ready_entries && !sh->failed) pthread_cond_wait(&sh->ready_cv, &sh->mu);
+    if (last >= __atomic_load_n(&sh->ready_entries, __ATOMIC_ACQUIRE)) {
+      pthread_mutex_lock(&sh->mu);
+      while (last >= sh->ready_entries && !sh->failed) pthread_cond_wait(&sh->ready_cv, &sh->mu);
+      pthread_mutex_unlock(&sh->mu);
+    }
   }
-  if (sh->failed) { pthread_mutex_unlock(&sh->mu); return false; }
-  if (u != (size_t)-1 && !f && sh->fiber_pool) { f = sh->fiber_pool; sh->fiber_pool = f->pool_next; f->pool_next = NULL; }
-  else if (u != (size_t)-1 && f) w->free_fibers = f->pool_next;
-  pthread_mutex_unlock(&sh->mu);
-  if (u == (size_t)-1) return false;
+  if (__atomic_load_n(&sh->failed, __ATOMIC_RELAXED)) return false;
+  if (f) w->free_fibers = f->pool_next;
+  else if (__atomic_load_n(&sh->fiber_pool, __ATOMIC_RELAXED)) {
+    pthread_mutex_lock(&sh->mu);
+    if (sh->fiber_pool) { f = sh->fiber_pool; sh->fiber_pool = f->pool_next; f->pool_next = NULL; }
+    pthread_mutex_unlock(&sh->mu);
+  }
   if (f) {                       /* recycled: keep the stack and the sink blocks */
     char* st = f->stack;
     const bool gd = f->guarded;
@@ -1125,7 +1135,7 @@ static void* prefetch_main(void* arg) {
     for (int k = 0; k < 6; ++k) s->pre_kernel_ms[k] += pgpu_pairing_plan_kernel_ms(s->pplan[c], k);
     pthread_mutex_lock(&sh->mu);
     if (prc != PGPU_OK) { fprintf(stderr, "* FATAL pairing prefetch failed: %s\n", pgpu_last_error(s->ctx0)); sh->failed = 1; }
-    else sh->ready_entries = sh->pre_lo[c + 1];
+    else __atomic_store_n(&sh->ready_entries, sh->pre_lo[c + 1], __ATOMIC_RELEASE);
     pthread_cond_broadcast(&sh->ready_cv);
     pthread_mutex_unlock(&sh->mu);
     pgpu_range_pop();
