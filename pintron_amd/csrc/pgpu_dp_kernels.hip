@@ -1052,11 +1052,10 @@ __device__ __forceinline__ void align_traceback_wave(const DevJob& job, DevResul
     }
     uint32_t d = (win[((s - s_lo) * 64u + l) * EB + (r >> 2)] >> (2u * (r & 3u))) & 3u;
     d = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);  // the walk is wave-uniform: keep it scalar
-    if (lane == 0) path[np] = (uint8_t)d;
+    path[np] = (uint8_t)d;                                // every lane, same address, same value: no exec games
     ++np;
-    if (d == 0)      { --i; --j; }
-    else if (d == 1) { --i; }
-    else             { --j; }
+    i -= d < 2u ? 1u : 0u;                                 // 0: diagonal, 1: up, 2: left -- no branches in the step
+    j -= d != 1u ? 1u : 0u;
     if (np == TB_PATH) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -1127,11 +1126,10 @@ __device__ __forceinline__ void align_traceback_coop(const DevJob& job, DevResul
     }
     uint32_t d = (win[((s - s_lo) * 64u + (gl - g_lo)) * EB + (r >> 2)] >> (2u * (r & 3u))) & 3u;
     d = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
-    if (lane == 0) path[np] = (uint8_t)d;
+    path[np] = (uint8_t)d;                                // every lane, same address, same value: no exec games
     ++np;
-    if (d == 0)      { --i; --j; }
-    else if (d == 1) { --i; }
-    else             { --j; }
+    i -= d < 2u ? 1u : 0u;                                 // 0: diagonal, 1: up, 2: left -- no branches in the step
+    j -= d != 1u ? 1u : 0u;
     if (np == TB_PATH) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -1382,24 +1380,19 @@ __device__ __forceinline__ void gap_traceback_wave(const DevJob& job, DevResult*
     }
     uint32_t b = win[((s - s_lo) * 64u + l) * R + r];
     b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
-    // decode to the reference's direction values: 0, 1, 2, or -2 (here 3)
-    uint32_t d;
-    if (plane == 2) d = (b >> 3) & 3u;
-    else if (plane == 1) d = ((b >> 2) & 1u) ? 3u : 2u;
-    else d = b & 3u;
-    if (lane == 0) path[np] = (uint8_t)d;
+    // decode to the reference's direction values: 0, 1, 2, or -2 (here 3); selects, not branches
+    const uint32_t dR = (b >> 3) & 3u, dG = 2u + ((b >> 2) & 1u), dL = b & 3u;
+    const uint32_t d = plane == 2 ? dR : (plane == 1 ? dG : dL);
+    path[np] = (uint8_t)d;                                 // every lane, same address, same value
     const uint32_t kk = k + np;                            // steps taken before this one
     ++np;
-    if (d == 0)      { --i; --j; }
-    else if (d == 1) { --i; }
-    else {
-      if (d == 3) {
-        if (plane == 2) { intron_end = (int32_t)j - 1; factor_cut = (int32_t)i; rev_end = (int32_t)kk; }
-        else            { intron_start = (int32_t)j - 1; rev_start = (int32_t)kk; }
-        --plane;
-      }
-      --j;
+    if (d == 3) {                                          // twice per job: the walk changes plane
+      if (plane == 2) { intron_end = (int32_t)j - 1; factor_cut = (int32_t)i; rev_end = (int32_t)kk; }
+      else            { intron_start = (int32_t)j - 1; rev_start = (int32_t)kk; }
+      --plane;
     }
+    i -= d < 2u ? 1u : 0u;
+    j -= d != 1u ? 1u : 0u;
     if (np == TB_PATH) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
