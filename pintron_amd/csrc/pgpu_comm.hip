@@ -165,7 +165,8 @@ extern "C" int pgpu_gather(pgpu_ctx* ctx, pgpu_comm* c, const void* send, uint64
       }
     }
     // own part straight into place, the others over the wire
-    if (send_bytes && !sink) HIP_TRY2(hipMemcpyAsync(c->d_recv, send, send_bytes, hipMemcpyHostToDevice, st));
+    if (send_bytes && !sink && hipMemcpyAsync(c->d_recv, send, send_bytes, hipMemcpyHostToDevice, st) != hipSuccess)
+      later = PGPU_EDEVICE;                              // reported after the receives have been posted
     int grc = g_rccl.GroupStart();
     if (grc == 0) {
       uint64_t at = counts[0];
@@ -185,6 +186,7 @@ extern "C" int pgpu_gather(pgpu_ctx* ctx, pgpu_comm* c, const void* send, uint64
   }
   HIP_TRY2(hipStreamSynchronize(st));
   if (later == PGPU_ENOSPC) return pgpu_ctx_fail(ctx, PGPU_ENOSPC, "gather buffer too small");
+  if (later == PGPU_EDEVICE) return pgpu_ctx_fail(ctx, PGPU_EDEVICE, "copy of rank 0's own payload failed");
   if (later != PGPU_OK) return pgpu_ctx_fail(ctx, later, "out of device memory in gather");
   return PGPU_OK;
 }

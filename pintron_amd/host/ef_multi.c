@@ -163,7 +163,11 @@ static int run_shard(int argc, char** argv, int rank, int world, const char* id_
   }
   /* nobody enters the communicator unless everybody can */
   health_post(id_path, rank, rc == 0);
-  if (health_wait(id_path, world, 120.0) != 0) {
+  /* (a rank that died is reported by the parent's watchdog at once; the limit only bounds a rank that lives and
+   * never gets through its start-up: PINTRON_RANK_TIMEOUT_S, 900 s by default -- a very large ests.txt on a cold
+   * file system is parsed in well under that) */
+  const char* lim = getenv("PINTRON_RANK_TIMEOUT_S");
+  if (health_wait(id_path, world, lim && atof(lim) > 0 ? atof(lim) : 900.0) != 0) {
     if (rc == 0) fprintf(stderr, "* FATAL rank %d: another rank could not start (GPU missing or not gfx950, input unreadable): giving up\n", rank);
     if (s) ef_session_close(s);
     return 1;

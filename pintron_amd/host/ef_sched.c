@@ -204,7 +204,7 @@ static inline void worker_sleep(uint32_t* wake, uint32_t seen) {
   syscall(SYS_futex, wake, FUTEX_WAIT_PRIVATE, seen, NULL, NULL, 0);
 }
 
-#define MAX_SERVICES 4
+#define MAX_SERVICES 8
 typedef struct service_thread {          /* one submitter: own context (stream, device buffers) */
   pthread_t thread;
   struct service* sv;
@@ -265,7 +265,7 @@ typedef struct out_chunk { struct out_chunk* next; size_t cap, used; char data[]
 /* A worker keeps several independent sets of fibres ("lanes"): while the requests of one lane are
  * with the GPU service, the fibres of the other lanes run on the CPU, so the worker only sleeps
  * when every lane is waiting. */
-#define MAX_LANES 8
+#define MAX_LANES 16
 typedef struct lane {
   fiber** fibers; size_t n_fibers;
   ef_jobbuf jb;
@@ -975,7 +975,10 @@ ef_session* ef_session_open(int argc, char** argv) {
   memset(&boot, 0, sizeof boot);
   boot.rc = boot.idx_rc = boot.svc_rc = PGPU_EDEVICE;
   boot.gen = s->in.gen->seq; boot.gen_len = strlen(s->in.gen->seq);
-  boot.n_svc = (int)env_size("PINTRON_SERVICES", 3);
+  /* four service threads, no coalescing wait, eight lanes per worker: since a batch became one launch on one
+   * stream (round 3) many small batches beat few large ones -- +9 % on C3, +14 % on a C5 share against
+   * 3 / 50 us / 4 (profiles/r03_sweep_sched_*.txt) */
+  boot.n_svc = (int)env_size("PINTRON_SERVICES", 4);
   if (boot.n_svc > MAX_SERVICES) boot.n_svc = MAX_SERVICES;
   pthread_t boot_thread;
   const bool booting = pthread_create(&boot_thread, NULL, gpu_boot_main, &boot) == 0;
@@ -1026,7 +1029,7 @@ ef_session* ef_session_open(int argc, char** argv) {
     }
   }
   sh->svc.n_threads = boot.n_svc;
-  sh->svc.coalesce_us = getenv("PINTRON_COALESCE_US") ? atol(getenv("PINTRON_COALESCE_US")) : 50;
+  sh->svc.coalesce_us = getenv("PINTRON_COALESCE_US") ? atol(getenv("PINTRON_COALESCE_US")) : 0;
   if (boot.svc_rc != PGPU_OK) {
     fprintf(stderr, "* FATAL the GPU contexts of the service threads could not be created\n");
     ef_session_close(s); return NULL;
@@ -1050,7 +1053,7 @@ ef_session* ef_session_open(int argc, char** argv) {
                                  c->trans_red ? 1u : 0u, c->short_edge_comp ? 1u : 0u };
     sh->meg_prm = mp;
   }
-  sh->n_lanes = (int)env_size("PINTRON_LANES", 4);
+  sh->n_lanes = (int)env_size("PINTRON_LANES", 8);
   if (sh->n_lanes > MAX_LANES) sh->n_lanes = MAX_LANES;
   s->load_s = t_loaded - t_start;
   s->index_s = now_s() - t_loaded;
