@@ -978,7 +978,12 @@ ef_session* ef_session_open(int argc, char** argv) {
   /* four service threads, no coalescing wait, eight lanes per worker: since a batch became one launch on one
    * stream (round 3) many small batches beat few large ones -- +9 % on C3, +14 % on a C5 share against
    * 3 / 50 us / 4 (profiles/r03_sweep_sched_*.txt) */
-  boot.n_svc = (int)env_size("PINTRON_SERVICES", 4);
+  {                                          /* ... one service thread per four cores of this rank's share, at most four */
+    size_t dflt = host_core_share() / 4;
+    if (dflt < 1) dflt = 1;
+    if (dflt > 4) dflt = 4;
+    boot.n_svc = (int)env_size("PINTRON_SERVICES", dflt);
+  }
   if (boot.n_svc > MAX_SERVICES) boot.n_svc = MAX_SERVICES;
   pthread_t boot_thread;
   const bool booting = pthread_create(&boot_thread, NULL, gpu_boot_main, &boot) == 0;
