@@ -224,7 +224,7 @@ typedef struct service {
   service_thread threads[MAX_SERVICES];
 } service;
 
-#define PRE_CHUNKS 8
+#define PRE_CHUNKS 16                 /* at most; PINTRON_PRE_CHUNKS ranges are used (default 10) */
 typedef struct shared {
   ef_inputs* in;
   pgpu_index* idx;
@@ -1026,8 +1026,11 @@ ef_session* ef_session_open(int argc, char** argv) {
     k += u->has_sibling ? 2 : 1;
   }
   if (!getenv("PINTRON_NO_PREFETCH") && in->n > 0) {
-    /* PRE_CHUNKS ranges of whole units with about the same number of entries */
-    sh->n_pre = sh->n_units < PRE_CHUNKS ? (int)sh->n_units : PRE_CHUNKS;
+    /* ranges of whole units with about the same number of entries (the workers wait for the first one only;
+     * small first ranges -- 1/32, 1/32, 1/16, then eighths -- were tried and lost 2.5 %: profiles/r03_sweep_chunks.txt) */
+    size_t want = env_size("PINTRON_PRE_CHUNKS", 10);
+    if (want > PRE_CHUNKS) want = PRE_CHUNKS;
+    sh->n_pre = sh->n_units < want ? (int)sh->n_units : (int)want;
     for (int cidx = 0; cidx <= sh->n_pre; ++cidx) {
       const size_t u = sh->n_units * (size_t)cidx / (size_t)sh->n_pre;
       sh->pre_lo[cidx] = u < sh->n_units ? sh->units[u].first : in->n;
