@@ -328,3 +328,28 @@ def test_closing_stderr_lines_have_the_reference_format(bins, tmp_path):
     assert re.fullmatch(r"\* INFO \(resource_usage\.\.@          src/util.c:187 \) User time:   +\d+s +\d+microsec\.  ", tail[6]), tail[6]
     assert re.fullmatch(r"\* INFO \(resource_usage\.\.@          src/util.c:188 \) System time: +\d+s +\d+microsec\.  ", tail[7]), tail[7]
     assert re.fullmatch(r"\* INFO \(resource_usage\.\.@          src/util.c:199 \) Mem\. used: +\d+KB  ", tail[8]), tail[8]
+
+
+def test_dp_trace_and_replay(bins, tmp_path):
+    """PINTRON_DP_TRACE records every answered DP request of a run; tools/replay_dp_trace.py puts them through
+    the oracle.  Here the answers come from the oracle itself (CPU stand-in of the C-ABI), so none may differ --
+    and a record corrupted on purpose must be reported.  (On the GPU box the same pair splits a wrong output into
+    "a kernel answered wrongly" and "the host logic went wrong": tools/stress_parity.py.)"""
+    import struct
+    import sys
+    for f in ("genomic.txt", "ests.txt"):
+        shutil.copy(os.path.join(GOLD, f), tmp_path)
+    trace = tmp_path / "dp.trace"
+    run(bins["estfact_sched_check"], tmp_path, {"PINTRON_THREADS": "3", "PINTRON_DP_TRACE": str(trace)})
+    tool = os.path.join(os.path.dirname(HERE), "tools", "replay_dp_trace.py")
+    ok = subprocess.run([sys.executable, tool, str(trace)], capture_output=True, text=True)
+    assert ok.returncode == 0 and "; 0 differ from the oracle" in ok.stdout, ok.stdout[-500:]
+    n = int(ok.stdout.split()[0])
+    assert n > 1500
+    data = bytearray(trace.read_bytes())
+    v0 = struct.unpack_from("<i", data, 36)[0]
+    struct.pack_into("<i", data, 36, v0 + 1)                 # first value of the first record
+    bad = tmp_path / "bad.trace"
+    bad.write_bytes(bytes(data))
+    r = subprocess.run([sys.executable, tool, str(bad)], capture_output=True, text=True)
+    assert r.returncode == 1 and "; 1 differ from the oracle" in r.stdout, r.stdout[-500:]
