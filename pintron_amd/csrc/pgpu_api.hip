@@ -77,8 +77,11 @@ static void* pinned(pgpu_ctx* ctx, int slot, size_t bytes) {
   if (ctx->pin_cap[slot] < bytes) {
     if (ctx->pin[slot]) (void)hipHostFree(ctx->pin[slot]);
     ctx->pin[slot] = nullptr; ctx->pin_cap[slot] = 0;
-    const size_t want = bytes + bytes / 2 + 4096;
+    // never less than 2 MB: the first batches of a run grow from a few hundred jobs to thousands, and every
+    // regrowth is a free (which waits for the device) and an allocation
+    const size_t want = std::max<size_t>(bytes + bytes / 2 + 4096, (size_t)2 << 20);
     if (hipHostMalloc(&ctx->pin[slot], want, hipHostMallocDefault) != hipSuccess) return nullptr;
+    pgpu_trace_alloc(slot ? "ctx pinned down" : "ctx pinned up", ctx->pin[slot], want);
     ctx->pin_cap[slot] = want;
   }
   return ctx->pin[slot];
@@ -97,11 +100,12 @@ void* pgpu_ctx_pool_get(pgpu_ctx* ctx, int pool, int slot, size_t bytes) {
   if (p.cap[slot] < bytes) {
     if (p.ptr[slot]) (void)hipFree(p.ptr[slot]);
     p.ptr[slot] = nullptr; p.cap[slot] = 0;
-    const size_t want = bytes + bytes / 2 + 4096;
+    const size_t want = std::max<size_t>(bytes + bytes / 2 + 4096, pool == 0 ? (size_t)64 << 20 : 0);
     if (hipMalloc(&p.ptr[slot], want) != hipSuccess) {
       if (hipMalloc(&p.ptr[slot], bytes) != hipSuccess) return nullptr;
       p.cap[slot] = bytes;
     } else p.cap[slot] = want;
+    pgpu_trace_alloc(pool ? "device pool 1" : "device pool 0", p.ptr[slot], p.cap[slot]);
   }
   return p.ptr[slot];
 }
@@ -206,6 +210,12 @@ extern "C" const char* pgpu_build_info(void) {
   return info;
 }
 
+static bool aux_stream(pgpu_ctx* ctx, int i) {
+  if (!ctx->aux[i] && hipStreamCreateWithFlags(&ctx->aux[i], hipStreamNonBlocking) != hipSuccess) { ctx->aux[i] = nullptr; return false; }
+  if (!ctx->ev_aux[i] && hipEventCreateWithFlags(&ctx->ev_aux[i], hipEventDisableTiming) != hipSuccess) { ctx->ev_aux[i] = nullptr; return false; }
+  return true;
+}
+
 extern "C" int pgpu_init(int device, pgpu_ctx** out) {
   if (!out) return PGPU_EINVAL;
   *out = nullptr;
@@ -223,13 +233,11 @@ extern "C" int pgpu_init(int device, pgpu_ctx** out) {
     delete ctx;
     return PGPU_EDEVICE;
   }
-  for (auto& a : ctx->aux)
-    if (hipStreamCreateWithFlags(&a, hipStreamNonBlocking) != hipSuccess) { delete ctx; return PGPU_EDEVICE; }
+  // the auxiliary streams are made when a plan first forks onto them (aux_stream): a stream costs ~5 ms and
+  // ~17 MB of host memory in the runtime, and the default one-launch batch forks only for LCF jobs with an N
   if (hipEventCreateWithFlags(&ctx->ev_upload, hipEventDisableTiming) != hipSuccess) { delete ctx; return PGPU_EDEVICE; }
   if (hipEventCreateWithFlags(&ctx->ev_done, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) { delete ctx; return PGPU_EDEVICE; }
   if (hipEventCreateWithFlags(&ctx->ev_wait, hipEventDisableTiming) != hipSuccess) { delete ctx; return PGPU_EDEVICE; }
-  for (auto& e : ctx->ev_aux)
-    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete ctx; return PGPU_EDEVICE; }
   { const char* f = getenv("PGPU_FANOUT"); ctx->fanout = !(f && f[0] == '0'); }
   { const char* f = getenv("PGPU_WAIT"); if (f) ctx->wait_poll_us = atol(f); }
   { const char* f = getenv("PGPU_ALIGN_COOP"); if (f && f[0] == '0') ctx->align_coop = false; }
@@ -752,7 +760,10 @@ extern "C" int pgpu_dp_plan_launch(pgpu_ctx* ctx, pgpu_dp_plan* p) {
   if (used_mask) {            // fork: the upload (plan_create) is on the main stream
     HIP_TRY(ctx, hipEventRecord(ctx->ev_upload, ctx->stream));
     for (int i = 0; i < pgpu_ctx::NAUX; ++i)
-      if (used_mask & (1u << i)) HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux[i], ctx->ev_upload, 0));
+      if (used_mask & (1u << i)) {
+        if (!aux_stream(ctx, i)) return set_err(ctx, PGPU_EDEVICE, "auxiliary stream %d could not be created", i);
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux[i], ctx->ev_upload, 0));
+      }
   }
   for (size_t oi = 0; oi < order.size(); ++oi) {
     for (size_t gi = order[oi]; gi < p->groups.size() && (gi == order[oi] || p->groups[gi].traceback); ++gi) {

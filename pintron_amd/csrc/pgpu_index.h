@@ -46,3 +46,12 @@ void pgpu_meg_launch_build(const pgpu_pairing* pairs, const unsigned long long* 
                            hipStream_t st);
 void pgpu_meg_launch_emit(uint32_t n_pat, const void* scratch, const void* info, const unsigned long long* rec_off,
                           uint8_t* out, hipStream_t st);
+// PGPU_TRACE_ALLOC=1: every page-locked host allocation of the library on stderr (size, address, call site)
+#include <cstdio>
+#include <cstdlib>
+static inline void pgpu_trace_alloc(const char* what, const void* q, size_t bytes) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("PGPU_TRACE_ALLOC"); on = (e && *e && *e != '0') ? 1 : 0; }
+  if (on) fprintf(stderr, "* alloc %-18s %10.1f MB at %p\n", what, bytes / 1048576.0, q);
+}
+

@@ -835,7 +835,9 @@ template <class T> static T* plan_alloc(pgpu_pairing_plan* p, int slot, size_t c
   const size_t bytes = (count ? count : 1) * sizeof(T);
   if (p->pooled) return (T*)pgpu_ctx_pool_get(p->owner, 1, slot, bytes);
   void* q = nullptr;
-  return hipMalloc(&q, bytes) == hipSuccess ? (T*)q : nullptr;
+  if (hipMalloc(&q, bytes) != hipSuccess) return nullptr;
+  pgpu_trace_alloc("plan device", q, bytes);
+  return (T*)q;
 }
 
 static void pairing_plan_free(pgpu_pairing_plan* p) {
@@ -1022,6 +1024,7 @@ extern "C" int pgpu_host_alloc(pgpu_ctx* ctx, size_t bytes, void** out) {
   *out = nullptr;
   if (pgpu_ctx_bind(ctx) != PGPU_OK) return PGPU_EDEVICE;
   if (hipHostMalloc(out, bytes ? bytes : 16, hipHostMallocDefault) != hipSuccess) return pgpu_ctx_fail(ctx, PGPU_ENOMEM, "out of page-locked host memory");
+  pgpu_trace_alloc("pgpu_host_alloc", *out, bytes);
   return PGPU_OK;
 }
 extern "C" int pgpu_host_free(pgpu_ctx* ctx, void* q) {

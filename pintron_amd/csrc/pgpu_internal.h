@@ -58,3 +58,4 @@ constexpr uint32_t ROW_CLASS_STRIPS = 128;
 __host__ __device__ inline size_t strip_bnd_bytes(uint32_t nc) { return (((size_t)nc + 1) * 4 + 15) & ~(size_t)15; }
 static inline uint32_t align_entry_bytes(uint32_t R) { return R == ROW_CLASS_STRIPS ? 16u : (R <= 4 ? 1u : R / 4); }
 static inline uint32_t gap_entry_bytes(uint32_t R) { return R; }
+

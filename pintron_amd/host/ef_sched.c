@@ -23,6 +23,8 @@
 #define _GNU_SOURCE
 #include <malloc.h>
 #include <pthread.h>
+#include <sys/uio.h>
+#include <errno.h>
 #include <sys/prctl.h>
 #include <sys/syscall.h>
 #include <linux/futex.h>
@@ -1265,11 +1267,47 @@ int ef_session_step(ef_session* s, ef_sched_stats* stats_out) {
   return sh->failed ? 1 : 0;
 }
 
-/* the six files of the step, in input order, into the current directory */
-/* one of the six files: the units' text in input order (one writer thread per file) */
+/* the six files of the step, in input order, into the current directory: every file is cut into ranges of
+ * units, a range is one task (gathering pwritev calls at the offset the lengths before it give), and a few
+ * threads take the tasks -- the largest file alone (raw-multifasta-out, ~150 MB on C3) no longer sets the time */
+enum { WRITE_RANGES = 8, WRITE_THREADS_MAX = 16, WRITE_IOV = 512 };
+typedef struct { int fd, k; size_t u0, u1; off_t at; } write_task;
+typedef struct { shared* sh; write_task* tasks; int n_tasks; int next; int failed; } write_pool;
+static void* write_pool_main(void* arg) {
+  pthread_setname_np(pthread_self(), "ef-writer");
+  write_pool* wp = (write_pool*)arg;
+  struct iovec iov[WRITE_IOV];
+  for (;;) {
+    const int t = __atomic_fetch_add(&wp->next, 1, __ATOMIC_RELAXED);
+    if (t >= wp->n_tasks) return NULL;
+    const write_task* wt = &wp->tasks[t];
+    off_t at = wt->at;
+    size_t u = wt->u0;
+    while (u < wt->u1) {
+      int n = 0; size_t bytes = 0;
+      for (; u < wt->u1 && n < WRITE_IOV; ++u) {
+        const unit* un = &wp->sh->units[u];
+        if (!un->len[wt->k]) continue;
+        iov[n].iov_base = un->buf[wt->k]; iov[n].iov_len = un->len[wt->k]; bytes += un->len[wt->k]; ++n;
+      }
+      int first = 0;
+      while (bytes) {                                   /* a short write continues where it stopped */
+        const ssize_t w = pwritev(wt->fd, iov + first, n - first, at);
+        if (w < 0) { if (errno == EINTR) continue; __atomic_store_n(&wp->failed, 1, __ATOMIC_RELAXED); return NULL; }
+        at += w; bytes -= (size_t)w;
+        size_t left = (size_t)w;
+        while (left && first < n) {
+          if (left >= iov[first].iov_len) { left -= iov[first].iov_len; ++first; }
+          else { iov[first].iov_base = (char*)iov[first].iov_base + left; iov[first].iov_len -= left; left = 0; }
+        }
+      }
+    }
+  }
+}
+
+/* units' text of file k (0..5, 6 = records) through a stream, in input order */
 typedef struct { shared* sh; FILE* f; int k; } file_writer;
 static void* file_writer_main(void* arg) {
-  pthread_setname_np(pthread_self(), "ef-writer");
   file_writer* fw = (file_writer*)arg;
   setvbuf(fw->f, NULL, _IOFBF, 1 << 20);
   for (size_t u = 0; u < fw->sh->n_units; ++u)
@@ -1282,11 +1320,37 @@ int ef_session_write_outputs(ef_session* s) {
   if (ef_open_outputs(&out)) return 1;
   shared* sh = &s->sh;
   FILE* dst[6] = { out.fout.f, out.fests.f, out.fmeg.f, out.fpmeg.f, out.ftmeg.f, out.fintronic.f };
-  file_writer fw[6]; pthread_t th[6]; bool started[6];
+  write_task tasks[6 * WRITE_RANGES];
+  write_pool wp = { sh, tasks, 0, 0, 0 };
   for (int k = 0; k < 6; ++k) {
-    fw[k].sh = sh; fw[k].f = dst[k]; fw[k].k = k;
-    started[k] = pthread_create(&th[k], NULL, file_writer_main, &fw[k]) == 0;
-    if (!started[k]) file_writer_main(&fw[k]);
+    fflush(dst[k]);
+    off_t at = 0;
+    for (int r = 0; r < WRITE_RANGES; ++r) {
+      const size_t u0 = sh->n_units * (size_t)r / WRITE_RANGES, u1 = sh->n_units * (size_t)(r + 1) / WRITE_RANGES;
+      size_t bytes = 0;
+      for (size_t u = u0; u < u1; ++u) bytes += sh->units[u].len[k];
+      if (bytes) { write_task wt = { fileno(dst[k]), k, u0, u1, at }; tasks[wp.n_tasks++] = wt; }
+      at += (off_t)bytes;
+    }
+  }
+  /* largest tasks first: the ranges of one file are about equal, the files are not */
+  {
+    size_t w[6] = {0};
+    for (int k = 0; k < 6; ++k) for (size_t u = 0; u < sh->n_units; u += 64) w[k] += sh->units[u].len[k];
+    for (int a = 1; a < wp.n_tasks; ++a) {
+      const write_task t = tasks[a]; int b = a;
+      while (b > 0 && w[tasks[b - 1].k] < w[t.k]) { tasks[b] = tasks[b - 1]; --b; }
+      tasks[b] = t;
+    }
+  }
+  {
+    size_t nth = env_size("PINTRON_WRITE_THREADS", host_core_share());
+    if (nth > WRITE_THREADS_MAX) nth = WRITE_THREADS_MAX;
+    if (nth > (size_t)wp.n_tasks) nth = (size_t)wp.n_tasks;
+    pthread_t th[WRITE_THREADS_MAX]; size_t started = 0;
+    for (size_t t = 1; t < nth; ++t) if (pthread_create(&th[started], NULL, write_pool_main, &wp) == 0) ++started;
+    write_pool_main(&wp);
+    for (size_t t = 0; t < started; ++t) pthread_join(th[t], NULL);
   }
   /* PINTRON_RECORDS_FILE=<path>: the packed factorization records (include/pintron_records.h) too */
   const char* rec_path = getenv("PINTRON_RECORDS_FILE");
@@ -1300,8 +1364,8 @@ int ef_session_write_outputs(ef_session* s) {
       if (fclose(rf) != 0) rec_rc = 1;
     }
   }
-  for (int k = 0; k < 6; ++k) if (started[k]) pthread_join(th[k], NULL);
   ef_close_outputs(&out);
+  if (wp.failed) { fprintf(stderr, "* FATAL writing the output files failed\n"); return 1; }
   return rec_rc;
 }
 
