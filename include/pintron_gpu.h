@@ -109,6 +109,15 @@ int pgpu_pairings(pgpu_ctx* ctx, const pgpu_index* idx,
 typedef struct pgpu_pairing_plan pgpu_pairing_plan;
 int pgpu_pairing_plan_create(pgpu_ctx* ctx, const pgpu_index* idx, const char* patterns,
                              const uint64_t* pat_off, size_t n_pat, pgpu_pairing_plan** plan);
+/* The same plan for a batch that is cut into several plans used one after the other (the chunks of the EST
+ * batch the host prefetches): only the patterns -- bytes, offsets, 2-bit packing -- are the plan's own, in ONE
+ * device allocation; every buffer a run writes (16 of them, ~60 bytes per pattern position, and the MEG stage's
+ * 11 KB per pattern) is shared by all resident plans of the context.  What a run leaves -- the pairings for
+ * fetch / run_meg, the MEG records for fetch_meg -- is valid until another resident plan of the same context
+ * runs; asking later is PGPU_EINVAL, never stale data.  (A one-shot process made 200 allocations of 7 GB for
+ * its ten chunks before this: a third of its first step.) */
+int pgpu_pairing_plan_create_resident(pgpu_ctx* ctx, const pgpu_index* idx, const char* patterns,
+                                      const uint64_t* pat_off, size_t n_pat, pgpu_pairing_plan** plan);
 int pgpu_pairing_plan_run(pgpu_ctx* ctx, pgpu_pairing_plan* plan, const pgpu_pairing_params* params);
 uint64_t pgpu_pairing_plan_count(const pgpu_pairing_plan* plan);       /* pairings of the last run */
 uint64_t pgpu_pairing_plan_positions(const pgpu_pairing_plan* plan);   /* pattern positions */

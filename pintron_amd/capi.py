@@ -44,7 +44,7 @@ assert C.sizeof(DpJob) == 48 and C.sizeof(DpResult) == 48
 EXPORTS = [
     "pgpu_init", "pgpu_destroy", "pgpu_last_error", "pgpu_abi_version", "pgpu_set_timing", "pgpu_device_numa_node",
     "pgpu_index_build", "pgpu_index_destroy", "pgpu_index_suffix_array", "pgpu_index_save", "pgpu_index_load", "pgpu_pairings",
-    "pgpu_pairing_plan_create", "pgpu_pairing_plan_run", "pgpu_pairing_plan_count",
+    "pgpu_pairing_plan_create", "pgpu_pairing_plan_create_resident", "pgpu_pairing_plan_run", "pgpu_pairing_plan_count",
     "pgpu_pairing_plan_positions", "pgpu_pairing_plan_kernel_ms", "pgpu_pairing_plan_fetch",
     "pgpu_pairing_plan_destroy",
     "pgpu_pairing_plan_run_meg", "pgpu_pairing_plan_meg_bytes", "pgpu_pairing_plan_fetch_meg",
@@ -107,6 +107,7 @@ def lib():
                                     C.POINTER(PairingParams), C.POINTER(Pairing), sz,
                                     C.POINTER(u64), C.POINTER(sz)]
         L.pgpu_pairing_plan_create.argtypes = [vp, vp, C.c_char_p, C.POINTER(u64), sz, C.POINTER(vp)]
+        L.pgpu_pairing_plan_create_resident.argtypes = [vp, vp, C.c_char_p, C.POINTER(u64), sz, C.POINTER(vp)]
         L.pgpu_pairing_plan_run.argtypes = [vp, vp, C.POINTER(PairingParams)]
         L.pgpu_pairing_plan_count.argtypes = [vp]
         L.pgpu_pairing_plan_count.restype = u64
@@ -225,16 +226,18 @@ class PairingPlan:
     run_meg()/fetch_meg() = the MEG stage behind the pairings."""
     STAGES = ["locate", "chain", "count+scan", "fill", "cross+scan", "emit"]
 
-    def __init__(self, ctx: Context, index: Index, patterns):
+    def __init__(self, ctx: Context, index: Index, patterns, resident=False):
         import numpy as np
         self.ctx, self.n_pat = ctx, len(patterns)
         self._blob = b"".join(patterns)
         self._off = np.zeros(len(patterns) + 1, dtype=np.uint64)
         np.cumsum([len(p) for p in patterns], out=self._off[1:])
         self.h = C.c_void_p()
-        ctx.check(ctx.L.pgpu_pairing_plan_create(ctx.h, index.h, self._blob,
-                                                 self._off.ctypes.data_as(C.POINTER(C.c_uint64)),
-                                                 self.n_pat, C.byref(self.h)))
+        # resident: the buffers a run writes are shared with the context's other resident plans (results valid
+        # until another of them runs)
+        create = ctx.L.pgpu_pairing_plan_create_resident if resident else ctx.L.pgpu_pairing_plan_create
+        ctx.check(create(ctx.h, index.h, self._blob, self._off.ctypes.data_as(C.POINTER(C.c_uint64)),
+                         self.n_pat, C.byref(self.h)))
 
     def run(self, min_factor_len=15, rate=0.2):
         prm = PairingParams(min_factor_len, 0, rate)

@@ -22,6 +22,8 @@ struct BufPool {
   void* ptr[SLOTS] = {nullptr};
   size_t cap[SLOTS] = {0};
   bool busy = false;
+  int sharers = 0;                // > 0: held by plans that use it one after the other (pgpu_pairing_plan_create_resident)
+  const void* owner = nullptr;    // whose results the buffers hold right now
 };
 
 struct pgpu_ctx {
@@ -92,7 +94,21 @@ bool pgpu_ctx_pool_acquire(pgpu_ctx* ctx, int pool) {
   ctx->pools[pool].busy = true;
   return true;
 }
-void pgpu_ctx_pool_release(pgpu_ctx* ctx, int pool) { ctx->pools[pool].busy = false; }
+void pgpu_ctx_pool_release(pgpu_ctx* ctx, int pool) { ctx->pools[pool].busy = false; ctx->pools[pool].owner = nullptr; }
+// several plans, used strictly one after the other, on the same buffers
+bool pgpu_ctx_pool_share(pgpu_ctx* ctx, int pool) {
+  BufPool& p = ctx->pools[pool];
+  if (p.busy && p.sharers == 0) return false;       // a plan holds it for itself
+  p.busy = true; ++p.sharers;
+  return true;
+}
+void pgpu_ctx_pool_unshare(pgpu_ctx* ctx, int pool, const void* who) {
+  BufPool& p = ctx->pools[pool];
+  if (p.owner == who) p.owner = nullptr;
+  if (p.sharers > 0 && --p.sharers == 0) p.busy = false;
+}
+void pgpu_ctx_pool_set_owner(pgpu_ctx* ctx, int pool, const void* who) { ctx->pools[pool].owner = who; }
+const void* pgpu_ctx_pool_owner(const pgpu_ctx* ctx, int pool) { return ctx->pools[pool].owner; }
 // returns a buffer of at least `bytes` from the (acquired) pool, growing it when needed
 void* pgpu_ctx_pool_get(pgpu_ctx* ctx, int pool, int slot, size_t bytes) {
   BufPool& p = ctx->pools[pool];

@@ -35,6 +35,10 @@ int pgpu_ctx_fail(pgpu_ctx* ctx, int code, const char* msg);
 bool pgpu_ctx_pool_acquire(pgpu_ctx* ctx, int pool);
 void pgpu_ctx_pool_release(pgpu_ctx* ctx, int pool);
 void* pgpu_ctx_pool_get(pgpu_ctx* ctx, int pool, int slot, size_t bytes);
+bool pgpu_ctx_pool_share(pgpu_ctx* ctx, int pool);
+void pgpu_ctx_pool_unshare(pgpu_ctx* ctx, int pool, const void* who);
+void pgpu_ctx_pool_set_owner(pgpu_ctx* ctx, int pool, const void* who);
+const void* pgpu_ctx_pool_owner(const pgpu_ctx* ctx, int pool);
 bool pgpu_ctx_timing(const pgpu_ctx* ctx);
 
 // pgpu_meg.hip: hand-written exclusive prefix sums and the per-pattern MEG kernels

@@ -816,6 +816,10 @@ struct pgpu_pairing_plan {
   hipEvent_t ev[8] = {nullptr};
   float ms[7] = {0};
   bool pooled = false;
+  // resident plan: only the patterns (bytes, offsets, packed) are the plan's own -- one allocation -- and every
+  // buffer a run writes comes from the context's pool, shared with the other resident plans of the context
+  bool resident = false;
+  void* d_resident = nullptr;
   pgpu_ctx* owner = nullptr;
   // MEG stage (pgpu_meg.hip)
   void *d_meg_scratch = nullptr, *d_meg_info = nullptr;
@@ -842,7 +846,8 @@ template <class T> static T* plan_alloc(pgpu_pairing_plan* p, int slot, size_t c
 
 static void pairing_plan_free(pgpu_pairing_plan* p) {
   if (!p) return;
-  if (p->pooled) pgpu_ctx_pool_release(p->owner, 1);
+  if (p->resident) { pgpu_ctx_pool_unshare(p->owner, 1, p); hipFree(p->d_resident); }
+  else if (p->pooled) pgpu_ctx_pool_release(p->owner, 1);
   else {
     hipFree(p->d_pats); hipFree(p->d_pcode); hipFree(p->d_pbad); hipFree(p->d_pat_off); hipFree(p->d_lo); hipFree(p->d_hi); hipFree(p->d_a);
     hipFree(p->d_thr); hipFree(p->d_cnt); hipFree(p->d_cnt_a); hipFree(p->d_cnt_b);
@@ -855,8 +860,26 @@ static void pairing_plan_free(pgpu_pairing_plan* p) {
   delete p;
 }
 
-extern "C" int pgpu_pairing_plan_create(pgpu_ctx* ctx, const pgpu_index* idx, const char* patterns,
-                                        const uint64_t* pat_off, size_t n_pat, pgpu_pairing_plan** out) {
+// the buffers of a resident plan that a run writes: taken from the shared pool anew at every run (another
+// plan may have made the pool grow, i.e. move, in between)
+static bool resident_scratch(pgpu_pairing_plan* p) {
+  const size_t tp = (size_t)p->total_pos, n_pat = p->n_pat;
+  p->d_lo = plan_alloc<uint32_t>(p, 2, tp); p->d_hi = plan_alloc<uint32_t>(p, 3, tp);
+  p->d_a = plan_alloc<uint32_t>(p, 4, tp); p->d_thr = plan_alloc<uint32_t>(p, 5, tp);
+  p->d_cnt = plan_alloc<uint32_t>(p, 6, tp + 1); p->d_cnt_a = plan_alloc<uint32_t>(p, 7, tp + 1);
+  p->d_cnt_b = plan_alloc<uint32_t>(p, 8, tp + 1);
+  p->d_cand_off = plan_alloc<unsigned long long>(p, 9, tp + 1);
+  p->d_out_off = plan_alloc<unsigned long long>(p, 10, tp + 1);
+  p->d_out_first = plan_alloc<unsigned long long>(p, 11, n_pat + 1);
+  p->d_tmp = plan_alloc<uint8_t>(p, 12, p->tmp_bytes);
+  p->d_cand = nullptr; p->d_keep = nullptr; p->d_out = nullptr;              // sized (and taken) once the counts are known
+  p->d_meg_scratch = nullptr; p->d_meg_out = nullptr;
+  return p->d_lo && p->d_hi && p->d_a && p->d_thr && p->d_cnt && p->d_cnt_a && p->d_cnt_b && p->d_cand_off && p->d_out_off &&
+         p->d_out_first && p->d_tmp;
+}
+
+static int pairing_plan_create(pgpu_ctx* ctx, const pgpu_index* idx, const char* patterns,
+                               const uint64_t* pat_off, size_t n_pat, bool resident, pgpu_pairing_plan** out) {
   if (!ctx || !idx || !out || !pat_off || (n_pat && pat_off[n_pat] && !patterns)) return PGPU_EINVAL;
   *out = nullptr;
   for (size_t i = 0; i < n_pat; ++i)
@@ -869,8 +892,22 @@ extern "C" int pgpu_pairing_plan_create(pgpu_ctx* ctx, const pgpu_index* idx, co
   p->idx = idx; p->n_pat = n_pat; p->total_pos = n_pat ? pat_off[n_pat] : 0;
   const size_t tp = (size_t)p->total_pos;
   p->owner = ctx;
-  p->pooled = pgpu_ctx_pool_acquire(ctx, 1);
+  p->resident = resident && pgpu_ctx_pool_share(ctx, 1);
+  p->pooled = p->resident || pgpu_ctx_pool_acquire(ctx, 1);
 #define NEED(ptr) do { if (!(ptr)) { rc = pgpu_ctx_fail(ctx, PGPU_ENOMEM, "out of device memory (pairing plan)"); goto done; } } while (0)
+  p->tmp_bytes = pgpu_scan_tmp_bytes(std::max(tp, n_pat) + 1);
+  if (p->resident) {
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t bad_words = (tp + 31) / 32;
+    const size_t o_off = up(tp + 64), o_code = o_off + up((n_pat + 1) * sizeof(unsigned long long)),
+                 o_bad = o_code + up((2 * bad_words + 4) * sizeof(uint32_t)), total = o_bad + up((bad_words + 4) * sizeof(uint32_t));
+    TRY_HIP(hipMalloc(&p->d_resident, total));
+    pgpu_trace_alloc("resident plan", p->d_resident, total);
+    uint8_t* base = (uint8_t*)p->d_resident;
+    p->d_pats = base; p->d_pat_off = (unsigned long long*)(base + o_off);
+    p->d_pcode = (uint32_t*)(base + o_code); p->d_pbad = (uint32_t*)(base + o_bad);
+    goto upload;
+  }
   NEED(p->d_pats = plan_alloc<uint8_t>(p, 0, tp + 64));
   NEED(p->d_pat_off = plan_alloc<unsigned long long>(p, 1, n_pat + 1));
   NEED(p->d_lo = plan_alloc<uint32_t>(p, 2, tp)); NEED(p->d_hi = plan_alloc<uint32_t>(p, 3, tp));
@@ -880,13 +917,13 @@ extern "C" int pgpu_pairing_plan_create(pgpu_ctx* ctx, const pgpu_index* idx, co
   NEED(p->d_cand_off = plan_alloc<unsigned long long>(p, 9, tp + 1));
   NEED(p->d_out_off = plan_alloc<unsigned long long>(p, 10, tp + 1));
   NEED(p->d_out_first = plan_alloc<unsigned long long>(p, 11, n_pat + 1));
-  p->tmp_bytes = pgpu_scan_tmp_bytes(std::max(tp, n_pat) + 1);
   NEED(p->d_tmp = plan_alloc<uint8_t>(p, 12, p->tmp_bytes));
   {
     const size_t bad_words = (tp + 31) / 32;
     NEED(p->d_pcode = plan_alloc<uint32_t>(p, 21, 2 * bad_words + 4));
     NEED(p->d_pbad = plan_alloc<uint32_t>(p, 22, bad_words + 4));
   }
+upload:
   if (pgpu_ctx_timing(ctx)) for (auto& e : p->ev) TRY_HIP(hipEventCreate(&e));
   if (tp) TRY_HIP(hipMemcpyAsync(p->d_pats, patterns, tp, hipMemcpyHostToDevice, st));
   TRY_HIP(hipMemcpyAsync(p->d_pat_off, pat_off, (n_pat + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
@@ -896,6 +933,15 @@ done:
   if (rc != PGPU_OK) { pairing_plan_free(p); return rc; }
   *out = p;
   return PGPU_OK;
+}
+
+extern "C" int pgpu_pairing_plan_create(pgpu_ctx* ctx, const pgpu_index* idx, const char* patterns,
+                                        const uint64_t* pat_off, size_t n_pat, pgpu_pairing_plan** out) {
+  return pairing_plan_create(ctx, idx, patterns, pat_off, n_pat, false, out);
+}
+extern "C" int pgpu_pairing_plan_create_resident(pgpu_ctx* ctx, const pgpu_index* idx, const char* patterns,
+                                                 const uint64_t* pat_off, size_t n_pat, pgpu_pairing_plan** out) {
+  return pairing_plan_create(ctx, idx, patterns, pat_off, n_pat, true, out);
 }
 
 // runs every kernel; the two size-dependent buffers (candidates, output) grow on demand, which
@@ -914,6 +960,10 @@ extern "C" int pgpu_pairing_plan_run(pgpu_ctx* ctx, pgpu_pairing_plan* p, const 
   p->n_cand = p->n_out = 0;
   p->have_pairs = false;
   if (p->n_pat == 0) return PGPU_OK;
+  if (p->resident) {
+    pgpu_ctx_pool_set_owner(ctx, 1, p);               // whatever another resident plan left there is gone from here on
+    if (!resident_scratch(p)) return pgpu_ctx_fail(ctx, PGPU_ENOMEM, "out of device memory (pairing plan)");
+  }
   pgpu_range_push("pairings");
   struct PopAtExit { ~PopAtExit() { pgpu_range_pop(); } } pop_at_exit;
   if (p->ev[0]) TRY_HIP(hipEventRecord(p->ev[0], st));
@@ -969,6 +1019,9 @@ extern "C" int pgpu_pairing_plan_run_meg(pgpu_ctx* ctx, pgpu_pairing_plan* p, co
   if (p->n_pat == 0) return PGPU_OK;
   if (!p->have_pairs || p->last_L != prm->min_factor_len)
     return pgpu_ctx_fail(ctx, PGPU_EINVAL, "run_meg needs the pairings of pgpu_pairing_plan_run with the same min_factor_len");
+  if (p->resident && pgpu_ctx_pool_owner(ctx, 1) != p)
+    return pgpu_ctx_fail(ctx, PGPU_EINVAL, "the pairings of this resident plan were overwritten by the run of another one");
+  if (p->resident) { p->d_meg_scratch = nullptr; p->d_meg_out = nullptr; }
   int rc = PGPU_OK;
   hipStream_t st = pgpu_ctx_stream(ctx);
   const uint32_t np = (uint32_t)p->n_pat;
@@ -979,7 +1032,7 @@ extern "C" int pgpu_pairing_plan_run_meg(pgpu_ctx* ctx, pgpu_pairing_plan* p, co
     NEED(p->d_meg_info = plan_alloc<uint8_t>(p, 17, (size_t)np * 16));
     NEED(p->d_meg_bytes = plan_alloc<uint32_t>(p, 18, (size_t)np + 1));
     NEED(p->d_meg_off = plan_alloc<unsigned long long>(p, 19, (size_t)np + 1));
-    if (pgpu_ctx_timing(ctx)) for (auto& e : p->meg_ev) TRY_HIP(hipEventCreate(&e));
+    if (pgpu_ctx_timing(ctx) && !p->meg_ev[0]) for (auto& e : p->meg_ev) TRY_HIP(hipEventCreate(&e));
   }
   if (p->meg_ev[0]) TRY_HIP(hipEventRecord(p->meg_ev[0], st));
   pgpu_meg_launch_build(p->d_out, p->d_out_first, p->d_pat_off, np, prm, p->d_meg_scratch, p->d_meg_info, p->d_meg_bytes, st);
@@ -1008,6 +1061,8 @@ extern "C" double pgpu_pairing_plan_meg_ms(const pgpu_pairing_plan* p) { return 
 extern "C" int pgpu_pairing_plan_fetch_meg(pgpu_ctx* ctx, pgpu_pairing_plan* p, void* out, size_t out_cap, uint64_t* rec_first) {
   if (!ctx || !p || !rec_first || (p->meg_total && !out)) return PGPU_EINVAL;
   if (out_cap < p->meg_total) return pgpu_ctx_fail(ctx, PGPU_ENOSPC, "MEG buffer too small");
+  if (p->resident && p->n_pat && pgpu_ctx_pool_owner(ctx, 1) != p)
+    return pgpu_ctx_fail(ctx, PGPU_EINVAL, "the results of this resident plan were overwritten by the run of another one");
   if (pgpu_ctx_bind(ctx) != PGPU_OK) return PGPU_EDEVICE;
   int rc = PGPU_OK;
   hipStream_t st = pgpu_ctx_stream(ctx);
@@ -1041,6 +1096,8 @@ extern "C" int pgpu_pairing_plan_fetch(pgpu_ctx* ctx, pgpu_pairing_plan* p, pgpu
                                        uint64_t* out_first) {
   if (!ctx || !p || !out_first) return PGPU_EINVAL;
   if (out_cap < p->n_out) return pgpu_ctx_fail(ctx, PGPU_ENOSPC, "pairing buffer too small");
+  if (p->resident && p->n_pat && pgpu_ctx_pool_owner(ctx, 1) != p)
+    return pgpu_ctx_fail(ctx, PGPU_EINVAL, "the results of this resident plan were overwritten by the run of another one");
   if (pgpu_ctx_bind(ctx) != PGPU_OK) return PGPU_EDEVICE;
   int rc = PGPU_OK;
   hipStream_t st = pgpu_ctx_stream(ctx);

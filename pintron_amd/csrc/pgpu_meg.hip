@@ -448,6 +448,7 @@ void meg_emit_kernel(uint32_t n_pat, const MegScratch* __restrict__ scratch, con
   }
   first[no] = (uint16_t)e;
   const uint32_t graph = (16 + 12 * h.x + 2 * (h.x + 1) + h.y + 3u) & ~3u;
+  for (uint8_t* z = tgt + e; z < rec + graph; ++z) *z = 0;        // the padding is part of the record: same bytes every run
   const uint32_t meg_txt = (uint32_t)(S->star[0] & 0xFFFFFFFFull), edge_txt = (uint32_t)(S->star[0] >> 32);
   uint32_t* tl = (uint32_t*)(rec + graph);
   tl[0] = meg_txt; tl[1] = edge_txt;
@@ -474,6 +475,7 @@ void meg_emit_kernel(uint32_t n_pat, const MegScratch* __restrict__ scratch, con
       *w++ = '\n';
     }
   }
+  while ((w - rec) & 3) *w++ = 0;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -1095,7 +1095,7 @@ static int make_pattern_plan(ef_session* s, int c) {
   size_t pos = 0;
   for (size_t k = lo; k < hi; ++k) { const size_t m = strlen(in->list[k]->seq); off[k - lo] = pos; memcpy(blob + pos, in->list[k]->seq, m); pos += m; }
   off[hi - lo] = pos;
-  const int prc = pgpu_pairing_plan_create(s->ctx0, sh->idx, blob, off, hi - lo, &s->pplan[c]);
+  const int prc = pgpu_pairing_plan_create_resident(s->ctx0, sh->idx, blob, off, hi - lo, &s->pplan[c]);
   free(blob); free(off);
   return prc;
 }
@@ -1111,8 +1111,11 @@ static void* prefetch_main(void* arg) {
     pgpu_range_push(rname);
     /* first step: the chunk's sequences go to the device here, chunk after chunk beside the workers
      * that already factorize the chunks before (they stay resident for the steps that follow) */
+    const double tc0 = now_s();
     int prc = s->pplan[c] ? PGPU_OK : make_pattern_plan(s, c);
+    const double tc1 = now_s();
     if (prc == PGPU_OK) prc = pgpu_pairing_plan_run(s->ctx0, s->pplan[c], &prm);
+    const double tc2 = now_s();
     bool have_meg = false;
     if (prc == PGPU_OK && sh->use_meg) {
       /* the graphs are built where the pairings lie; only the finished records cross PCIe */
@@ -1146,6 +1149,9 @@ static void* prefetch_main(void* arg) {
       prc = pgpu_pairing_plan_fetch(s->ctx0, s->pplan[c], sh->pre_tri[c], cnt, sh->pre_first[c]);
     }
     for (int k = 0; k < 6; ++k) s->pre_kernel_ms[k] += pgpu_pairing_plan_kernel_ms(s->pplan[c], k);
+    if (getenv("PINTRON_VERBOSE") && atoi(getenv("PINTRON_VERBOSE")) >= 2)
+      fprintf(stderr, "* prefetch chunk %d: at %.3fs of the step; plan + upload %.1f ms, pairings %.1f ms, MEGs + download %.1f ms\n", c,
+              tc0 - s->pre_t0, 1e3 * (tc1 - tc0), 1e3 * (tc2 - tc1), 1e3 * (now_s() - tc2));
     pthread_mutex_lock(&sh->mu);
     if (prc != PGPU_OK) { fprintf(stderr, "* FATAL pairing prefetch failed: %s\n", pgpu_last_error(s->ctx0)); sh->failed = 1; }
     else __atomic_store_n(&sh->ready_entries, sh->pre_lo[c + 1], __ATOMIC_RELEASE);

@@ -43,6 +43,9 @@ int pgpu_pairing_plan_create(pgpu_ctx* ctx, const pgpu_index* idx, const char* p
   p->off = (uint64_t*)malloc((n + 1) * sizeof(uint64_t)); memcpy(p->off, off, (n + 1) * sizeof(uint64_t));
   *out = p; return PGPU_OK;
 }
+int pgpu_pairing_plan_create_resident(pgpu_ctx* ctx, const pgpu_index* idx, const char* patterns, const uint64_t* off, size_t n, pgpu_pairing_plan** out) {
+  return pgpu_pairing_plan_create(ctx, idx, patterns, off, n, out);     /* the stand-in has no scratch to share */
+}
 int pgpu_pairing_plan_run(pgpu_ctx* ctx, pgpu_pairing_plan* p, const pgpu_pairing_params* prm) {
   (void)ctx;
   if (getenv("PINTRON_FAKE_CACHE") && p->out && p->first) return PGPU_OK;   /* profiling aid: see below */

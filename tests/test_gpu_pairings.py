@@ -196,3 +196,58 @@ def test_long_exact_repeat_in_the_genomic(gpu_ctx):
     for e, g in zip(ests, got):
         assert np.array_equal(g.reshape(-1, 3), oi.pairings(e)), len(e)
     oi.close()
+
+
+def test_resident_plans_share_their_scratch(gpu_ctx):
+    """pgpu_pairing_plan_create_resident: plans that own only their patterns and write every run into buffers shared
+    by the context's resident plans (the prefetch chunks of the batched host).  Chunks of DIFFERENT sizes, used in
+    turn and out of order, give exactly the pairings and MEG records of ordinary plans -- whatever the other plan
+    left in the shared buffers -- and results that another plan's run has overwritten are refused, not returned."""
+    import pintron_amd.capi as capi
+    from pintron_amd import synth
+    w = synth.make("C3", n_est=900, seed=11)
+    ests = []
+    for s in w.est_seqs:
+        ests += [s, PL.revcomp(s)]
+    chunks = [ests[:200], ests[200:1400], ests[1400:1500], ests[1500:]]          # the second makes the pool grow
+    idx = capi.Index(gpu_ctx, w.genomic)
+    want = []
+    for ch in chunks:                                                            # ordinary plans: the expectation
+        p = capi.PairingPlan(gpu_ctx, idx, ch)
+        p.run()
+        tri, first = p.fetch()
+        p.run_meg()
+        want.append((tri.copy(), first.copy(), p.fetch_meg()))
+        p.close()
+    plans = [capi.PairingPlan(gpu_ctx, idx, ch, resident=True) for ch in chunks]
+    try:
+        for order in ([0, 1, 2, 3], [3, 1, 0, 2, 1]):
+            for k in order:
+                plans[k].run()
+                tri, first = plans[k].fetch()
+                assert np.array_equal(tri, want[k][0]) and np.array_equal(first, want[k][1]), k
+                plans[k].run_meg()
+                for i, (a, b) in enumerate(zip(plans[k].fetch_meg(), want[k][2])):
+                    if a != b:
+                        at = next((o for o in range(min(len(a), len(b))) if a[o] != b[o]), min(len(a), len(b)))
+                        raise AssertionError("chunk %d record %d differs at byte %d of %d / %d: %r vs %r"
+                                             % (k, i, at, len(a), len(b), a[max(0, at - 8):at + 8], b[max(0, at - 8):at + 8]))
+        plans[0].run()
+        plans[1].run()                                                           # overwrites what plan 0 left
+        for stale in (plans[0].fetch, plans[0].run_meg, plans[0].fetch_meg):
+            with pytest.raises(capi.PgpuError) as e:
+                stale()
+            assert "overwritten" in str(e.value)
+        tri, first = plans[1].fetch()                                            # the owner is still served
+        assert np.array_equal(tri, want[1][0])
+        # an ordinary plan beside them keeps buffers of its own
+        q = capi.PairingPlan(gpu_ctx, idx, chunks[2])
+        q.run()
+        plans[3].run()
+        tri, first = q.fetch()
+        assert np.array_equal(tri, want[2][0])
+        q.close()
+    finally:
+        for p in plans:
+            p.close()
+        idx.close()

@@ -20,10 +20,8 @@ pf = re.findall(r"(\d+) page faults", s)
 print("%-44s wall %.3f = main %.3f + after %.3f | %s | %s | faults %s" % (sys.argv[3][:44], t1 - t0, b - a, t1 - b, run, res, "+".join(pf)))
 PY
 }
-for i in 1 2; do
-  one A=1
-  one GLIBC_TUNABLES=glibc.malloc.hugetlb=1
-  one MALLOC_ARENA_MAX=4
-  one PINTRON_FIBERS=512
+for i in 1 2 3 4; do
+  one PINTRON_WARM_ARENAS=1
+  one PINTRON_WARM_ARENAS=0
 done
 md5sum raw-multifasta-out.txt
