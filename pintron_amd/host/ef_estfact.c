@@ -141,9 +141,10 @@ ef_est* ef_compute_est_fact(const ef_seq* gen, const ef_seq* est, ef_backend* be
   return fe;
 }
 
-typedef struct { ef_seq** ests; ef_seq** revs; long lo, hi; } prep_job;
+typedef struct { ef_seq** ests; ef_seq** revs; long lo, hi; ef_record_arena* arena; } prep_job;
 static void* prep_main(void* arg) {
   prep_job* j = (prep_job*)arg;
+  if (j->arena) ef_record_arena_enter(j->arena);          /* the reversed siblings and the /gb= names */
   for (long i = j->lo; i < j->hi; ++i) {
     ef_seq* est = j->ests[i];
     ef_set_gb_identification(est);
@@ -155,6 +156,7 @@ static void* prep_main(void* arg) {
       j->revs[i] = rev;
     }
   }
+  if (j->arena) ef_record_arena_leave();
   return NULL;
 }
 
@@ -166,6 +168,21 @@ int ef_load_inputs(int argc, char** argv, ef_inputs* in) {
 
 /* first half: configuration + genomic.txt (enough to start building the index) */
 int ef_load_genomic(int argc, char** argv, ef_inputs* in) {
+  const int rc = ef_load_genomic_sequence(argc, argv, in);
+  if (rc == 0) ef_prepare_genomic_tables(in);
+  return rc;
+}
+
+/* ... in two steps for the batched program: the sequence as the device index needs it (read, header, N tails:
+ * milliseconds), and the host-side tables over it (k-mer positions of the small-exon search, the four score
+ * tables of the intron classifier: 0.3 s for a 1 Mb gene on eight threads) -- the second runs beside the
+ * start-up of the GPU runtime instead of in front of it */
+void ef_prepare_genomic_tables(ef_inputs* in) {
+  ef_seq_index_kmers(in->gen);
+  ef_classify_prepare(in->gen);
+}
+
+int ef_load_genomic_sequence(int argc, char** argv, ef_inputs* in) {
   memset(in, 0, sizeof(*in));
   if (ef_config_load(&in->cfg, argc, argv) != 0) return 2;
   ef_seq** gens = NULL;
@@ -176,8 +193,6 @@ int ef_load_genomic(int argc, char** argv, ef_inputs* in) {
   free(gens);
   ef_parse_genomic_header(in->gen);
   if (ef_ntails_removal(in->gen) != 0) { fprintf(stderr, "* FATAL The sequence is only composed by Ns.\n"); return 1; }
-  ef_seq_index_kmers(in->gen);
-  ef_classify_prepare(in->gen);
   return 0;
 }
 
@@ -189,33 +204,24 @@ int ef_shard_rank = 0, ef_shard_world = 1;
 /* second half: ests.txt and the preparation of every EST */
 int ef_load_ests(ef_inputs* in) {
   ef_seq** ests = NULL;
-  long n_in = ef_read_multifasta("ests.txt", &ests);
+  /* EST-sharded run: the rank's contiguous part of the file, cut by bytes at record starts (the sequences are
+   * what the bytes are, so the parts are balanced by total sequence length up to the headers) */
+  in->arena = ef_record_arena_new();
+  long n_in = ef_read_multifasta_arena("ests.txt", ef_shard_rank, ef_shard_world, in->arena, &ests);
   if (n_in < 0) { fprintf(stderr, "* FATAL File ests.txt not found! Terminating\n"); return 1; }
-  if (ef_shard_world > 1) {
-    unsigned long long total = 0, acc = 0;
-    for (long i = 0; i < n_in; ++i) total += strlen(ests[i]->seq);
-    long lo = 0, hi = n_in, i = 0;
-    for (int r = 1; r <= ef_shard_world; ++r) {          /* bound r: first i with acc * world >= total * r */
-      while (i < n_in && acc * (unsigned long long)ef_shard_world < total * (unsigned long long)r) { acc += strlen(ests[i]->seq); ++i; }
-      if (r == ef_shard_rank) lo = i;
-      if (r == ef_shard_rank + 1) { hi = r == ef_shard_world ? n_in : i; break; }
-    }
-    for (long k = 0; k < n_in; ++k) if (k < lo || k >= hi) ef_seq_free(ests[k]);
-    memmove(ests, ests + lo, (size_t)(hi - lo) * sizeof(ef_seq*));
-    n_in = hi - lo;
-  }
   /* preparation loop (src/main-est-fact.c:190-213): every EST is prepared on its own, so the
    * loop is split over a few threads; the list is then filled in input order */
   ef_seq** revs = (ef_seq**)calloc((size_t)n_in + 1, sizeof(ef_seq*));
-  enum { PREP_THREADS = 8 };
-  prep_job jobs[PREP_THREADS]; pthread_t th[PREP_THREADS]; bool started[PREP_THREADS];
-  for (int t = 0; t < PREP_THREADS; ++t) {
-    jobs[t].ests = ests; jobs[t].revs = revs;
-    jobs[t].lo = n_in * t / PREP_THREADS; jobs[t].hi = n_in * (t + 1) / PREP_THREADS;
+  enum { PREP_THREADS_MAX = 32 };
+  const int prep_threads = ef_parse_threads < 1 ? 1 : ef_parse_threads > PREP_THREADS_MAX ? PREP_THREADS_MAX : ef_parse_threads;
+  prep_job jobs[PREP_THREADS_MAX]; pthread_t th[PREP_THREADS_MAX]; bool started[PREP_THREADS_MAX];
+  for (int t = 0; t < prep_threads; ++t) {
+    jobs[t].ests = ests; jobs[t].revs = revs; jobs[t].arena = in->arena;
+    jobs[t].lo = n_in * t / prep_threads; jobs[t].hi = n_in * (t + 1) / prep_threads;
     started[t] = n_in >= 1024 && pthread_create(&th[t], NULL, prep_main, &jobs[t]) == 0;
     if (!started[t]) prep_main(&jobs[t]);
   }
-  for (int t = 0; t < PREP_THREADS; ++t) if (started[t]) pthread_join(th[t], NULL);
+  for (int t = 0; t < prep_threads; ++t) if (started[t]) pthread_join(th[t], NULL);
   in->list = (ef_seq**)malloc((size_t)(2 * n_in + 1) * sizeof(ef_seq*));
   for (long i = 0; i < n_in; ++i) {
     in->list[in->n++] = ests[i];
@@ -228,6 +234,7 @@ int ef_load_ests(ef_inputs* in) {
 void ef_free_inputs(ef_inputs* in) {
   for (size_t k = 0; k < in->n; ++k) ef_seq_free(in->list[k]);
   free(in->list);
+  ef_record_arena_free(in->arena); in->arena = NULL;
   ef_seq_free(in->gen);
   ef_genomic_epoch_bump();                   /* its address may come back with another gene behind it */
 }

@@ -3,7 +3,12 @@
  * function); the implementation is our own. */
 #define _GNU_SOURCE
 #include <ctype.h>
+#include <fcntl.h>
 #include <pthread.h>
+#include <stdint.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -40,15 +45,60 @@ void ef_cell_release_all(void) {
   ef_cell_free_list = NULL; ef_cell64_free_list = NULL;
 }
 
+/* ---- record arena ------------------------------------------------------------------------------- */
+typedef struct rec_slab { struct rec_slab* next; void* base; size_t total, cap, used; } rec_slab;
+struct ef_record_arena { rec_slab* slabs; pthread_mutex_t mu; };
+static _Thread_local ef_record_arena* tl_arena;
+static _Thread_local rec_slab* tl_slab;
+enum { SLAB_BYTES = 16u << 20, HUGE_PAGE = 2u << 20 };
+
+ef_record_arena* ef_record_arena_new(void) {
+  ef_record_arena* a = (ef_record_arena*)calloc(1, sizeof *a);
+  pthread_mutex_init(&a->mu, NULL);
+  return a;
+}
+void ef_record_arena_free(ef_record_arena* a) {
+  if (!a) return;
+  while (a->slabs) { rec_slab* nx = a->slabs->next; munmap(a->slabs->base, a->slabs->total); a->slabs = nx; }
+  pthread_mutex_destroy(&a->mu);
+  free(a);
+}
+void ef_record_arena_enter(ef_record_arena* a) { tl_arena = a; tl_slab = NULL; }
+void ef_record_arena_leave(void) { tl_arena = NULL; tl_slab = NULL; }
+
+/* n bytes for a record of the calling thread: from its current slab of the arena it entered, else malloc */
+static void* rec_alloc(size_t n) {
+  if (!tl_arena) return malloc(n);
+  n = (n + 15) & ~(size_t)15;
+  if (!tl_slab || tl_slab->used + n > tl_slab->cap) {
+    const size_t body = n + sizeof(rec_slab) + 64 > SLAB_BYTES ? n + sizeof(rec_slab) + 64 : SLAB_BYTES;
+    const size_t total = body + HUGE_PAGE;                       /* room to start on a huge-page boundary */
+    void* base = mmap(NULL, total, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (base == MAP_FAILED) return NULL;
+    char* start = (char*)(((uintptr_t)base + HUGE_PAGE - 1) & ~(uintptr_t)(HUGE_PAGE - 1));
+    if (getenv("PINTRON_ARENA_THP")) madvise(start, body & ~(size_t)(HUGE_PAGE - 1), MADV_HUGEPAGE);   /* experiment: direct compaction can stall */
+    rec_slab* sl = (rec_slab*)start;
+    sl->base = base; sl->total = total; sl->cap = body; sl->used = (sizeof(rec_slab) + 15) & ~(size_t)15;
+    pthread_mutex_lock(&tl_arena->mu);
+    sl->next = tl_arena->slabs; tl_arena->slabs = sl;
+    pthread_mutex_unlock(&tl_arena->mu);
+    tl_slab = sl;
+  }
+  void* r = (char*)tl_slab + tl_slab->used;
+  tl_slab->used += n;
+  return r;
+}
+
 static char* dup_range(const char* s, size_t n) {
-  char* r = (char*)malloc(n + 1);
+  char* r = (char*)rec_alloc(n + 1);
   memcpy(r, s, n);
   r[n] = '\0';
   return r;
 }
+static char* dup_str(const char* s) { return dup_range(s, strlen(s)); }
 
 void ef_seq_free(ef_seq* s) {
-  if (!s) return;
+  if (!s || s->in_arena) return;               /* an arena's records go with the arena */
   free(s->id); free(s->seq); free(s->original_seq); free(s->gb); free(s->chr);
   free(s->kmer_first); free(s->kmer_pos); free(s->bps_memo);
   for (int k = 0; k < 4; ++k) free(s->score5_tab[k]);
@@ -83,8 +133,10 @@ void ef_seq_index_kmers(ef_seq* gen) {
 }
 
 static ef_seq* seq_new(void) {
-  ef_seq* s = (ef_seq*)calloc(1, sizeof(ef_seq));
+  ef_seq* s = (ef_seq*)rec_alloc(sizeof(ef_seq));
+  memset(s, 0, sizeof *s);
   s->strand = 1;
+  s->in_arena = tl_arena != NULL;
   return s;
 }
 
@@ -107,20 +159,23 @@ static bool next_line(const char* buf, size_t size, size_t* pos, line_t* ln) {
  * beginning with '>', its sequence is the concatenation of the following non-empty lines up to
  * the next '>' line, the literal line "#\#" or the end of the file. */
 /* the records of buf[0, sz), which starts at a record (or before the first one) */
-typedef struct { const char* buf; size_t sz; ef_seq** v; size_t n; } parse_range;
+typedef struct { const char* buf; size_t sz; ef_seq** v; size_t n; ef_record_arena* arena; } parse_range;
 static void* parse_records(void* arg) {
   parse_range* r = (parse_range*)arg;
   const char* buf = r->buf; const size_t sz = r->sz;
   size_t pos = 0, cap = 16, n = 0;
   ef_seq** v = (ef_seq**)malloc(cap * sizeof(ef_seq*));
+  ef_record_arena* before = tl_arena; rec_slab* slab_before = tl_slab;
+  if (r->arena) ef_record_arena_enter(r->arena);
+  size_t scap = 4096;
+  char* data = (char*)malloc(scap);             /* the lines of one record are gathered here, then copied at their size */
   line_t ln;
   bool have = next_line(buf, sz, &pos, &ln);
   while (have) {
     if (ln.len > 0 && ln.p[0] == '>') {
       ef_seq* s = seq_new();
       s->id = dup_range(ln.p + 1, ln.len - 1);
-      size_t scap = 256, slen = 0;
-      char* data = (char*)malloc(scap);
+      size_t slen = 0;
       while ((have = next_line(buf, sz, &pos, &ln))) {
         if (ln.len > 0 && ln.p[0] == '>') break;
         if (ln.len == 3 && memcmp(ln.p, "#\\#", 3) == 0) break;
@@ -131,8 +186,7 @@ static void* parse_records(void* arg) {
         memcpy(data + slen, ln.p, use);
         slen += use;
       }
-      data[slen] = '\0';
-      s->seq = data;
+      s->seq = dup_range(data, slen);
       s->original_seq = dup_range(data, slen);
       if (n == cap) { cap *= 2; v = (ef_seq**)realloc(v, cap * sizeof(ef_seq*)); }
       v[n++] = s;
@@ -140,6 +194,8 @@ static void* parse_records(void* arg) {
       have = next_line(buf, sz, &pos, &ln);
     }
   }
+  free(data);
+  tl_arena = before; tl_slab = slab_before;
   r->v = v; r->n = n;
   return NULL;
 }
@@ -147,33 +203,34 @@ static void* parse_records(void* arg) {
 /* A record starts at every line that begins with '>', whatever came before it, so a large file is
  * cut at such lines into a few ranges that are parsed side by side (a C5-sized ests.txt holds two
  * million records: one thread spends most of its time in malloc) and joined in file order. */
-long ef_read_multifasta(const char* path, ef_seq*** out) {
-  FILE* f = fopen(path, "rb");
-  if (!f) return -1;
-  fseek(f, 0, SEEK_END);
-  const long sz = ftell(f);
-  fseek(f, 0, SEEK_SET);
-  char* buf = (char*)malloc((size_t)sz + 1);
-  if (fread(buf, 1, (size_t)sz, f) != (size_t)sz) { fclose(f); free(buf); return -1; }
-  fclose(f);
-  buf[sz] = '\0';
-  enum { MAX_PARTS = 8 };
-  const int want = (sz >= (8 << 20) || getenv("PINTRON_PARSE_SPLIT")) ? MAX_PARTS : 1;   /* the variable: tests */
+int ef_parse_threads = 8;                    /* the scheduler sets it to the process's share of the cores */
+enum { MAX_PARTS = 32 };
+
+/* the cut of buf[0, sz) at or after `at`: behind the first newline at or after `at` that is followed by '>' */
+static size_t cut_in_buffer(const char* buf, size_t sz, size_t at) {
+  const char* q = buf + at;
+  while ((q = (const char*)memchr(q, '\n', (size_t)(buf + sz - q))) != NULL && q + 1 < buf + sz && q[1] != '>') ++q;
+  return (!q || q + 1 >= buf + sz) ? sz : (size_t)(q + 1 - buf);
+}
+
+static long parse_buffer(const char* buf, size_t sz, ef_record_arena* arena, ef_seq*** out) {
+  int want = (sz >= (8u << 20) || getenv("PINTRON_PARSE_SPLIT")) ? ef_parse_threads : 1;   /* the variable: tests */
+  if (want > MAX_PARTS) want = MAX_PARTS;
+  if (want < 1) want = 1;
   size_t cut[MAX_PARTS + 1];
   int parts = 0;
   cut[0] = 0;
   for (int t = 1; t < want; ++t) {
-    size_t at = (size_t)sz * (size_t)t / (size_t)want;
+    const size_t at = sz * (size_t)t / (size_t)want;
     if (at <= cut[parts]) continue;
-    const char* q = buf + at;                         /* the next "\n>" at or after `at` */
-    while ((q = (const char*)memchr(q, '\n', (size_t)(buf + sz - q))) != NULL && q + 1 < buf + sz && q[1] != '>') ++q;
-    if (!q || q + 1 >= buf + sz) break;
-    cut[++parts] = (size_t)(q + 1 - buf);
+    const size_t c = cut_in_buffer(buf, sz, at);
+    if (c >= sz) break;
+    cut[++parts] = c;
   }
-  cut[++parts] = (size_t)sz;
+  cut[++parts] = sz;
   parse_range rg[MAX_PARTS]; pthread_t th[MAX_PARTS]; bool started[MAX_PARTS];
   for (int t = 0; t < parts; ++t) {
-    rg[t].buf = buf + cut[t]; rg[t].sz = cut[t + 1] - cut[t]; rg[t].v = NULL; rg[t].n = 0;
+    rg[t].buf = buf + cut[t]; rg[t].sz = cut[t + 1] - cut[t]; rg[t].v = NULL; rg[t].n = 0; rg[t].arena = arena;
     started[t] = parts > 1 && pthread_create(&th[t], NULL, parse_records, &rg[t]) == 0;
     if (!started[t]) parse_records(&rg[t]);
   }
@@ -182,9 +239,79 @@ long ef_read_multifasta(const char* path, ef_seq*** out) {
   ef_seq** v = (ef_seq**)malloc((n + 1) * sizeof(ef_seq*));
   size_t at = 0;
   for (int t = 0; t < parts; ++t) { memcpy(v + at, rg[t].v, rg[t].n * sizeof(ef_seq*)); at += rg[t].n; free(rg[t].v); }
-  free(buf);
   *out = v;
   return (long)n;
+}
+
+/* bytes [a, b) of the file: mapped (no copy out of the page cache, the pages entered in one go), read into a
+ * block where mapping fails.  The parser takes sizes, never a terminator. */
+typedef struct { const char* p; size_t len; void* map; size_t map_len; char* heap; } file_bytes;
+static int file_bytes_open(const char* path, long a, long b, file_bytes* fb) {
+  memset(fb, 0, sizeof *fb);
+  const int fd = open(path, O_RDONLY);
+  if (fd < 0) return -1;
+  struct stat sb;
+  if (fstat(fd, &sb) != 0) { close(fd); return -1; }
+  if (b < 0 || b > (long)sb.st_size) b = (long)sb.st_size;
+  if (a > b) a = b;
+  fb->len = (size_t)(b - a);
+  if (fb->len == 0) { close(fd); fb->p = ""; return 0; }
+  const long page = sysconf(_SC_PAGESIZE);
+  const long a0 = a & ~(page - 1);
+  void* m = mmap(NULL, (size_t)(b - a0), PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, a0);
+  if (m != MAP_FAILED) { fb->map = m; fb->map_len = (size_t)(b - a0); fb->p = (const char*)m + (a - a0); close(fd); return 0; }
+  fb->heap = (char*)malloc(fb->len + 1);
+  const ssize_t got = fb->heap ? pread(fd, fb->heap, fb->len, a) : -1;
+  close(fd);
+  if (got != (ssize_t)fb->len) { free(fb->heap); return -1; }
+  fb->p = fb->heap;
+  return 0;
+}
+static void file_bytes_close(file_bytes* fb) { if (fb->map) munmap(fb->map, fb->map_len); free(fb->heap); }
+
+long ef_read_multifasta(const char* path, ef_seq*** out) { return ef_read_multifasta_arena(path, 0, 1, NULL, out); }
+long ef_read_multifasta_part(const char* path, int part, int parts, ef_seq*** out) { return ef_read_multifasta_arena(path, part, parts, NULL, out); }
+
+/* Part `part` of `parts` of the file (0 of 1: all of it), for the EST-sharded runs: the records that begin in
+ * [cut(part), cut(part + 1)), where cut(t) is the first record start behind a newline at or after byte
+ * size * t / parts (cut(0) = 0, cut(parts) = size) -- the same rule on every rank, so the parts are disjoint,
+ * in file order, and together the whole file; and a rank reads and parses only its own bytes (every rank
+ * parsing all two million reads of a C5-sized file cost each of them 1.5 s for a step of 0.2 s).  The records
+ * go to `arena` when there is one, else to malloc. */
+static long file_cut(FILE* f, long sz, long at) {
+  if (at <= 0) return 0;
+  if (at >= sz) return sz;
+  enum { WIN = 1 << 20 };
+  char* w = (char*)malloc(WIN + 1);
+  long found = sz;
+  for (long pos = at; pos < sz && found == sz;) {
+    fseek(f, pos, SEEK_SET);
+    const size_t got = fread(w, 1, WIN + 1, f);                  /* one byte of overlap: the '>' behind a newline at the window's end */
+    if (got == 0) break;
+    for (size_t k = 0; k + 1 < got; ++k) if (w[k] == '\n' && w[k + 1] == '>') { found = pos + (long)k + 1; break; }
+    if (got < (size_t)WIN + 1) break;
+    pos += WIN;
+  }
+  free(w);
+  return found;
+}
+
+long ef_read_multifasta_arena(const char* path, int part, int parts, ef_record_arena* arena, ef_seq*** out) {
+  long a = 0, b = -1;
+  if (parts > 1) {
+    FILE* f = fopen(path, "rb");
+    if (!f) return -1;
+    fseek(f, 0, SEEK_END);
+    const long sz = ftell(f);
+    a = file_cut(f, sz, (long)((unsigned long long)sz * (unsigned)part / (unsigned)parts));
+    b = part + 1 >= parts ? sz : file_cut(f, sz, (long)((unsigned long long)sz * (unsigned)(part + 1) / (unsigned)parts));
+    fclose(f);
+  }
+  file_bytes fb;
+  if (file_bytes_open(path, a, b, &fb) != 0) return -1;
+  const long n = parse_buffer(fb.p, fb.len, arena, out);
+  file_bytes_close(&fb);
+  return n;
 }
 
 /* parse_genomic_header (src/io-multifasta.c:307-423): ">chr:start:end:+-1", else defaults */
@@ -345,12 +472,12 @@ void ef_polyAT_substitution(ef_seq* est) {
 /* copy_and_reverse (src/main-est-fact.c:67-87) */
 ef_seq* ef_copy_and_reverse(const ef_seq* est) {
   ef_seq* r = seq_new();
-  r->seq = strdup(est->seq);
-  r->original_seq = strdup(est->original_seq);
+  r->seq = dup_str(est->seq);
+  r->original_seq = dup_str(est->original_seq);
   ef_reverse_and_complement(r);
-  r->id = strdup(est->id);
-  r->gb = est->gb ? strdup(est->gb) : NULL;
-  r->chr = est->chr ? strdup(est->chr) : NULL;
+  r->id = dup_str(est->id);
+  r->gb = est->gb ? dup_str(est->gb) : NULL;
+  r->chr = est->chr ? dup_str(est->chr) : NULL;
   memcpy(r->strand_as_read, est->strand_as_read, sizeof r->strand_as_read);
   r->strand = -est->strand;
   r->fixed_strand = est->fixed_strand;

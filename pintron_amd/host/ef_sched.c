@@ -971,7 +971,7 @@ ef_session* ef_session_open(int argc, char** argv) {
   pthread_mutex_init(&s->sh.svc.mu, NULL);
   pthread_cond_init(&s->sh.svc.posted, NULL);
   pthread_cond_init(&s->sh.svc.finished, NULL);
-  int load_rc = ef_load_genomic(argc, argv, &s->in);
+  int load_rc = ef_load_genomic_sequence(argc, argv, &s->in);
   if (load_rc != 0) { ef_session_close(s); return NULL; }
   gpu_boot boot;
   memset(&boot, 0, sizeof boot);
@@ -989,6 +989,8 @@ ef_session* ef_session_open(int argc, char** argv) {
   if (boot.n_svc > MAX_SERVICES) boot.n_svc = MAX_SERVICES;
   pthread_t boot_thread;
   const bool booting = pthread_create(&boot_thread, NULL, gpu_boot_main, &boot) == 0;
+  ef_parse_threads = (int)env_size("PINTRON_PARSE_THREADS", host_core_share());      /* the cores idle while the GPU runtime starts */
+  ef_prepare_genomic_tables(&s->in);
   load_rc = ef_load_ests(&s->in);
   ef_classify_init();
   const double t_loaded = now_s();

@@ -224,6 +224,53 @@ def test_c_program_shards_one_gene_over_ranks(bins, tmp_path):
     assert not [p for p in os.listdir(tmp_path) if p.startswith(".pintron-comm-id")], "rendezvous files left behind"
 
 
+def test_c_program_ranks_read_only_their_part_of_the_file(bins, tmp_path):
+    """A rank of a sharded run reads and parses only its byte range of ests.txt, cut at record starts by a rule
+    every rank applies to the file on its own (ef_read_multifasta_part): whatever the layout -- text before the
+    first record, wrapped and empty lines, the '#\\#' terminator, CRLF, records of very different lengths, more
+    ranks than records -- the parts are disjoint, ordered and complete, i.e. the gathered files are those of one
+    process."""
+    import random
+    from pintron_amd import synth
+    w = synth.make("C2", n_est=60, seed=21)
+    rng = random.Random(5)
+    recs = []
+    for k, (h, sq) in enumerate(zip(w.est_headers, w.est_seqs)):
+        sq = sq.decode() if isinstance(sq, bytes) else sq
+        h = h.decode() if isinstance(h, bytes) else h
+        if k % 7 == 3:
+            sq = sq[:rng.randrange(30, 60)]                           # a short record between long ones
+        width = rng.choice([60, 70, 200, 10 ** 6])
+        lines = [sq[i:i + width] for i in range(0, len(sq), width)]
+        if k % 5 == 1:
+            lines.insert(1, "")                                       # an empty line inside a record
+        eol = "\r\n" if k % 4 == 2 else "\n"
+        recs.append(">" + h.lstrip(">") + eol + eol.join(lines) + eol)
+    layouts = {
+        "plain": "".join(recs),
+        "junk_first": "this line precedes the first record\n\n" + "".join(recs),
+        "few": "".join(recs[:3]),                                     # fewer records than ranks
+        "no_final_newline": "".join(recs).rstrip("\r\n"),
+    }
+    e = dict(os.environ, TMPDIR=str(tmp_path), PINTRON_THREADS="2")
+    for tag, text in layouts.items():
+        one = tmp_path / (tag + "_one")
+        one.mkdir()
+        (one / "genomic.txt").write_text(w.genomic_fasta())
+        (one / "ests.txt").write_text(text)
+        subprocess.run([bins["estfact_sched_check"]], cwd=one, env=e, check=True, stderr=subprocess.DEVNULL)
+        for world in (2, 5):
+            many = tmp_path / ("%s_%d" % (tag, world))
+            many.mkdir()
+            (many / "genomic.txt").write_text(w.genomic_fasta())
+            (many / "ests.txt").write_text(text)
+            subprocess.run([bins["estfact_sched_check"], "--gpus=%d" % world], cwd=many, env=e, check=True, stderr=subprocess.DEVNULL,
+                           timeout=120)
+            for f in FILES:
+                assert filecmp.cmp(one / f, many / f, shallow=False), (tag, world, f)
+    assert os.path.getsize(tmp_path / "plain_one" / "raw-multifasta-out.txt") > 5000
+
+
 @pytest.mark.parametrize("fault", ["1:open", "2:step", "1:abort", "0:step", "0:open"])
 def test_c_program_a_failing_rank_ends_all_ranks(bins, tmp_path, fault):
     """A rank that cannot open its session, whose step fails, or that dies outright (abort) must not
