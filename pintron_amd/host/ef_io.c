@@ -63,6 +63,13 @@ void ef_record_arena_free(ef_record_arena* a) {
   pthread_mutex_destroy(&a->mu);
   free(a);
 }
+/* the arena's mappings, for a process that is about to end and gives its pages back from several threads */
+size_t ef_record_arena_regions(ef_record_arena* a, void** base, size_t* len, size_t max) {
+  size_t n = 0;
+  if (!a) return 0;
+  for (rec_slab* sl = a->slabs; sl && n < max; sl = sl->next) { base[n] = sl->base; len[n] = sl->total; ++n; }
+  return n;
+}
 void ef_record_arena_enter(ef_record_arena* a) { tl_arena = a; tl_slab = NULL; }
 void ef_record_arena_leave(void) { tl_arena = NULL; tl_slab = NULL; }
 

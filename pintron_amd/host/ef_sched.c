@@ -1277,7 +1277,9 @@ int ef_session_step(ef_session* s, ef_sched_stats* stats_out) {
 
 /* the six files of the step, in input order, into the current directory: every file is cut into ranges of
  * units, a range is one task (gathering pwritev calls at the offset the lengths before it give), and a few
- * threads take the tasks -- the largest file alone (raw-multifasta-out, ~150 MB on C3) no longer sets the time */
+ * threads take the tasks -- the largest file alone (raw-multifasta-out, ~150 MB on C3) no longer sets the time.
+ * (Filling the files through shared mappings from all threads was tried and is slower: C5 0.85 - 1.0 s against
+ * 0.69 - 0.92 s, C3 0.08 against 0.05 s -- tools/exp/oneshot_ab.sh.) */
 enum { WRITE_RANGES = 8, WRITE_THREADS_MAX = 16, WRITE_IOV = 512 };
 typedef struct { int fd, k; size_t u0, u1; off_t at; } write_task;
 typedef struct { shared* sh; write_task* tasks; int n_tasks; int next; int failed; } write_pool;
@@ -1440,6 +1442,51 @@ void ef_session_close(ef_session* s) {
 
 int ef_leave_without_cleanup = 0;
 
+/* A process that ends hands its pages back to the kernel one after the other, on one core, at ~0.1 s per GB:
+ * 0.3 s of a one-shot C3 run, 0.8 s of a full C5 input.  What is this program's own and large -- the record
+ * arena, the text of the output files, the fibre stacks, the unit table -- is dropped from all cores first
+ * (madvise(MADV_DONTNEED) needs the address-space lock only for reading: 0.08 s for 4 GB, tools/exp/exit_cost).
+ * Nothing of it is read afterwards: the files are written, the statistics copied.  The memory of malloc's
+ * arenas and of the GPU runtime is left alone. */
+typedef struct { char* p; size_t len; } page_range;
+typedef struct { page_range* r; size_t n; size_t next; } page_release;
+static void* page_release_main(void* arg) {
+  page_release* pr = (page_release*)arg;
+  for (;;) {
+    const size_t k = __atomic_fetch_add(&pr->next, 1, __ATOMIC_RELAXED);
+    if (k >= pr->n) return NULL;
+    madvise(pr->r[k].p, pr->r[k].len, MADV_DONTNEED);
+  }
+}
+static void session_release_pages(ef_session* s) {
+  shared* sh = &s->sh;
+  size_t cap = 1024, n = 0;
+  for (fiber* f = sh->fiber_pool; f; f = f->pool_next) ++cap;
+  for (out_chunk* c = sh->chunks; c; c = c->next) ++cap;
+  for (out_chunk* c = sh->spare_chunks; c; c = c->next) ++cap;
+  void** ab = (void**)malloc(65536 * sizeof(void*)); size_t* al = (size_t*)malloc(65536 * sizeof(size_t));
+  const size_t na = ef_record_arena_regions(s->in.arena, ab, al, 65536);
+  page_range* r = (page_range*)malloc((cap + na) * 16 * sizeof(page_range));
+  const size_t piece = (size_t)8 << 20, room = (cap + na) * 16;
+#define ADD_RANGE(ptr, bytes) do { \
+    uintptr_t a_ = ((uintptr_t)(ptr) + 4095) & ~(uintptr_t)4095, b_ = ((uintptr_t)(ptr) + (bytes)) & ~(uintptr_t)4095; \
+    for (; a_ < b_ && n < room; a_ += piece) { r[n].p = (char*)a_; r[n].len = b_ - a_ < piece ? b_ - a_ : piece; ++n; } } while (0)
+  for (size_t k = 0; k < na; ++k) ADD_RANGE(ab[k], al[k]);
+  for (out_chunk* c = sh->chunks; c; c = c->next) ADD_RANGE(c->data, c->cap);
+  for (out_chunk* c = sh->spare_chunks; c; c = c->next) ADD_RANGE(c->data, c->cap);
+  for (fiber* f = sh->fiber_pool; f; f = f->pool_next) if (f->guarded) ADD_RANGE(f->stack, sh->stack_size);
+  if (sh->units) ADD_RANGE(sh->units, (sh->n_units + 1) * sizeof(unit));
+#undef ADD_RANGE
+  page_release pr = { r, n, 0 };
+  size_t nth = host_core_share();
+  if (nth > 16) nth = 16;
+  pthread_t th[16]; size_t started = 0;
+  for (size_t t = 1; t < nth; ++t) if (pthread_create(&th[started], NULL, page_release_main, &pr) == 0) ++started;
+  page_release_main(&pr);
+  for (size_t t = 0; t < started; ++t) pthread_join(th[t], NULL);
+  free(r); free(ab); free(al);
+}
+
 int ef_run_batched_stats(int argc, char** argv, ef_sched_stats* stats_out) {
   const run_mark m0 = run_mark_now();
   ef_session* s = ef_session_open(argc, argv);
@@ -1454,7 +1501,9 @@ int ef_run_batched_stats(int argc, char** argv, ef_sched_stats* stats_out) {
   /* The files are on disk and every stream has been waited for.  A process that is about to
    * exit (ef_leave_without_cleanup, set by the est-fact program) does not take the session apart
    * (200 000 sequences, fibre stacks, device pools: 0.3 s): the caller ends it with _exit. */
-  if (!ef_leave_without_cleanup) ef_session_close(s);
+  const bool leave = ef_leave_without_cleanup != 0;
+  if (!leave) ef_session_close(s);
+  else if (!getenv("PINTRON_NO_PAGE_RELEASE")) session_release_pages(s);
   ef_log_reference_timers(st.index_s, st.prefetch_s, st.workers_s, st.load_s + (m3.wall - m2.wall), now_s() - m0.wall);
   if (getenv("PINTRON_VERBOSE")) {
     fprintf(stderr, "* run: open %.3fs step %.3fs write %.3fs close %.3fs\n", m1.wall - m0.wall, m2.wall - m1.wall, m3.wall - m2.wall, now_s() - m3.wall);

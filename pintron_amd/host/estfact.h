@@ -97,6 +97,7 @@ static inline size_t ef_genomic_len(const char* gen) {
 typedef struct ef_record_arena ef_record_arena;
 ef_record_arena* ef_record_arena_new(void);
 void ef_record_arena_free(ef_record_arena* a);
+size_t ef_record_arena_regions(ef_record_arena* a, void** base, size_t* len, size_t max);
 void ef_record_arena_enter(ef_record_arena* a);   /* the calling thread's records go to `a` from here on ... */
 void ef_record_arena_leave(void);                 /* ... until here */
 

@@ -9,5 +9,8 @@ s=open('/tmp/ec.txt').read().strip(); b=float(re.search(r'leaves at ([0-9.]+)',s
 print('%-28s wall %.3f after-main %.3f | %s' % (' '.join(sys.argv[3:]), float(sys.argv[2])-float(sys.argv[1]), float(sys.argv[2])-b, s.split(' leaves')[0]))" $T0 $T1 "$@"
 }
 run 0 1 0 0 1
-run 0 1 0 0 4
-run 0 1 0 1024 1
+run 0 1 0 2048 1 0 0
+run 0 1 0 2048 1 0 16
+run 0 1 0 2048 1 0 4
+run 0 1 0 4096 1 0 0
+run 0 1 0 4096 1 0 16
