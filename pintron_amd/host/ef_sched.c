@@ -246,6 +246,12 @@ typedef struct shared {
   bool use_meg;
   pgpu_meg_params meg_prm;
   unsigned char* pre_meg[PRE_CHUNKS]; size_t pre_meg_cap[PRE_CHUNKS]; uint64_t* pre_meg_first[PRE_CHUNKS];
+  /* page-locked memory is slow to get (0.25 s per GB): the records and offsets of all chunks are cut from ONE
+   * allocation sized after the first chunk (a chunk that does not fit gets a block of its own), and the
+   * patterns of every chunk go up through one staging buffer */
+  unsigned char* pre_slab; size_t pre_slab_cap, pre_slab_used;
+  bool pre_own[PRE_CHUNKS], pre_first_own[PRE_CHUNKS];
+  char* up_stage; size_t up_stage_cap;
   size_t ready_entries;                       /* entries below this have their pairings (written under mu with a release store; read without the lock) */
   pthread_cond_t ready_cv;
   bool kernel_timing;
@@ -1089,16 +1095,24 @@ static int make_pattern_plan(ef_session* s, int c) {
   shared* sh = &s->sh;
   ef_inputs* in = &s->in;
   const size_t lo = sh->pre_lo[c], hi = sh->pre_lo[c + 1];
-  size_t total = 0;
-  for (size_t k = lo; k < hi; ++k) total += strlen(in->list[k]->seq);
-  char* blob = (char*)malloc(total + 1);
   uint64_t* off = (uint64_t*)malloc((hi - lo + 1) * sizeof(uint64_t));
-  if (!blob || !off) { free(blob); free(off); return PGPU_ENOMEM; }
-  size_t pos = 0;
-  for (size_t k = lo; k < hi; ++k) { const size_t m = strlen(in->list[k]->seq); off[k - lo] = pos; memcpy(blob + pos, in->list[k]->seq, m); pos += m; }
-  off[hi - lo] = pos;
-  const int prc = pgpu_pairing_plan_create_resident(s->ctx0, sh->idx, blob, off, hi - lo, &s->pplan[c]);
-  free(blob); free(off);
+  if (!off) return PGPU_ENOMEM;
+  size_t total = 0;
+  for (size_t k = lo; k < hi; ++k) { off[k - lo] = total; total += strlen(in->list[k]->seq); }
+  off[hi - lo] = total;
+  if (total + 1 > sh->up_stage_cap) {                       /* page-locked: the copy to the device runs at PCIe speed */
+    if (sh->up_stage) pgpu_host_free(s->ctx0, sh->up_stage);
+    sh->up_stage = NULL; sh->up_stage_cap = 0;
+    void* q = NULL;
+    const size_t want = total + total / 4 + 4096;
+    if (pgpu_host_alloc(s->ctx0, want, &q) == PGPU_OK) { sh->up_stage = (char*)q; sh->up_stage_cap = want; }
+  }
+  char* blob = sh->up_stage ? sh->up_stage : (char*)malloc(total + 1);
+  if (!blob) { free(off); return PGPU_ENOMEM; }
+  for (size_t k = lo; k < hi; ++k) memcpy(blob + off[k - lo], in->list[k]->seq, (size_t)(off[k - lo + 1] - off[k - lo]));
+  const int prc = pgpu_pairing_plan_create_resident(s->ctx0, sh->idx, blob, off, hi - lo, &s->pplan[c]);   /* returns after the copy */
+  if (blob != sh->up_stage) free(blob);
+  free(off);
   return prc;
 }
 
@@ -1127,16 +1141,31 @@ static void* prefetch_main(void* arg) {
       else {
         const size_t bytes = (size_t)pgpu_pairing_plan_meg_bytes(s->pplan[c]);
         const size_t entries = sh->pre_lo[c + 1] - sh->pre_lo[c];
-        if (bytes > sh->pre_meg_cap[c] || !sh->pre_meg[c]) {
-          if (sh->pre_meg[c]) pgpu_host_free(s->ctx0, sh->pre_meg[c]);
-          sh->pre_meg[c] = NULL;
-          sh->pre_meg_cap[c] = bytes + bytes / 8 + 4096;
+        if (!sh->pre_slab && c == 1 && sh->n_pre > 2) {
+          /* the first chunk got blocks of its own -- the workers wait for it -- and the rest are about as large as
+           * the second: their memory is allocated now, in one piece, while the workers have the first to do */
+          const size_t per = (bytes + bytes / 4 + 4096 + (entries + 2) * sizeof(uint64_t) + 511) & ~(size_t)511;
           void* q = NULL;
-          if (pgpu_host_alloc(s->ctx0, sh->pre_meg_cap[c], &q) == PGPU_OK) sh->pre_meg[c] = (unsigned char*)q;
+          if (pgpu_host_alloc(s->ctx0, per * (size_t)(sh->n_pre - 1), &q) == PGPU_OK) { sh->pre_slab = (unsigned char*)q; sh->pre_slab_cap = per * (size_t)(sh->n_pre - 1); }
+        }
+        if (bytes > sh->pre_meg_cap[c] || !sh->pre_meg[c]) {
+          if (sh->pre_meg[c] && sh->pre_own[c]) pgpu_host_free(s->ctx0, sh->pre_meg[c]);
+          sh->pre_meg[c] = NULL; sh->pre_own[c] = false;
+          sh->pre_meg_cap[c] = bytes + bytes / 8 + 4096;
+          const size_t need = (sh->pre_meg_cap[c] + 255) & ~(size_t)255;
+          if (sh->pre_slab && sh->pre_slab_used + need <= sh->pre_slab_cap) { sh->pre_meg[c] = sh->pre_slab + sh->pre_slab_used; sh->pre_slab_used += need; }
+          else {
+            void* q = NULL;
+            if (pgpu_host_alloc(s->ctx0, sh->pre_meg_cap[c], &q) == PGPU_OK) { sh->pre_meg[c] = (unsigned char*)q; sh->pre_own[c] = true; }
+          }
         }
         if (!sh->pre_meg_first[c]) {
-          void* q = NULL;
-          if (pgpu_host_alloc(s->ctx0, (entries + 1) * sizeof(uint64_t), &q) == PGPU_OK) sh->pre_meg_first[c] = (uint64_t*)q;
+          const size_t need = ((entries + 1) * sizeof(uint64_t) + 255) & ~(size_t)255;
+          if (sh->pre_slab && sh->pre_slab_used + need <= sh->pre_slab_cap) { sh->pre_meg_first[c] = (uint64_t*)(sh->pre_slab + sh->pre_slab_used); sh->pre_slab_used += need; }
+          else {
+            void* q = NULL;
+            if (pgpu_host_alloc(s->ctx0, (entries + 1) * sizeof(uint64_t), &q) == PGPU_OK) { sh->pre_meg_first[c] = (uint64_t*)q; sh->pre_first_own[c] = true; }
+          }
         }
         if (!sh->pre_meg[c] || !sh->pre_meg_first[c]) prc = PGPU_ENOMEM;
         else prc = pgpu_pairing_plan_fetch_meg(s->ctx0, s->pplan[c], sh->pre_meg[c], sh->pre_meg_cap[c], sh->pre_meg_first[c]);
@@ -1426,10 +1455,12 @@ void ef_session_close(ef_session* s) {
   free(sh->units);
   for (int c = 0; c < PRE_CHUNKS && s->ctx0; ++c) {
     free(sh->pre_tri[c]); free(sh->pre_first[c]);
-    if (sh->pre_meg[c]) pgpu_host_free(s->ctx0, sh->pre_meg[c]);
-    if (sh->pre_meg_first[c]) pgpu_host_free(s->ctx0, sh->pre_meg_first[c]);
+    if (sh->pre_meg[c] && sh->pre_own[c]) pgpu_host_free(s->ctx0, sh->pre_meg[c]);
+    if (sh->pre_meg_first[c] && sh->pre_first_own[c]) pgpu_host_free(s->ctx0, sh->pre_meg_first[c]);
     if (s->pplan[c]) pgpu_pairing_plan_destroy(s->ctx0, s->pplan[c]);
   }
+  if (sh->pre_slab) pgpu_host_free(s->ctx0, sh->pre_slab);
+  if (sh->up_stage) pgpu_host_free(s->ctx0, sh->up_stage);
   for (int k = 0; k < MAX_SERVICES; ++k) if (sh->svc.threads[k].ctx) pgpu_destroy(sh->svc.threads[k].ctx);
   if (s->ctx0 && sh->idx) pgpu_index_destroy(s->ctx0, sh->idx);
   if (s->ctx0) pgpu_destroy(s->ctx0);
