@@ -109,8 +109,8 @@ int pgpu_pairings(pgpu_ctx* ctx, const pgpu_index* idx,
 typedef struct pgpu_pairing_plan pgpu_pairing_plan;
 int pgpu_pairing_plan_create(pgpu_ctx* ctx, const pgpu_index* idx, const char* patterns,
                              const uint64_t* pat_off, size_t n_pat, pgpu_pairing_plan** plan);
-/* The same plan for a batch that is cut into several plans used one after the other (the chunks of the EST
- * batch the host prefetches): only the patterns -- bytes, offsets, 2-bit packing -- are the plan's own, in ONE
+/* The same plan (build_vertex_set, src/max-emb-graph.c:218-392, as above) for a batch that is cut into several
+ * plans used one after the other (the chunks of the EST batch the host prefetches): only the patterns -- bytes, offsets, 2-bit packing -- are the plan's own, in ONE
  * device allocation; every buffer a run writes (16 of them, ~60 bytes per pattern position, and the MEG stage's
  * 11 KB per pattern) is shared by all resident plans of the context.  What a run leaves -- the pairings for
  * fetch / run_meg, the MEG records for fetch_meg -- is valid until another resident plan of the same context
