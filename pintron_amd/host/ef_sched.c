@@ -929,6 +929,7 @@ static void* pool_builder_main(void* arg) {
 typedef struct {
   pgpu_ctx* ctx; int rc; const char* gen; size_t gen_len; pgpu_index* idx; int idx_rc;
   int n_svc; pgpu_ctx* svc[MAX_SERVICES]; int svc_rc;     /* the contexts of the service threads come up here too */
+  double t_init, t_index, t_svc;                          /* PINTRON_VERBOSE: runtime start-up + first context, index, service contexts */
 } gpu_boot;
 static void boot_service_contexts(gpu_boot* b) {
   b->svc_rc = PGPU_OK;
@@ -940,7 +941,9 @@ static void boot_service_contexts(gpu_boot* b) {
 static void* gpu_boot_main(void* arg) {
   pthread_setname_np(pthread_self(), "ef-gpu-boot");
   gpu_boot* b = (gpu_boot*)arg;
+  const double tb0 = now_s();
   b->rc = pgpu_init(ef_gpu_device_from_env(), &b->ctx);
+  b->t_init = now_s() - tb0;
   if (b->rc == PGPU_OK) {
     if (env_flag("PINTRON_KERNEL_TIMING")) pgpu_set_timing(b->ctx, 1);
     /* PINTRON_INDEX_CACHE=<directory>: the index of a sequence is kept there under its hash and
@@ -954,11 +957,15 @@ static void* gpu_boot_main(void* arg) {
       b->idx_rc = pgpu_index_load(b->ctx, path, b->gen, b->gen_len, &b->idx);
       if (b->idx_rc == PGPU_OK) { boot_service_contexts(b); return NULL; }
     }
+    const double tb1 = now_s();
     b->idx_rc = pgpu_index_build(b->ctx, b->gen, b->gen_len, &b->idx);
+    b->t_index = now_s() - tb1;
     /* of a sharded run only rank 0 saves (all ranks built the same index) */
     if (b->idx_rc == PGPU_OK && cache && cache[0] && ef_shard_rank == 0 && pgpu_index_save(b->ctx, b->idx, b->gen, path) != PGPU_OK)
       fprintf(stderr, "* WARN the index could not be saved to %s\n", path);
+    const double tb2 = now_s();
     if (b->idx_rc == PGPU_OK) boot_service_contexts(b);
+    b->t_svc = now_s() - tb2;
   }
   return NULL;
 }
@@ -1053,8 +1060,8 @@ ef_session* ef_session_open(int argc, char** argv) {
     ef_session_close(s); return NULL;
   }
   if (getenv("PINTRON_VERBOSE"))
-    fprintf(stderr, "* open: load %.3fs, then GPU runtime + index + service contexts still %.3fs, rest %.3fs\n",
-            t_loaded - t_start, t_booted - t_loaded, now_s() - t_booted);
+    fprintf(stderr, "* open: load %.3fs, then GPU runtime + index + service contexts still %.3fs, rest %.3fs (GPU side: runtime + first context %.3fs, index %.3fs, service contexts %.3fs)\n",
+            t_loaded - t_start, t_booted - t_loaded, now_s() - t_booted, boot.t_init, boot.t_index, boot.t_svc);
   /* the workers hide the GPU latency with lanes, not with oversubscription */
   s->nthreads = env_size("PINTRON_THREADS", host_core_share());
   if (s->nthreads > sh->n_units) s->nthreads = sh->n_units ? sh->n_units : 1;
