@@ -938,6 +938,13 @@ static void boot_service_contexts(gpu_boot* b) {
     if (b->svc_rc == PGPU_OK && env_flag("PINTRON_KERNEL_TIMING")) pgpu_set_timing(b->svc[k], 1);
   }
 }
+static void* boot_service_contexts_main(void* arg) {
+  gpu_boot* b = (gpu_boot*)arg;
+  const double t0 = now_s();
+  boot_service_contexts(b);
+  b->t_svc = now_s() - t0;
+  return NULL;
+}
 static void* gpu_boot_main(void* arg) {
   pthread_setname_np(pthread_self(), "ef-gpu-boot");
   gpu_boot* b = (gpu_boot*)arg;
@@ -946,26 +953,30 @@ static void* gpu_boot_main(void* arg) {
   b->t_init = now_s() - tb0;
   if (b->rc == PGPU_OK) {
     if (env_flag("PINTRON_KERNEL_TIMING")) pgpu_set_timing(b->ctx, 1);
+    /* the runtime is up: the service threads' contexts (a stream each) are made beside the index */
+    pthread_t svc_thread;
+    const bool svc_started = pthread_create(&svc_thread, NULL, boot_service_contexts_main, b) == 0;
     /* PINTRON_INDEX_CACHE=<directory>: the index of a sequence is kept there under its hash and
      * loaded instead of built the next time the same genomic sequence comes by */
     const char* cache = getenv("PINTRON_INDEX_CACHE");
     char path[1200];
+    bool loaded = false;
+    const double tb1 = now_s();
     if (cache && cache[0]) {
       unsigned long long h = 1469598103934665603ull;
       for (size_t i = 0; i < b->gen_len; ++i) { h ^= (unsigned char)b->gen[i]; h *= 1099511628211ull; }
       snprintf(path, sizeof path, "%s/pintron-index-%016llx-%zu.bin", cache, h, b->gen_len);
       b->idx_rc = pgpu_index_load(b->ctx, path, b->gen, b->gen_len, &b->idx);
-      if (b->idx_rc == PGPU_OK) { boot_service_contexts(b); return NULL; }
+      loaded = b->idx_rc == PGPU_OK;
     }
-    const double tb1 = now_s();
-    b->idx_rc = pgpu_index_build(b->ctx, b->gen, b->gen_len, &b->idx);
+    if (!loaded) {
+      b->idx_rc = pgpu_index_build(b->ctx, b->gen, b->gen_len, &b->idx);
+      /* of a sharded run only rank 0 saves (all ranks built the same index) */
+      if (b->idx_rc == PGPU_OK && cache && cache[0] && ef_shard_rank == 0 && pgpu_index_save(b->ctx, b->idx, b->gen, path) != PGPU_OK)
+        fprintf(stderr, "* WARN the index could not be saved to %s\n", path);
+    }
     b->t_index = now_s() - tb1;
-    /* of a sharded run only rank 0 saves (all ranks built the same index) */
-    if (b->idx_rc == PGPU_OK && cache && cache[0] && ef_shard_rank == 0 && pgpu_index_save(b->ctx, b->idx, b->gen, path) != PGPU_OK)
-      fprintf(stderr, "* WARN the index could not be saved to %s\n", path);
-    const double tb2 = now_s();
-    if (b->idx_rc == PGPU_OK) boot_service_contexts(b);
-    b->t_svc = now_s() - tb2;
+    if (svc_started) pthread_join(svc_thread, NULL); else boot_service_contexts_main(b);
   }
   return NULL;
 }
