@@ -563,15 +563,28 @@ static hipError_t build_lcf_tables(pgpu_index* idx, const char* genomic, hipStre
   uint32_t fb = n;
   for (uint32_t i = 0; i < n; ++i) { const char c = genomic[i]; if (c != 'A' && c != 'C' && c != 'G' && c != 'T') { fb = i; break; } }
   idx->first_bad = fb;
+  // The tables of the suffix-array LCF are optional: floor(log2 n) x n x 4 B of range minima is 14 MB for a 200 kb
+  // gene but 10 GB for 100 Mb.  Without them (switched off, a sequence beyond PGPU_LCF_SA_MAX_BASES -- default
+  // 2^26 --, or no memory) every LCF job takes lcf_kernel: pgpu_dp_plan_create_parts looks at d_focc / d_rmq.
+  {
+    const char* sw = getenv("PGPU_LCF_SA");
+    const char* mx = getenv("PGPU_LCF_SA_MAX_BASES");
+    const unsigned long long max_bases = mx && atoll(mx) > 0 ? (unsigned long long)atoll(mx) : (1ull << 26);
+    if ((sw && sw[0] == '0' && sw[1] == '\0') || n > max_bases) return hipSuccess;
+  }
   hipError_t e = hipMalloc((void**)&idx->d_focc, LCF_FOCC_ENTRIES * sizeof(uint32_t));
-  if (e != hipSuccess) return e;
+  if (e != hipSuccess) { idx->d_focc = nullptr; (void)hipGetLastError(); return hipSuccess; }
   e = hipMemsetAsync(idx->d_focc, 0xFF, LCF_FOCC_ENTRIES * sizeof(uint32_t), st);
   if (e != hipSuccess) return e;
   uint32_t levels = 0;
   while (n >= 2 && (2u << levels) <= n) ++levels;              // levels j = 1..levels with 2^j <= n
   idx->rmq_levels = levels;
   e = hipMalloc((void**)&idx->d_rmq, ((size_t)(levels ? levels : 1) * (n ? n : 1)) * sizeof(uint32_t));
-  if (e != hipSuccess) return e;
+  if (e != hipSuccess) {                                       // no room for the range minima: the matrix kernel serves
+    idx->d_rmq = nullptr; idx->rmq_levels = 0; (void)hipGetLastError();
+    hipFree(idx->d_focc); idx->d_focc = nullptr;
+    return hipSuccess;
+  }
   if (n == 0) return hipSuccess;
   const dim3 blk(256), grd((n + 255) / 256);
   hipLaunchKernelGGL(first_occ_kernel, grd, blk, 0, st, idx->d_gen, n, idx->d_focc);

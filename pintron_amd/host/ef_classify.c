@@ -212,8 +212,11 @@ static int classify_uncached(const ef_seq* gs, int start, int end) {
   if (idx < 0) { want += idx; idx = 0; }
   if (want < 0) want = 0;
   const char* intron = gen + idx;
-  const char* nul = (const char*)memchr(intron, 0, (size_t)want);
-  const size_t il = nul ? (size_t)(nul - intron) : (size_t)want;
+  /* real_substring stops at the terminator of the sequence: the intron is cut at the end of the genomic
+   * sequence, whose length is known (looking for the terminator meant reading the whole intron, up to
+   * tens of kilobases, for every candidate of the small-exon search) */
+  const size_t gl = ef_genomic_len(gen);
+  const size_t il = (size_t)idx >= gl ? 0 : ((size_t)want < gl - (size_t)idx ? (size_t)want : gl - (size_t)idx);
   /* The branch-point scan looks at the windows 30..14 bases before the END of the intron only (and
    * gives up on introns shorter than 30), so its verdict is a property of the end position; the
    * small-exon search proposes thousands of introns sharing a few ends. */

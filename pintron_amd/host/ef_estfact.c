@@ -100,6 +100,7 @@ ef_est* ef_compute_est_fact(const ef_seq* gen, const ef_seq* est, ef_backend* be
     ef_meg* V = NULL;
     bool same;
     do {
+      ef_phase(EFP_MEG);
       V = ef_build_meg(est, be, cfg, &inc);
       ef_meg_stats(V, &tp, &te);
       same = prev_tp > 2 && prev_te > 0 && (prev_tp <= tp || prev_te <= te);
@@ -110,11 +111,13 @@ ef_est* ef_compute_est_fact(const ef_seq* gen, const ef_seq* est, ef_backend* be
     fe = ef_get_est_factorizations(est, V, cfg, gen, be);
     expired = fe == NULL;
     if (fe) {
+      ef_phase(EFP_FACTREF);
       ef_refine_est_factorizations(gen, fe, cfg, be);
       ef_remove_factorizations_with_very_small_exons(fe->factorizations);
       if (!efl_empty(fe->factorizations)) ef_remove_duplicated_factorizations(fe->factorizations);
     }
     const bool aligned = fe && !efl_empty(fe->factorizations);
+    ef_phase(EFP_SIDE);
     if ((!expired || aligned) && side && side->fmeg) {            /* report_meg (:73-88) */
       ef_sink_puts(side->fmeg, "\n\n***********\n\n");
       ef_write_single_est_info(side->fmeg, est);
@@ -136,7 +139,9 @@ ef_est* ef_compute_est_fact(const ef_seq* gen, const ef_seq* est, ef_backend* be
       }
     }
     if (expired) ++inc;                                          /* :277-283: longer factors, again */
+    ef_phase(EFP_FREE);
     ef_meg_free(V);
+    ef_phase(EFP_OTHER);
   } while (expired);
   return fe;
 }

@@ -808,6 +808,7 @@ static bool detect_polyA(ef_list* fact, const char* gen, const char* est, bool* 
 /* ---------------------------------------------------------------------------------------------- */
 ef_est* ef_get_est_factorizations(const ef_seq* est_info, ef_meg* V, const ef_config* cfg,
                                   const ef_seq* gen_info, ef_backend* be) {
+  ef_phase(EFP_EMBED);
   ef_est* est = (ef_est*)calloc(1, sizeof(ef_est));
   est->info = est_info;
   const char* GEN = gen_info->seq;
@@ -824,6 +825,7 @@ ef_est* ef_get_est_factorizations(const ef_seq* est_info, ef_meg* V, const ef_co
     while (efi_has_next(&it)) {
       ef_pairing* root = (ef_pairing*)efi_next(&it);
       if (root->visited) continue;
+      ef_phase(EFP_EMBED);
       ef_list* embs = subtree_embeddings(root, cfg, GEN, &wk);
       if (!embs) {
         /* budget spent (:190-193): nothing of this attempt is kept, the caller retries */
@@ -841,10 +843,11 @@ ef_est* ef_get_est_factorizations(const ef_seq* est_info, ef_meg* V, const ef_co
         ef_list* f = (ef_list*)efi_next(&ci);
         bool ok = not_source_sink(f, (int)est_len);
         if (ok) ok = exon_start_end_ok(f);
-        if (ok) { f = handle_endpoints(f, GEN, EST, be); if (efl_empty(f)) ok = false; }
-        if (ok) { f = ef_clean_external_exons(f, GEN, EST, be); if (efl_empty(f)) ok = false; }
-        if (ok) { f = clean_low_complexity(f, GEN, EST, cfg); if (efl_empty(f)) ok = false; }
-        if (ok) { f = ef_clean_noisy_exons(f, GEN, EST, false, be); if (efl_empty(f)) ok = false; }
+        if (ok) { ef_phase(EFP_ENDPOINTS); f = handle_endpoints(f, GEN, EST, be); if (efl_empty(f)) ok = false; }
+        if (ok) { ef_phase(EFP_EXTERNAL); f = ef_clean_external_exons(f, GEN, EST, be); if (efl_empty(f)) ok = false; }
+        if (ok) { ef_phase(EFP_DUST); f = clean_low_complexity(f, GEN, EST, cfg); if (efl_empty(f)) ok = false; }
+        if (ok) { ef_phase(EFP_NOISY); f = ef_clean_noisy_exons(f, GEN, EST, false, be); if (efl_empty(f)) ok = false; }
+        ef_phase(EFP_ADD);
         if (ok) ok = est_coverage_ok(f, EST);
         if (ok) {
           bool added;
@@ -867,6 +870,7 @@ ef_est* ef_get_est_factorizations(const ef_seq* est_info, ef_meg* V, const ef_co
     while (efi_has_next(&it)) { ef_pairing* p = (ef_pairing*)efi_next(&it); if (p->emb_memo) { efl_free(p->emb_memo, embedding_free); p->emb_memo = NULL; } }
   }
 
+  ef_phase(EFP_FILTERS);
   /* FILTER 1: coverage (:278-331) */
   {
     const size_t nf = efl_size(flist);
@@ -918,6 +922,7 @@ ef_est* ef_get_est_factorizations(const ef_seq* est_info, ef_meg* V, const ef_co
     }
     if (gl != gl_small) free(gl);
   }
+  ef_phase(EFP_GAPERR);
   /* FILTER 4: gap errors (:416-433) */
   {
     ef_iter it = efl_begin(flist);
@@ -930,6 +935,7 @@ ef_est* ef_get_est_factorizations(const ef_seq* est_info, ef_meg* V, const ef_co
     efl_free(flist, ef_factorization_free);
     flist = efl_new();
   }
+  ef_phase(EFP_INTRON);
   /* intron refinement (:446-490) */
   {
     ef_iter it = efl_begin(flist);
@@ -953,6 +959,7 @@ ef_est* ef_get_est_factorizations(const ef_seq* est_info, ef_meg* V, const ef_co
       }
     }
   }
+  ef_phase(EFP_TAIL);
   /* tail correction and polyA (:573-585) -- on the ORIGINAL EST sequence */
   est->polyA_signals = efl_new();
   est->polyadenil_signals = efl_new();

@@ -333,62 +333,110 @@ static void small_exon_between(ef_factor* p1, ef_factor* p2, ef_iter* it, const 
     else if (elen < LB_SMALL_EXON) go = false;
     if (go) {
       char* efact = ef_real_substring((int)estart, (int)elen, E);
-      char* allg = ef_real_substring((int)allgstart, (int)allglen, G);
+      /* the intron is read where it lies; the copy the reference makes (real_substring of up to 20 kb) is only
+       * needed by the strstr() fallback, which wants to cut it with a terminator */
+      const bool in_place = allgstart + allglen <= ef_genomic_len(G);
+      char* allg_copy = NULL;
+      const char* allg = in_place ? G + allgstart : (allg_copy = ef_real_substring((int)allgstart, (int)allglen, G));
       size_t max_len = 0, ecut1 = 0, ecut2 = 0, gcut1_1 = 0, gcut1_2 = 0, gcut2_1 = 0, gcut2_2 = 0;
       const size_t max_offstart = zmin(zmin(f1slen + 1 - MIN_PERFECT_BORDER, elen + 1 - LB_SMALL_EXON), allglen + 1 - (2 * MIL) - LB_SMALL_EXON);
       /* The reference runs strstr() over the whole intron for every (offstart, offend) pair
        * (:781-834).  Same occurrences, same order, found through the 6-mer index of the genomic
        * sequence (gen->kmer_*, built once per gene; every pattern is at least LB_SMALL_EXON = 6
        * long): the candidates of a window are a contiguous run of the 6-mer's ascending position
-       * list.  Patterns whose first six characters are not all ACGT fall back to strstr(). */
-      for (size_t os = 0; os < max_offstart; ++os) {
+       * list, and how far a candidate matches the pattern of this offstart is computed once for all
+       * offends (a pattern of length plen occurs there iff the match is at least plen long).
+       * Patterns whose first six characters are not all ACGT fall back to strstr().
+       * A pair whose pattern is not longer than the best found so far cannot replace it (strict
+       * comparison at :820): such pairs -- all later offends of this offstart, and every later offstart
+       * once elen - os itself is not longer -- are skipped. */
+      for (size_t os = 0; os < max_offstart && elen - os > max_len; ++os) {
         const size_t max_offend = zmin(zmin(f2plen + 1 - MIN_PERFECT_BORDER, elen + 1 - os - LB_SMALL_EXON), allglen + 1 - (2 * MIL) - LB_SMALL_EXON - os);
         const int code = kmer_code(efact + os);
-        const uint32_t* cand = NULL; size_t nc = 0;
+        enum { CAND_MAX = 48 };
+        uint32_t cq[CAND_MAX], cm[CAND_MAX]; size_t nc = 0;       /* window-relative position, match length */
+        bool listed = false;
         if (code >= 0) {                                       /* occurrences inside the window */
           const uint32_t* all = gen->kmer_pos + gen->kmer_first[code];
           const size_t nall = gen->kmer_first[code + 1] - gen->kmer_first[code];
-          const size_t from = lower_bound_u32(all, nall, (uint32_t)allgstart);
-          cand = all + from; nc = nall - from;
+          size_t k = lower_bound_u32(all, nall, (uint32_t)(allgstart + os + MIL));     /* text_lo of every offend */
+          listed = true;
+          const size_t pmax = elen - os;                       /* the longest pattern of this offstart */
+          for (; k < nall; ++k) {
+            const size_t qa = all[k];
+            if (qa >= allgstart + allglen) break;
+            if (nc == CAND_MAX) { listed = false; break; }
+            const size_t q = qa - allgstart;
+            size_t room = allglen - q; if (room > pmax) room = pmax;
+            size_t m = LB_SMALL_EXON;
+            while (m < room && allg[q + m] == efact[os + m]) ++m;
+            cq[nc] = (uint32_t)q; cm[nc] = (uint32_t)m; ++nc;
+          }
         }
-        for (size_t oe = 0; oe < max_offend; ++oe) {
+        if (code >= 0 && !listed) {                            /* more occurrences than the table holds: as before, one by one */
+          const uint32_t* all = gen->kmer_pos + gen->kmer_first[code];
+          const size_t nall = gen->kmer_first[code + 1] - gen->kmer_first[code];
+          const size_t from = lower_bound_u32(all, nall, (uint32_t)allgstart);
+          const uint32_t* cand = all + from; const size_t ncand = nall - from;
+          for (size_t oe = 0; oe < max_offend && elen - os - oe > max_len; ++oe) {
+            const size_t plen = elen - os - oe;
+            const size_t text_lo = os + MIL, text_hi = allglen - oe - MIL;
+            for (size_t cursor = 0; cursor < ncand; ++cursor) {
+              const size_t qa = cand[cursor];
+              if (qa >= allgstart + allglen) break;
+              const size_t q = qa - allgstart;
+              if (q < text_lo || plen > text_hi || q > text_hi - plen) continue;
+              if (memcmp(allg + q + LB_SMALL_EXON, efact + os + LB_SMALL_EXON, plen - LB_SMALL_EXON) != 0) continue;
+              const size_t i1s = allgstart + os, i1e = allgstart + q - 1;
+              const size_t i2s = i1e + 1 + elen - os - oe, i2e = allgstart + allglen - oe - 1;
+              const int t1 = ef_classify_intron(gen, (int)i1s, (int)i1e), t2 = ef_classify_intron(gen, (int)i2s, (int)i2e);
+              if (t1 != INTRON_ND && t2 != INTRON_ND && plen > max_len) {
+                max_len = plen; ecut1 = estart + os; ecut2 = estart + os + plen; gcut1_1 = i1s; gcut1_2 = i1e + 1; gcut2_1 = i2s; gcut2_2 = i2e + 1;
+              }
+            }
+          }
+          continue;
+        }
+        /* no listed candidate matches further than `reach`: the offends whose pattern is longer find nothing */
+        size_t oe0 = 0;
+        if (code >= 0) {
+          size_t reach = 0;
+          for (size_t c = 0; c < nc; ++c) if (cm[c] > reach) reach = cm[c];
+          if (reach < LB_SMALL_EXON) continue;                 /* no occurrence at all */
+          if (elen - os > reach) oe0 = elen - os - reach;
+        }
+        for (size_t oe = oe0; oe < max_offend && elen - os - oe > max_len; ++oe) {
           const size_t plen = elen - os - oe;                 /* pattern efact[os .. elen-oe) */
           const size_t text_lo = os + MIL, text_hi = allglen - oe - MIL;   /* text allg[text_lo .. text_hi) */
-          size_t cursor = 0;                                   /* next candidate (index mode) */
-          char sv_e = 0, sv_g = 0;
-          char* occ = NULL;
-          if (code < 0) {
-            sv_e = efact[elen - oe]; efact[elen - oe] = '\0';
-            sv_g = allg[text_hi]; allg[text_hi] = '\0';
-            occ = allg + text_lo;
-          }
-          for (;;) {
-            size_t q;
-            if (code < 0) {
-              occ = strstr(occ, efact + os);
-              if (!occ) break;
-              q = (size_t)(occ - allg);
-              ++occ;
-            } else {
-              bool found = false;
-              while (cursor < nc) {
-                const size_t qa = cand[cursor++];               /* absolute position, ascending */
-                if (qa >= allgstart + allglen) { cursor = nc; break; }
-                q = qa - allgstart;
-                if (q < text_lo || plen > text_hi || q > text_hi - plen) continue;
-                if (memcmp(allg + q + LB_SMALL_EXON, efact + os + LB_SMALL_EXON, plen - LB_SMALL_EXON) == 0) { found = true; break; }
+          if (code >= 0) {
+            if (plen > text_hi) continue;
+            for (size_t c = 0; c < nc; ++c) {
+              const size_t q = cq[c];
+              if (q > text_hi - plen) break;                   /* ascending: the rest lies further right */
+              if (cm[c] < plen) continue;                      /* (q >= text_lo by construction of the list) */
+              const size_t i1s = allgstart + os, i1e = allgstart + q - 1;
+              const size_t i2s = i1e + 1 + elen - os - oe, i2e = allgstart + allglen - oe - 1;
+              const int t1 = ef_classify_intron(gen, (int)i1s, (int)i1e), t2 = ef_classify_intron(gen, (int)i2s, (int)i2e);
+              if (t1 != INTRON_ND && t2 != INTRON_ND && plen > max_len) {
+                max_len = plen; ecut1 = estart + os; ecut2 = estart + os + plen; gcut1_1 = i1s; gcut1_2 = i1e + 1; gcut2_1 = i2s; gcut2_2 = i2e + 1;
               }
-              if (!found) break;
             }
+            continue;
+          }
+          /* strstr() over a terminated copy of the window */
+          if (!allg_copy) allg_copy = ef_real_substring((int)allgstart, (int)allglen, G);
+          const char sv_e = efact[elen - oe], sv_g = allg_copy[text_hi];
+          efact[elen - oe] = '\0'; allg_copy[text_hi] = '\0';
+          for (char* occ = allg_copy + text_lo; (occ = strstr(occ, efact + os)) != NULL; ++occ) {
+            const size_t q = (size_t)(occ - allg_copy);
             const size_t i1s = allgstart + os, i1e = allgstart + q - 1;
             const size_t i2s = i1e + 1 + elen - os - oe, i2e = allgstart + allglen - oe - 1;
             const int t1 = ef_classify_intron(gen, (int)i1s, (int)i1e), t2 = ef_classify_intron(gen, (int)i2s, (int)i2e);
-            if (t1 != INTRON_ND && t2 != INTRON_ND) {
-              const size_t sl = elen - os - oe;
-              if (sl > max_len) { max_len = sl; ecut1 = estart + os; ecut2 = estart + os + sl; gcut1_1 = i1s; gcut1_2 = i1e + 1; gcut2_1 = i2s; gcut2_2 = i2e + 1; }
+            if (t1 != INTRON_ND && t2 != INTRON_ND && plen > max_len) {
+              max_len = plen; ecut1 = estart + os; ecut2 = estart + os + plen; gcut1_1 = i1s; gcut1_2 = i1e + 1; gcut2_1 = i2s; gcut2_2 = i2e + 1;
             }
           }
-          if (code < 0) { efact[elen - oe] = sv_e; allg[text_hi] = sv_g; }
+          efact[elen - oe] = sv_e; allg_copy[text_hi] = sv_g;
         }
       }
       if (max_len >= LB_SMALL_EXON) {
@@ -397,7 +445,7 @@ static void small_exon_between(ef_factor* p1, ef_factor* p2, ef_iter* it, const 
         p1->EST_end = (int)ecut1 - 1; p1->GEN_end = (int)gcut1_1 - 1;
         efi_insert_before(it, nw);
       }
-      free(efact); free(allg);
+      free(efact); free(allg_copy);
     }
   }
 }
@@ -445,9 +493,14 @@ static void clean_factorizations(const ef_seq* gen, ef_est* e, const ef_config* 
 void ef_refine_est_factorizations(const ef_seq* gen, ef_est* e, const ef_config* cfg, ef_backend* be) {
   remove_invalid(e->factorizations);
   ef_remove_duplicated_factorizations(e->factorizations);
+  ef_phase(EFP_REF_AFFIX);
   recover_affixes(gen, e, be);
+  ef_phase(EFP_REF_FALSE_SMALL);
   remove_false_small_exons(gen, e, be);
   ef_remove_duplicated_factorizations(e->factorizations);
+  ef_phase(EFP_REF_NEW_SMALL);
   search_new_small_exons(gen, e, cfg, be);
+  ef_phase(EFP_REF_CLEAN);
   clean_factorizations(gen, e, cfg, be);
+  ef_phase(EFP_FACTREF);
 }

@@ -339,7 +339,9 @@ int ef_main_multi(int argc, char** argv) {
     rank = atoi(getenv("PINTRON_RANK"));
     snprintf(id_path, sizeof id_path, "%s", getenv("PINTRON_COMM_FILE") ? getenv("PINTRON_COMM_FILE") : ".pintron-comm-id");
     prctl(PR_SET_PDEATHSIG, SIGKILL);                 /* no orphans inside a collective */
-    if (getppid() == 1) return 1;                     /* the parent was gone before the request took effect */
+    /* the parent was gone before the request took effect: it exported its own pid before it started us (a ppid
+     * of 1 says nothing -- est-fact may BE pid 1 of a container, and an orphan under a subreaper gets another) */
+    { const char* pp = getenv("PINTRON_PARENT_PID"); if (pp && atol(pp) > 0 && (long)getppid() != atol(pp)) return 1; }
   } else {
     snprintf(id_path, sizeof id_path, "%s/.pintron-comm-id-%ld", getenv("TMPDIR") ? getenv("TMPDIR") : "/tmp", (long)getpid());
     unlink(id_path);
@@ -360,6 +362,7 @@ int ef_main_multi(int argc, char** argv) {
       setenv("PINTRON_GPUS", wv, 1);
       setenv("PINTRON_COMM_FILE", id_path, 1);
       setenv("LOCAL_WORLD_SIZE", wv, 1);              /* the ranks share the host's cores (host_core_share) */
+      { char pv[32]; snprintf(pv, sizeof pv, "%ld", (long)getpid()); setenv("PINTRON_PARENT_PID", pv, 1); }
       kids = (pid_t*)calloc((size_t)world, sizeof(pid_t));
       for (int r = 1; r < world; ++r) {
         char rv[32];

@@ -126,6 +126,7 @@ typedef struct fiber {
   size_t unit;
   size_t cur_entry;          /* entry of the prepared list being factorized */
   int lane;
+  int phase;                 /* PINTRON_PROFILE: what the per-EST code is doing (estfact.h: EFP_*) */
   /* pending request */
   const ef_dp_req* reqs; ef_dp_res* ress; size_t nreq;   /* nreq independent DP requests */
   ef_dp_req req1; int rc;
@@ -266,6 +267,7 @@ typedef struct shared {
   /* output text of the units lives in large chunks owned by the step (freed together) */
   struct out_chunk* chunks;              /* under mu */
   struct out_chunk* spare_chunks;        /* chunks of the previous step, reused (their pages stay mapped) */
+  unsigned long long prof_cyc[EFP_N], prof_susp[EFP_N], prof_jobs[EFP_N];   /* PINTRON_PROFILE, summed over the workers (under mu) */
 } shared;
 
 typedef struct out_chunk { struct out_chunk* next; size_t cap, used; char data[]; } out_chunk;
@@ -308,6 +310,7 @@ static int fiber_dp_many(void* self, const ef_dp_req* reqs, ef_dp_res* res, size
   fiber* f = (fiber*)self;
   if (n == 0) return 0;
   f->reqs = reqs; f->ress = res; f->nreq = n; f->state = F_WAIT_DP;
+  if (ef_prof_on) { ef_prof.susp[f->phase]++; ef_prof.jobs[f->phase] += n; }
   if (EF_TSAN) tsan_to(f->w->tsan_sched);
   ctx_switch(&f->ctx, &f->w->sched);
   return f->rc;
@@ -390,14 +393,18 @@ static void fiber_main(void* arg) {
     f->cur_entry = k;
     ef_est* fe = ef_compute_est_fact(in->gen, in->list[k], &f->be, &in->cfg, &side);
     const bool aligned = !efl_empty(fe->factorizations);
+    ef_phase(EFP_OUTPUT);
     if (aligned) {
       ef_write_multifasta_output(in->gen, fe, &fs[0], in->cfg.retain_externals);
       ef_write_factorization_records(in->gen, fe, &fs[6], in->cfg.retain_externals, (uint32_t)f->unit);
       ef_write_single_est_info(&fs[1], fe->info);
     }
+    ef_phase(EFP_FREE);
     ef_est_free(fe);
+    ef_phase(EFP_OTHER);
     if (aligned) break;
   }
+  ef_phase(EFP_OUTPUT);
   for (int k = 0; k < EF_N_OUT; ++k) {
     u->len[k] = fs[k].len;
     u->buf[k] = fs[k].len ? out_alloc(f->w, fs[k].len) : NULL;
@@ -630,7 +637,9 @@ static int collect_dp(worker* w, lane* ln) {
   for (;;) {
     const uint32_t seen = __atomic_load_n(&w->wake, __ATOMIC_ACQUIRE);
     if (__atomic_load_n(&rq->done, __ATOMIC_ACQUIRE)) break;
+    ef_phase(EFP_SLEEP);
     worker_sleep(&w->wake, seen);
+    ef_phase(EFP_SCHED_COLLECT);
   }
   ln->posted = false;
   const int rc = rq->rc;
@@ -669,6 +678,7 @@ static void* worker_main(void* arg) {
     ln->inflight = (fiber**)malloc(per_lane * sizeof(fiber*));
     ef_jobbuf_init(&ln->jb);
   }
+  if (ef_prof_on) { memset(&ef_prof, 0, sizeof ef_prof); ef_prof.dummy = EFP_SCHED; ef_prof.last = ef_prof_now(); }
   bool more = true;
   int cursor = 0;
   const bool prefetch_on = !getenv("PINTRON_NO_FIBER_PREFETCH");
@@ -689,6 +699,7 @@ static void* worker_main(void* arg) {
        * (the wake word is read before the lanes are looked at again, so a completion in between is
        * not slept through) */
       const double tw = now_s();
+      ef_phase(EFP_SLEEP);
       for (;;) {
         const uint32_t seen = __atomic_load_n(&w->wake, __ATOMIC_ACQUIRE);
         for (int k = 0; k < n_lanes && li < 0; ++k) {
@@ -699,15 +710,19 @@ static void* worker_main(void* arg) {
         worker_sleep(&w->wake, seen);
       }
       w->stats.dp_s += now_s() - tw;
+      ef_phase(EFP_SCHED);
       if (li < 0) break;
     }
     if (li < 0) break;                   /* no fibres, no ESTs left, nothing in flight */
     cursor = (li + 1) % n_lanes;
     lane* ln = &w->lanes[li];
     double t0 = now_s();
+    ef_phase(EFP_SCHED_COLLECT);
     if (collect_dp(w, ln) != 0) { sh->failed = 1; break; }
     w->stats.dp_s += now_s() - t0;
+    ef_phase(EFP_SCHED_START);
     while (more && ln->n_fibers < per_lane) more = start_fiber(w, li);
+    ef_phase(EFP_SCHED);
     if (ln->n_fibers > 0) {
       /* run every runnable fibre of the lane until it blocks or ends (the batches of the other
        * lanes are on the GPU meanwhile) */
@@ -718,7 +733,12 @@ static void* worker_main(void* arg) {
          * caches.  While fibre i runs, the top of the stack of the one after the next (the frames of
          * the DP call it returns through) and its answers are fetched. */
         if (prefetch_on && i + 2 < ln->n_fibers) fiber_prefetch(ln->fibers[i + 2]);
-        if (f->state == F_RUNNABLE) { if (EF_TSAN) tsan_to(f->tsan); ctx_switch(&w->sched, &f->ctx); }
+        if (f->state == F_RUNNABLE) {
+          if (EF_TSAN) tsan_to(f->tsan);
+          if (ef_prof_on) { ef_phase(EFP_SCHED); ef_prof.cur = &f->phase; }
+          ctx_switch(&w->sched, &f->ctx);
+          if (ef_prof_on) { ef_phase(f->phase); ef_prof.cur = NULL; ef_prof.dummy = EFP_SCHED; }
+        }
       }
       size_t keep = 0;
       for (size_t i = 0; i < ln->n_fibers; ++i) {
@@ -738,7 +758,9 @@ static void* worker_main(void* arg) {
       int brc = submit_pairings(w, ln);
       w->stats.pairing_s += now_s() - t0;
       t0 = now_s();
+      ef_phase(EFP_SCHED_LAUNCH);
       if (brc == 0) brc = launch_dp(w, ln);
+      ef_phase(EFP_SCHED);
       w->stats.dp_s += now_s() - t0;
       if (brc != 0) { sh->failed = 1; break; }
     }
@@ -759,6 +781,12 @@ static void* worker_main(void* arg) {
     w->free_fibers = NULL;
   }
   ef_cell_release_all();
+  if (ef_prof_on) {
+    ef_phase(EFP_SCHED);
+    pthread_mutex_lock(&sh->mu);
+    for (int k = 0; k < EFP_N; ++k) { sh->prof_cyc[k] += ef_prof.cyc[k]; sh->prof_susp[k] += ef_prof.susp[k]; sh->prof_jobs[k] += ef_prof.jobs[k]; }
+    pthread_mutex_unlock(&sh->mu);
+  }
   return NULL;
 }
 
@@ -1254,7 +1282,23 @@ int ef_session_step(ef_session* s, ef_sched_stats* stats_out) {
   if (sv_started > 0)            /* a worker that cannot get a thread is simply not started: the others take its ESTs */
     for (size_t t = 0; t < s->nthreads; ++t) { ws[w_started].sh = sh; if (pthread_create(&th[w_started], NULL, worker_main, &ws[w_started]) == 0) ++w_started; }
   if (sv_started == 0 || w_started == 0) { fprintf(stderr, "* FATAL cannot start the service / worker threads\n"); sh->failed = 1; }
+  const unsigned long long prof_c0 = ef_prof_now(); const double prof_t0 = now_s();
+  memset(sh->prof_cyc, 0, sizeof sh->prof_cyc); memset(sh->prof_susp, 0, sizeof sh->prof_susp); memset(sh->prof_jobs, 0, sizeof sh->prof_jobs);
   for (size_t t = 0; t < w_started; ++t) pthread_join(th[t], NULL);
+  if (ef_prof_on && w_started) {
+    static const char* nm[EFP_N] = { "other", "meg", "embeddings", "endpoints", "external", "dust", "noisy", "add", "filters", "gap-errors",
+                                     "refine-intron", "tail/polyA", "refinement", "output", "side-files", "free", "scheduler", "sleep",
+                                     "ref:affixes", "ref:false-small", "ref:new-small", "ref:clean", "sched:launch", "sched:collect", "sched:start" };
+    const double hz = (double)(ef_prof_now() - prof_c0) / (now_s() - prof_t0);
+    unsigned long long ts = 0, tj = 0; double tot = 0;
+    fprintf(stderr, "* profile (per worker thread, %zu workers, %zu units): phase, seconds, suspensions / unit, jobs / unit\n", w_started, sh->n_units);
+    for (int k = 0; k < EFP_N; ++k) {
+      const double sec = (double)sh->prof_cyc[k] / hz / (double)w_started;
+      fprintf(stderr, "*   %-14s %8.4f s  %6.2f  %6.2f\n", nm[k], sec, (double)sh->prof_susp[k] / (double)sh->n_units, (double)sh->prof_jobs[k] / (double)sh->n_units);
+      ts += sh->prof_susp[k]; tj += sh->prof_jobs[k]; if (k != EFP_SLEEP) tot += sec;
+    }
+    fprintf(stderr, "*   %-14s %8.4f s  %6.2f  %6.2f\n", "all but sleep", tot, (double)ts / (double)sh->n_units, (double)tj / (double)sh->n_units);
+  }
   if (pre_started) pthread_join(s->pre_thread, NULL);
   pthread_mutex_lock(&sv->mu); sv->stop = true; pthread_cond_broadcast(&sv->posted); pthread_mutex_unlock(&sv->mu);
   for (int k = 0; k < sv_started; ++k) pthread_join(sv->threads[k].thread, NULL);
@@ -1350,7 +1394,8 @@ static void* write_pool_main(void* arg) {
       int first = 0;
       while (bytes) {                                   /* a short write continues where it stopped */
         const ssize_t w = pwritev(wt->fd, iov + first, n - first, at);
-        if (w < 0) { if (errno == EINTR) continue; __atomic_store_n(&wp->failed, 1, __ATOMIC_RELAXED); return NULL; }
+        if (w < 0 && errno == EINTR) continue;
+        if (w <= 0) { __atomic_store_n(&wp->failed, 1, __ATOMIC_RELAXED); return NULL; }   /* 0: quota / odd filesystem, never spin on it */
         at += w; bytes -= (size_t)w;
         size_t left = (size_t)w;
         while (left && first < n) {
@@ -1514,8 +1559,10 @@ static void session_release_pages(ef_session* s) {
   for (out_chunk* c = sh->chunks; c; c = c->next) ++cap;
   for (out_chunk* c = sh->spare_chunks; c; c = c->next) ++cap;
   void** ab = (void**)malloc(65536 * sizeof(void*)); size_t* al = (size_t*)malloc(65536 * sizeof(size_t));
+  if (!ab || !al) { free(ab); free(al); return; }
   const size_t na = ef_record_arena_regions(s->in.arena, ab, al, 65536);
   page_range* r = (page_range*)malloc((cap + na) * 16 * sizeof(page_range));
+  if (!r) { free(ab); free(al); return; }
   const size_t piece = (size_t)8 << 20, room = (cap + na) * 16;
 #define ADD_RANGE(ptr, bytes) do { \
     uintptr_t a_ = ((uintptr_t)(ptr) + 4095) & ~(uintptr_t)4095, b_ = ((uintptr_t)(ptr) + (bytes)) & ~(uintptr_t)4095; \

@@ -231,6 +231,35 @@ static inline void efw_int(ef_wbuf* w, long long v) {                     /* pri
   while (k) *w->p++ = t[--k];
 }
 
+/* ---- PINTRON_PROFILE=1: where the host time of the per-EST code goes -------------------------------
+ * The per-EST code marks the phase it is in (one store and, when profiling is on, one time-stamp
+ * read); the scheduler charges the cycles between two marks / suspensions of a fibre to the phase
+ * that was current, and counts the suspensions and DP jobs asked in each phase.  Per thread; the
+ * scheduler sums the threads of a step and prints the table (ef_sched.c). */
+enum { EFP_OTHER = 0, EFP_MEG, EFP_EMBED, EFP_ENDPOINTS, EFP_EXTERNAL, EFP_DUST, EFP_NOISY, EFP_ADD, EFP_FILTERS,
+       EFP_GAPERR, EFP_INTRON, EFP_TAIL, EFP_FACTREF, EFP_OUTPUT, EFP_SIDE, EFP_FREE, EFP_SCHED, EFP_SLEEP,
+       EFP_REF_AFFIX, EFP_REF_FALSE_SMALL, EFP_REF_NEW_SMALL, EFP_REF_CLEAN, EFP_SCHED_LAUNCH, EFP_SCHED_COLLECT, EFP_SCHED_START, EFP_N };
+extern int ef_prof_on;
+typedef struct { unsigned long long cyc[EFP_N], susp[EFP_N], jobs[EFP_N]; unsigned long long last; int dummy; int* cur; } ef_prof_state;
+extern _Thread_local ef_prof_state ef_prof;
+static inline unsigned long long ef_prof_now(void) {
+#if defined(__x86_64__)
+  unsigned lo, hi; __asm__ volatile("rdtsc" : "=a"(lo), "=d"(hi)); return ((unsigned long long)hi << 32) | lo;
+#else
+  return 0;
+#endif
+}
+/* enter phase `id`; returns the phase that was current (to go back to it) */
+static inline int ef_phase(int id) {
+  if (!ef_prof_on) return 0;
+  ef_prof_state* p = &ef_prof;
+  int* cur = p->cur ? p->cur : &p->dummy;
+  const unsigned long long t = ef_prof_now();
+  const int was = *cur;
+  p->cyc[was] += t - p->last; p->last = t; *cur = id;
+  return was;
+}
+
 /* ---- backend: where pairings and dynamic programs are computed ------------------------------ */
 /* DP request/response in the vocabulary of include/pintron_gpu.h (same kinds, same result slots) */
 enum { EF_DP_ALIGN = 0, EF_DP_GAP = 1, EF_DP_ED = 2, EF_DP_KBAND = 3, EF_DP_LCF = 4,
