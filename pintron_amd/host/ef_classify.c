@@ -155,12 +155,42 @@ static double score5(const char* gen, int splice5, int k) {           /* GetScor
  * Both are filled with the very functions the per-intron path calls, over ranges of positions on a
  * few threads. */
 typedef struct { ef_seq* gs; size_t lo, hi, n; } prep_range;
+
+/* the verdict of classify_genomic_intron_start_end's last lines (:209-228) for given scores */
+static inline unsigned cmp_bits(double u12, double u2) {
+  return (u12 > u2 ? 1u : 0u) | ((u12 - u2 > 0.25 && u12 >= 0.75) ? 2u : 0u);
+}
+enum { P5_GT = 1, P5_GC = 2, P5_AT = 3, P3_AG = 1, P3_AC = 2 };
+static inline int pair_is(const char* p, char a, char b) {       /* strcmp with "xy" or "XY" */
+  return (p[0] == a && p[1] == b) || (p[0] == (char)(a + 32) && p[1] == (char)(b + 32));
+}
+
 static void* prepare_range(void* arg) {
   prep_range* r = (prep_range*)arg;
   const char* gen = r->gs->seq;
   for (size_t e = r->lo; e < r->hi; ++e) {
     if (e >= 30) r->gs->bps_memo[e] = good_bps(gen + (e - 30), 30, 14, 30) != -1 ? 2 : 1;
-    for (int k = 0; k < 4; ++k) r->gs->score5_tab[k][e] = score5(gen, (int)e, 2 + k);
+    double sc[4];
+    for (int k = 0; k < 4; ++k) sc[k] = r->gs->score5_tab[k][e] = score5(gen, (int)e, 2 + k);
+    /* cls_start[e]: bits 0-1 the kind of gen[e], gen[e+1]; bits 2-3 cmp_bits of the scores that kind selects when
+     * the intron's end agrees (GT..AG, GC..AG, AT..AC); bits 4-5 cmp_bits of the general case */
+    unsigned char cs = 0;
+    if (e + 1 < r->n) {
+      const int kind = pair_is(gen + e, 'G', 'T') ? P5_GT : pair_is(gen + e, 'G', 'C') ? P5_GC : pair_is(gen + e, 'A', 'T') ? P5_AT : 0;
+      const double m23 = sc[1] > sc[0] ? sc[1] : sc[0];          /* u12 = s2, then "if (t > u12) u12 = t" with t = s3 */
+      const double m45 = sc[3] > sc[2] ? sc[3] : sc[2];
+      unsigned own = 0;
+      if (kind == P5_GT) own = cmp_bits(sc[0], sc[2]);
+      else if (kind == P5_GC) own = cmp_bits(m23, sc[3]);
+      else if (kind == P5_AT) own = cmp_bits(sc[1], m45);
+      cs = (unsigned char)((unsigned)kind | (own << 2) | (cmp_bits(m23, m45) << 4) | 0x80u);     /* bit 7: filled */
+    }
+    r->gs->cls_start[e] = cs;
+    /* cls_end[e] for an intron whose LAST character is gen[e]: bit 0-1 kind of gen[e-1], gen[e]; bit 2 branch
+     * point found (the verdict bps_memo keeps under e + 1, filled by the iteration of e + 1 or below) */
+    unsigned char ce = 0;
+    if (e >= 1 && e < r->n) ce = (unsigned char)((pair_is(gen + e - 1, 'A', 'G') ? P3_AG : pair_is(gen + e - 1, 'A', 'C') ? P3_AC : 0) | 0x80u);
+    r->gs->cls_end[e] = ce;
   }
   return NULL;
 }
@@ -170,6 +200,8 @@ void ef_classify_prepare(ef_seq* gs) {
   const size_t n = strlen(gs->seq);
   if (!gs->bps_memo) gs->bps_memo = (unsigned char*)calloc(n + 2, 1);
   for (int k = 0; k < 4; ++k) { free(gs->score5_tab[k]); gs->score5_tab[k] = (double*)malloc((n + 2) * sizeof(double)); }
+  free(gs->cls_start); free(gs->cls_end);
+  gs->cls_start = (unsigned char*)calloc(n + 2, 1); gs->cls_end = (unsigned char*)calloc(n + 2, 1);
   gs->score5_len = n + 1;
   enum { T = 8 };
   prep_range rg[T]; pthread_t th[T]; bool started[T];
@@ -179,6 +211,8 @@ void ef_classify_prepare(ef_seq* gs) {
     if (!started[t]) prepare_range(&rg[t]);
   }
   for (int t = 0; t < T; ++t) if (started[t]) pthread_join(th[t], NULL);
+  /* the branch-point verdict of the intron that ends ON e is kept under e + 1 */
+  for (size_t e = 0; e + 1 <= n; ++e) if (gs->bps_memo[e + 1] == 2) gs->cls_end[e] |= 4u;
 }
 
 static inline double score5_at(const ef_seq* gs, int start, int k) {
@@ -195,6 +229,18 @@ static int classify_uncached(const ef_seq* gs, int start, int end);
  * immutable for the whole run). */
 int ef_classify_intron(const ef_seq* gs, int start, int end) {
   const char* gen = gs->seq;
+  /* the common case from the two byte tables: an intron of at least 30 characters inside the sequence */
+  if (gs->cls_start && start >= 0 && end - start >= 29 && (size_t)end < gs->score5_len - 1) {
+    const unsigned cs = gs->cls_start[start], ce = gs->cls_end[end];
+    if ((cs & ce & 0x80u) != 0) {
+      const unsigned p5 = cs & 3u, p3 = ce & 3u;
+      const bool own = (p5 == P5_GT && p3 == P3_AG) || (p5 == P5_GC && p3 == P3_AG) || (p5 == P5_AT && p3 == P3_AC);
+      const unsigned bits = own ? (cs >> 2) & 3u : (cs >> 4) & 3u;
+      if (ce & 4u) return (bits & 1u) ? 0 : 1;                    /* branch point: u12 > u2 ? U12 : U2 */
+      if (own && p5 != P5_AT) return 1;                           /* GT..AG / GC..AG without one: U2 */
+      return (bits & 2u) ? 0 : 2;
+    }
+  }
   typedef struct { const char* gen; unsigned epoch; int start, end, type; } slot;
   static _Thread_local slot memo[1024];
   const unsigned ep = ef_genomic_epoch_now();       /* (address, epoch): see ef_genomic_len */

@@ -309,10 +309,12 @@ static void small_exon_between(ef_factor* p1, ef_factor* p2, ef_iter* it, const 
   const size_t sed = s_sed >= 0 ? (size_t)(uint32_t)r4[s_sed].v[0] : 0;
   const size_t ped = s_ped >= 0 ? (size_t)(uint32_t)r4[s_ped].v[0] : 0;
   bool go = false;
+  ef_phase(EFP_NS_BETWEEN_CLASS);
   const int orig_class = ef_classify_intron(gen, p1->GEN_end + 1, p2->GEN_start - 1);
   if (sed + ped > MAX_ERRORS_AS_SMALL) go = true;
   if (orig_class == INTRON_ND) go = true;
   if (go) {
+    ef_phase(EFP_NS_BETWEEN_SEARCH);
     size_t e1socc = 0, g1socc = 0, f1slen = e1slen;
     if (sed > 0) { const ef_dp_res r = r4[s_l1]; f1slen = (size_t)r.v[0]; e1socc = (size_t)r.v[1]; g1socc = (size_t)r.v[2]; }
     size_t e2pocc = 0, g2pocc = 0, f2plen = e2plen;
@@ -350,29 +352,57 @@ static void small_exon_between(ef_factor* p1, ef_factor* p2, ef_iter* it, const 
        * A pair whose pattern is not longer than the best found so far cannot replace it (strict
        * comparison at :820): such pairs -- all later offends of this offstart, and every later offstart
        * once elen - os itself is not longer -- are skipped. */
+      /* The index lookups of all offstarts are independent of each other and every one of them is a chain of
+       * cache misses (offset table, position list, the characters behind each occurrence): they are issued for
+       * all offstarts first, stage by stage with prefetches, and the decision loops below find the lists ready. */
+      ef_phase(EFP_TMP1);
+      enum { OS_MAX = 24, CAND_MAX = 12 };
+      int os_code[OS_MAX]; const uint32_t* os_all[OS_MAX]; uint32_t os_nall[OS_MAX], os_k[OS_MAX];
+      uint32_t os_q[OS_MAX][CAND_MAX], os_m[OS_MAX][CAND_MAX]; unsigned char os_nc[OS_MAX]; bool os_listed[OS_MAX];
+      const size_t n_os = max_offstart < OS_MAX ? max_offstart : OS_MAX;
+      for (size_t os = 0; os < n_os; ++os) {
+        os_code[os] = kmer_code(efact + os);
+        if (os_code[os] >= 0) __builtin_prefetch(&gen->kmer_first[os_code[os]], 0, 3);
+      }
+      for (size_t os = 0; os < n_os; ++os) {
+        if (os_code[os] < 0) continue;
+        os_all[os] = gen->kmer_pos + gen->kmer_first[os_code[os]];
+        os_nall[os] = gen->kmer_first[os_code[os] + 1] - gen->kmer_first[os_code[os]];
+        for (uint32_t b = 0; b < os_nall[os]; b += 16) __builtin_prefetch(os_all[os] + b, 0, 3);
+        if (os_nall[os]) __builtin_prefetch(os_all[os] + os_nall[os] - 1, 0, 3);
+      }
+      for (size_t os = 0; os < n_os; ++os) {
+        os_nc[os] = 0; os_listed[os] = false;
+        if (os_code[os] < 0) continue;
+        const uint32_t* all = os_all[os];
+        size_t k = lower_bound_u32(all, os_nall[os], (uint32_t)(allgstart + os + MIL));     /* text_lo of every offend */
+        os_listed[os] = true;
+        for (; k < os_nall[os]; ++k) {
+          const size_t qa = all[k];
+          if (qa >= allgstart + allglen) break;
+          if (os_nc[os] == CAND_MAX) { os_listed[os] = false; break; }
+          os_q[os][os_nc[os]++] = (uint32_t)(qa - allgstart);
+          __builtin_prefetch(allg + (qa - allgstart) + LB_SMALL_EXON, 0, 3);
+        }
+      }
+      for (size_t os = 0; os < n_os; ++os) {
+        if (!os_listed[os]) continue;
+        const size_t pmax = elen - os;                       /* the longest pattern of this offstart */
+        for (size_t c = 0; c < os_nc[os]; ++c) {
+          const size_t q = os_q[os][c];
+          size_t room = allglen - q; if (room > pmax) room = pmax;
+          size_t m = LB_SMALL_EXON;
+          while (m < room && allg[q + m] == efact[os + m]) ++m;
+          os_m[os][c] = (uint32_t)m;
+        }
+      }
+      ef_phase(EFP_TMP2);
       for (size_t os = 0; os < max_offstart && elen - os > max_len; ++os) {
         const size_t max_offend = zmin(zmin(f2plen + 1 - MIN_PERFECT_BORDER, elen + 1 - os - LB_SMALL_EXON), allglen + 1 - (2 * MIL) - LB_SMALL_EXON - os);
-        const int code = kmer_code(efact + os);
-        enum { CAND_MAX = 48 };
-        uint32_t cq[CAND_MAX], cm[CAND_MAX]; size_t nc = 0;       /* window-relative position, match length */
-        bool listed = false;
-        if (code >= 0) {                                       /* occurrences inside the window */
-          const uint32_t* all = gen->kmer_pos + gen->kmer_first[code];
-          const size_t nall = gen->kmer_first[code + 1] - gen->kmer_first[code];
-          size_t k = lower_bound_u32(all, nall, (uint32_t)(allgstart + os + MIL));     /* text_lo of every offend */
-          listed = true;
-          const size_t pmax = elen - os;                       /* the longest pattern of this offstart */
-          for (; k < nall; ++k) {
-            const size_t qa = all[k];
-            if (qa >= allgstart + allglen) break;
-            if (nc == CAND_MAX) { listed = false; break; }
-            const size_t q = qa - allgstart;
-            size_t room = allglen - q; if (room > pmax) room = pmax;
-            size_t m = LB_SMALL_EXON;
-            while (m < room && allg[q + m] == efact[os + m]) ++m;
-            cq[nc] = (uint32_t)q; cm[nc] = (uint32_t)m; ++nc;
-          }
-        }
+        const int code = os < n_os ? os_code[os] : kmer_code(efact + os);
+        const bool listed = os < n_os && os_listed[os];
+        const uint32_t* cq = os < n_os ? os_q[os] : NULL; const uint32_t* cm = os < n_os ? os_m[os] : NULL;
+        const size_t nc = listed ? os_nc[os] : 0;
         if (code >= 0 && !listed) {                            /* more occurrences than the table holds: as before, one by one */
           const uint32_t* all = gen->kmer_pos + gen->kmer_first[code];
           const size_t nall = gen->kmer_first[code + 1] - gen->kmer_first[code];
@@ -423,12 +453,38 @@ static void small_exon_between(ef_factor* p1, ef_factor* p2, ef_iter* it, const 
             }
             continue;
           }
-          /* strstr() over a terminated copy of the window */
-          if (!allg_copy) allg_copy = ef_real_substring((int)allgstart, (int)allglen, G);
-          const char sv_e = efact[elen - oe], sv_g = allg_copy[text_hi];
-          efact[elen - oe] = '\0'; allg_copy[text_hi] = '\0';
-          for (char* occ = allg_copy + text_lo; (occ = strstr(occ, efact + os)) != NULL; ++occ) {
-            const size_t q = (size_t)(occ - allg_copy);
+          /* The first six characters of the pattern hold a byte that is no upper-case A, C, G or T (an N of the
+           * EST, mostly): strstr() compares bytes, so the pattern can only occur where the genomic sequence has
+           * that very byte -- its positions are listed per byte value (gen->other_*), nearly always none.  (The
+           * reference's strstr() over the whole intron for each of these pairs was 4 us a call and most of this
+           * function's time.) */
+          if (plen > text_hi) continue;
+          size_t j = 0;
+          while (base2(efact[os + j]) >= 0) ++j;               /* < LB_SMALL_EXON: kmer_code said so */
+          if (!in_place || !gen->other_first) {                /* a window cut by the end of the sequence: as the reference does it */
+            if (!allg_copy) allg_copy = ef_real_substring((int)allgstart, (int)allglen, G);
+            const char sv_e = efact[elen - oe], sv_g = allg_copy[text_hi];
+            efact[elen - oe] = '\0'; allg_copy[text_hi] = '\0';
+            for (char* occ = allg_copy + text_lo; (occ = strstr(occ, efact + os)) != NULL; ++occ) {
+              const size_t q = (size_t)(occ - allg_copy);
+              const size_t i1s = allgstart + os, i1e = allgstart + q - 1;
+              const size_t i2s = i1e + 1 + elen - os - oe, i2e = allgstart + allglen - oe - 1;
+              const int t1 = ef_classify_intron(gen, (int)i1s, (int)i1e), t2 = ef_classify_intron(gen, (int)i2s, (int)i2e);
+              if (t1 != INTRON_ND && t2 != INTRON_ND && plen > max_len) {
+                max_len = plen; ecut1 = estart + os; ecut2 = estart + os + plen; gcut1_1 = i1s; gcut1_2 = i1e + 1; gcut2_1 = i2s; gcut2_2 = i2e + 1;
+              }
+            }
+            efact[elen - oe] = sv_e; allg_copy[text_hi] = sv_g;
+            continue;
+          }
+          const unsigned char bad = (unsigned char)efact[os + j];
+          if (bad == 0) continue;                              /* (a pattern cut by the end of the EST: strstr would look for less; not reached: elen is inside the EST) */
+          const uint32_t* ol = gen->other_pos + gen->other_first[bad];
+          const size_t nol = gen->other_first[bad + 1] - gen->other_first[bad];
+          for (size_t k = lower_bound_u32(ol, nol, (uint32_t)(allgstart + text_lo + j)); k < nol; ++k) {
+            const size_t q = ol[k] - j - allgstart;             /* window-relative start of the would-be occurrence */
+            if (q > text_hi - plen) break;
+            if (memcmp(allg + q, efact + os, plen) != 0) continue;
             const size_t i1s = allgstart + os, i1e = allgstart + q - 1;
             const size_t i2s = i1e + 1 + elen - os - oe, i2e = allgstart + allglen - oe - 1;
             const int t1 = ef_classify_intron(gen, (int)i1s, (int)i1e), t2 = ef_classify_intron(gen, (int)i2s, (int)i2e);
@@ -436,9 +492,9 @@ static void small_exon_between(ef_factor* p1, ef_factor* p2, ef_iter* it, const 
               max_len = plen; ecut1 = estart + os; ecut2 = estart + os + plen; gcut1_1 = i1s; gcut1_2 = i1e + 1; gcut2_1 = i2s; gcut2_2 = i2e + 1;
             }
           }
-          efact[elen - oe] = sv_e; allg_copy[text_hi] = sv_g;
         }
       }
+      ef_phase(EFP_TMP3);
       if (max_len >= LB_SMALL_EXON) {
         ef_factor* nw = factor_new((int)ecut1, (int)ecut2 - 1, (int)gcut1_2, (int)gcut2_1 - 1);
         p2->EST_start = (int)ecut2; p2->GEN_start = (int)gcut2_2;
@@ -459,11 +515,13 @@ static void search_new_small_exons(const ef_seq* gen, ef_est* e, const ef_config
     ef_iter fi = efl_begin(f);
     if (efi_has_next(&fi)) {
       p1 = (ef_factor*)efi_next(&fi);
-      if (p1->EST_start > LB_SMALL_EXON) small_exon_at_prefix(p1, &fi, gen, e, cfg, be);
+      if (p1->EST_start > LB_SMALL_EXON) { ef_phase(EFP_NS_PREFIX); small_exon_at_prefix(p1, &fi, gen, e, cfg, be); ef_phase(EFP_REF_NEW_SMALL); }
     }
     if (efi_has_next(&fi)) p2 = (ef_factor*)efi_next(&fi);
     while (p2 != NULL) {
+      ef_phase(EFP_NS_BETWEEN_ASK);
       small_exon_between(p1, p2, &fi, gen, e, cfg, be);
+      ef_phase(EFP_REF_NEW_SMALL);
       p1 = p2; p2 = NULL;
       if (efi_has_next(&fi)) p2 = (ef_factor*)efi_next(&fi);
     }

@@ -108,7 +108,9 @@ void ef_seq_free(ef_seq* s) {
   if (!s || s->in_arena) return;               /* an arena's records go with the arena */
   free(s->id); free(s->seq); free(s->original_seq); free(s->gb); free(s->chr);
   free(s->kmer_first); free(s->kmer_pos); free(s->bps_memo);
+  free(s->other_first); free(s->other_pos);
   for (int k = 0; k < 4; ++k) free(s->score5_tab[k]);
+  free(s->cls_start); free(s->cls_end);
   free(s);
 }
 
@@ -123,6 +125,17 @@ void ef_seq_index_kmers(ef_seq* gen) {
   gen->bps_memo = (unsigned char*)calloc(n + 2, 1);
   gen->kmer_first = (uint32_t*)calloc(4097, sizeof(uint32_t));
   gen->kmer_pos = (uint32_t*)malloc((n + 1) * sizeof(uint32_t));
+  {                                          /* the bytes that are no upper-case ACGT, by value */
+    free(gen->other_first); free(gen->other_pos);
+    gen->other_first = (uint32_t*)calloc(257, sizeof(uint32_t));
+    size_t n_other = 0;
+    for (size_t i = 0; i < n; ++i) if (kmer_base(gen->seq[i]) < 0) { ++gen->other_first[(unsigned char)gen->seq[i] + 1]; ++n_other; }
+    for (int c = 0; c < 256; ++c) gen->other_first[c + 1] += gen->other_first[c];
+    gen->other_pos = (uint32_t*)malloc((n_other + 1) * sizeof(uint32_t));
+    uint32_t fill[256];
+    memcpy(fill, gen->other_first, sizeof fill);
+    for (size_t i = 0; i < n; ++i) if (kmer_base(gen->seq[i]) < 0) gen->other_pos[fill[(unsigned char)gen->seq[i]]++] = (uint32_t)i;
+  }
   if (n < EF_KMER) return;
   const size_t nk = n - EF_KMER + 1;
   int* codes = (int*)malloc(nk * sizeof(int));

@@ -208,6 +208,7 @@ static inline void worker_sleep(uint32_t* wake, uint32_t seen) {
 }
 
 #define MAX_SERVICES 8
+#define EF_MAX_WORKERS 256
 typedef struct service_thread {          /* one submitter: own context (stream, device buffers) */
   pthread_t thread;
   struct service* sv;
@@ -264,6 +265,10 @@ typedef struct shared {
   /* fibres (256 KB stacks) are recycled: within a worker through its own free list, across steps
    * through this one (under mu) */
   fiber* fiber_pool;
+  /* ... and what a worker had at the end of a step is what worker of the same number starts the next step with:
+   * sixteen workers drawing their first thousand fibres one by one from the shared list queue up on its lock
+   * (13 - 20 ms of every warm step, PINTRON_PROFILE "sched:start") */
+  fiber* worker_pool[EF_MAX_WORKERS];
   /* output text of the units lives in large chunks owned by the step (freed together) */
   struct out_chunk* chunks;              /* under mu */
   struct out_chunk* spare_chunks;        /* chunks of the previous step, reused (their pages stay mapped) */
@@ -285,6 +290,7 @@ typedef struct lane {
 
 typedef struct worker {
   shared* sh;
+  size_t index;                          /* of this worker among the step's workers */
   ef_ctx sched;
   void* tsan_sched;          /* the worker thread's own context, for ThreadSanitizer */
   fiber* free_fibers;
@@ -429,16 +435,25 @@ static bool start_fiber(worker* w, int li) {
   if (sh->n_pre) {                             /* the pairings of this unit may still be on their way */
     const size_t last = sh->units[u].first + (sh->units[u].has_sibling ? 1 : 0);
     if (last >= __atomic_load_n(&sh->ready_entries, __ATOMIC_ACQUIRE)) {
+      const int was = ef_phase(EFP_WAIT_PREFETCH);
       pthread_mutex_lock(&sh->mu);
       while (last >= sh->ready_entries && !sh->failed) pthread_cond_wait(&sh->ready_cv, &sh->mu);
       pthread_mutex_unlock(&sh->mu);
+      ef_phase(was);
     }
   }
   if (__atomic_load_n(&sh->failed, __ATOMIC_RELAXED)) return false;
   if (f) w->free_fibers = f->pool_next;
   else if (__atomic_load_n(&sh->fiber_pool, __ATOMIC_RELAXED)) {
-    pthread_mutex_lock(&sh->mu);
-    if (sh->fiber_pool) { f = sh->fiber_pool; sh->fiber_pool = f->pool_next; f->pool_next = NULL; }
+    pthread_mutex_lock(&sh->mu);                 /* a few dozen at a time: the lock is shared by all workers */
+    if (sh->fiber_pool) {
+      f = sh->fiber_pool;
+      fiber* last = f;
+      for (int k = 0; k < 32 && last->pool_next; ++k) last = last->pool_next;
+      sh->fiber_pool = last->pool_next;
+      last->pool_next = NULL;
+      w->free_fibers = f->pool_next; f->pool_next = NULL;
+    }
     pthread_mutex_unlock(&sh->mu);
   }
   if (f) {                       /* recycled: keep the stack and the sink blocks */
@@ -679,6 +694,7 @@ static void* worker_main(void* arg) {
     ef_jobbuf_init(&ln->jb);
   }
   if (ef_prof_on) { memset(&ef_prof, 0, sizeof ef_prof); ef_prof.dummy = EFP_SCHED; ef_prof.last = ef_prof_now(); }
+  if (w->index < EF_MAX_WORKERS) { w->free_fibers = sh->worker_pool[w->index]; sh->worker_pool[w->index] = NULL; }
   bool more = true;
   int cursor = 0;
   const bool prefetch_on = !getenv("PINTRON_NO_FIBER_PREFETCH");
@@ -772,6 +788,7 @@ static void* worker_main(void* arg) {
     free(ln->fibers); free(ln->inflight);
   }
   if (w->ctx) pgpu_destroy(w->ctx);
+  if (w->free_fibers && w->index < EF_MAX_WORKERS) { sh->worker_pool[w->index] = w->free_fibers; w->free_fibers = NULL; }
   if (w->free_fibers) {
     fiber* last = w->free_fibers;
     while (last->pool_next) last = last->pool_next;
@@ -1124,6 +1141,15 @@ ef_session* ef_session_open(int argc, char** argv) {
   return s;
 }
 
+/* the workers' own fibre lists back into the shared one (before the session is taken apart or measured) */
+static void merge_worker_pools(shared* sh) {
+  for (size_t t = 0; t < EF_MAX_WORKERS; ++t) {
+    fiber* f = sh->worker_pool[t];
+    sh->worker_pool[t] = NULL;
+    while (f) { fiber* nx = f->pool_next; f->pool_next = sh->fiber_pool; sh->fiber_pool = f; f = nx; }
+  }
+}
+
 /* forget the previous step's output; its chunks are kept for the next step unless `release` */
 static void free_unit_buffers(shared* sh, bool release) {
   for (size_t u = 0; u < sh->n_units; ++u)
@@ -1280,7 +1306,7 @@ int ef_session_step(ef_session* s, ef_sched_stats* stats_out) {
   pthread_t* th = (pthread_t*)malloc(s->nthreads * sizeof(pthread_t));
   size_t w_started = 0;
   if (sv_started > 0)            /* a worker that cannot get a thread is simply not started: the others take its ESTs */
-    for (size_t t = 0; t < s->nthreads; ++t) { ws[w_started].sh = sh; if (pthread_create(&th[w_started], NULL, worker_main, &ws[w_started]) == 0) ++w_started; }
+    for (size_t t = 0; t < s->nthreads; ++t) { ws[w_started].sh = sh; ws[w_started].index = w_started; if (pthread_create(&th[w_started], NULL, worker_main, &ws[w_started]) == 0) ++w_started; }
   if (sv_started == 0 || w_started == 0) { fprintf(stderr, "* FATAL cannot start the service / worker threads\n"); sh->failed = 1; }
   const unsigned long long prof_c0 = ef_prof_now(); const double prof_t0 = now_s();
   memset(sh->prof_cyc, 0, sizeof sh->prof_cyc); memset(sh->prof_susp, 0, sizeof sh->prof_susp); memset(sh->prof_jobs, 0, sizeof sh->prof_jobs);
@@ -1288,16 +1314,17 @@ int ef_session_step(ef_session* s, ef_sched_stats* stats_out) {
   if (ef_prof_on && w_started) {
     static const char* nm[EFP_N] = { "other", "meg", "embeddings", "endpoints", "external", "dust", "noisy", "add", "filters", "gap-errors",
                                      "refine-intron", "tail/polyA", "refinement", "output", "side-files", "free", "scheduler", "sleep",
-                                     "ref:affixes", "ref:false-small", "ref:new-small", "ref:clean", "sched:launch", "sched:collect", "sched:start" };
+                                     "ref:affixes", "ref:false-small", "ref:new-small", "ref:clean", "sched:launch", "sched:collect", "sched:start", "wait:prefetch",
+                                     "new-small:prefix", "new-small:ask", "new-small:class", "new-small:search", "search:lookups", "search:decide", "search:end" };
     const double hz = (double)(ef_prof_now() - prof_c0) / (now_s() - prof_t0);
     unsigned long long ts = 0, tj = 0; double tot = 0;
     fprintf(stderr, "* profile (per worker thread, %zu workers, %zu units): phase, seconds, suspensions / unit, jobs / unit\n", w_started, sh->n_units);
     for (int k = 0; k < EFP_N; ++k) {
       const double sec = (double)sh->prof_cyc[k] / hz / (double)w_started;
       fprintf(stderr, "*   %-14s %8.4f s  %6.2f  %6.2f\n", nm[k], sec, (double)sh->prof_susp[k] / (double)sh->n_units, (double)sh->prof_jobs[k] / (double)sh->n_units);
-      ts += sh->prof_susp[k]; tj += sh->prof_jobs[k]; if (k != EFP_SLEEP) tot += sec;
+      ts += sh->prof_susp[k]; tj += sh->prof_jobs[k]; if (k != EFP_SLEEP && k != EFP_WAIT_PREFETCH) tot += sec;
     }
-    fprintf(stderr, "*   %-14s %8.4f s  %6.2f  %6.2f\n", "all but sleep", tot, (double)ts / (double)sh->n_units, (double)tj / (double)sh->n_units);
+    fprintf(stderr, "*   %-14s %8.4f s  %6.2f  %6.2f\n", "all but sleeps", tot, (double)ts / (double)sh->n_units, (double)tj / (double)sh->n_units);
   }
   if (pre_started) pthread_join(s->pre_thread, NULL);
   pthread_mutex_lock(&sv->mu); sv->stop = true; pthread_cond_broadcast(&sv->posted); pthread_mutex_unlock(&sv->mu);
@@ -1499,6 +1526,7 @@ void ef_session_close(ef_session* s) {
   for (int t = 0; t < s->n_pool_threads; ++t) pthread_join(s->pool_thread[t], NULL);
   s->n_pool_threads = 0;
   free_unit_buffers(sh, true);
+  merge_worker_pools(sh);
   if (getenv("PINTRON_STACK_STATS")) {      /* how deep did the fibres' stacks get? (first byte written above the sentinel) */
     size_t n = 0, sum = 0, mx = 0;
     for (fiber* f = sh->fiber_pool; f; f = f->pool_next) {
@@ -1554,6 +1582,7 @@ static void* page_release_main(void* arg) {
 }
 static void session_release_pages(ef_session* s) {
   shared* sh = &s->sh;
+  merge_worker_pools(sh);
   size_t cap = 1024, n = 0;
   for (fiber* f = sh->fiber_pool; f; f = f->pool_next) ++cap;
   for (out_chunk* c = sh->chunks; c; c = c->next) ++cap;

@@ -63,6 +63,10 @@ typedef struct {
    * (12 bits), ascending inside a group; built once by ef_seq_index_kmers */
   uint32_t* kmer_first;   /* 4097 offsets into kmer_pos */
   uint32_t* kmer_pos;
+  /* genomic only: the positions of every byte of seq that is not an upper-case A, C, G or T, grouped by byte
+   * value, ascending inside a group (a pattern that holds such a byte can only occur where the sequence has it) */
+  uint32_t* other_first;  /* 257 offsets into other_pos */
+  uint32_t* other_pos;
   /* genomic only: branch-point verdict of classify-intron per intron END position, filled on
    * demand (0 = not computed yet, 1 = no branch point, 2 = branch point found) */
   unsigned char* bps_memo;
@@ -70,6 +74,11 @@ typedef struct {
    * (classify-intron's GetScoreOf5Prime*BySS), filled once by ef_classify_prepare */
   double* score5_tab[4];
   size_t score5_len;
+  /* genomic only: what classify-intron decides from the scores, per intron START (cls_start: the first two
+   * characters' kind and, for the matrices that kind selects and for the general case, the two score
+   * comparisons) and per intron END (cls_end: branch point found, last two characters' kind) -- two bytes
+   * looked up per candidate intron instead of five doubles from four tables (ef_classify.c) */
+  unsigned char* cls_start; unsigned char* cls_end;
   unsigned char in_arena;   /* the record and its strings lie in a record arena (ef_record_arena): ef_seq_free leaves them */
 } ef_seq;
 
@@ -238,7 +247,8 @@ static inline void efw_int(ef_wbuf* w, long long v) {                     /* pri
  * scheduler sums the threads of a step and prints the table (ef_sched.c). */
 enum { EFP_OTHER = 0, EFP_MEG, EFP_EMBED, EFP_ENDPOINTS, EFP_EXTERNAL, EFP_DUST, EFP_NOISY, EFP_ADD, EFP_FILTERS,
        EFP_GAPERR, EFP_INTRON, EFP_TAIL, EFP_FACTREF, EFP_OUTPUT, EFP_SIDE, EFP_FREE, EFP_SCHED, EFP_SLEEP,
-       EFP_REF_AFFIX, EFP_REF_FALSE_SMALL, EFP_REF_NEW_SMALL, EFP_REF_CLEAN, EFP_SCHED_LAUNCH, EFP_SCHED_COLLECT, EFP_SCHED_START, EFP_N };
+       EFP_REF_AFFIX, EFP_REF_FALSE_SMALL, EFP_REF_NEW_SMALL, EFP_REF_CLEAN, EFP_SCHED_LAUNCH, EFP_SCHED_COLLECT, EFP_SCHED_START, EFP_WAIT_PREFETCH,
+       EFP_NS_PREFIX, EFP_NS_BETWEEN_ASK, EFP_NS_BETWEEN_CLASS, EFP_NS_BETWEEN_SEARCH, EFP_TMP1, EFP_TMP2, EFP_TMP3, EFP_N };
 extern int ef_prof_on;
 typedef struct { unsigned long long cyc[EFP_N], susp[EFP_N], jobs[EFP_N]; unsigned long long last; int dummy; int* cur; } ef_prof_state;
 extern _Thread_local ef_prof_state ef_prof;

@@ -185,6 +185,85 @@ def make_long_transcripts(seed=77):
     return g, e
 
 
+def make_small_exons(seed=11, n_est=240):
+    """Genes with exons of 8 - 22 bases between long ones, Ns in the ESTs AND in the genomic sequence (some of them
+    inside a small exon and at the same place in the ESTs), soft-masked (lower-case) stretches in the introns:
+    what search_for_new_small_exons / remove_false_small_exons (src/factorization-refinement.c:641-1125) look at,
+    including the patterns with a byte that is no upper-case ACGT.  Returns (genomic_fasta_text, ests_fasta_text)."""
+    import random
+    rng = random.Random(seed)
+
+    def rs(n):
+        return "".join(rng.choice("ACGT") for _ in range(n))
+
+    def mut(s, rate, n_rate):
+        out = []
+        for c in s:
+            x = rng.random()
+            if c == "N":
+                out.append(c)
+            elif x < n_rate:
+                out.append("N")
+            elif x < n_rate + rate * 0.6:
+                out.append(rng.choice("ACGT"))
+            elif x < n_rate + rate * 0.8:
+                pass
+            elif x < n_rate + rate:
+                out.append(c)
+                out.append(rng.choice("ACGT"))
+            else:
+                out.append(c)
+        return "".join(out)
+
+    def intron(n):
+        body = rs(n)
+        if rng.random() < 0.5:                       # a soft-masked repeat and a few Ns inside
+            a = rng.randint(0, n // 2)
+            body = body[:a] + body[a:a + n // 4].lower() + body[a + n // 4:]
+        if rng.random() < 0.5:
+            a = rng.randint(0, n - 10)
+            body = body[:a] + "NNN" + body[a + 3:]
+        return ("GC" if rng.random() < 0.1 else "GT") + body + "AG"
+
+    gen = rs(1500)
+    transcripts = []
+    for _gene in range(4):
+        exons = []
+        for k in range(5):
+            if k in (1, 3):
+                x = rs(rng.randint(8, 22))
+                if rng.random() < 0.5:                # an N of the sequence inside the small exon
+                    a = rng.randint(2, len(x) - 3)
+                    x = x[:a] + "N" + x[a + 1:]
+            else:
+                x = rs(rng.randint(120, 260))
+            exons.append(x)
+        tr = ""
+        for k, x in enumerate(exons):
+            gen += x
+            tr += x
+            if k + 1 < len(exons):
+                gen += intron(rng.randint(300, 2500))
+        gen += rs(800)
+        transcripts.append(tr)
+    ests = []
+    for i in range(n_est):
+        tr = transcripts[i % len(transcripts)]
+        a = rng.randint(0, max(0, len(tr) - 450))
+        piece = tr[a:a + rng.randint(300, 600)]
+        x = mut(piece, rng.choice((0.0, 0.01, 0.03, 0.05)), rng.choice((0.0, 0.002, 0.01)))
+        if rng.random() < 0.4:
+            x = str(_rc_text(x))
+        ests.append(x)
+    g = ">chrS:1:%d:+1\n%s\n" % (len(gen), gen)
+    e = "".join(">/gb=SMX%04d /clone_end=3'\n%s\n" % (i, x) for i, x in enumerate(ests))
+    return g, e
+
+
+def _rc_text(s):
+    return s[::-1].translate(str.maketrans("ACGTacgtN", "TGCAtgcaN"))
+
+
 def make_region_start_repeats(seed=5):
     """Transcripts that begin with the very first bases of the genomic region (pairings with t == 0,
     the occurrence without a preceding character: DESIGN.md section 4b), and repeats of those first

@@ -67,6 +67,26 @@ def test_synthetic_sample_matches_compiled_reference(bins, tmp_path):
 
 
 @pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("seed", [12, 13, 16])   # seeds whose inputs reach every branch (occurrences found through the other-byte index too)
+def test_small_exons_and_non_acgt_bytes_match_compiled_reference(bins, tmp_path, seed):
+    """search_for_new_small_exons / remove_false_small_exons (src/factorization-refinement.c:641-1125) on genes that
+    have small exons, with Ns in ESTs and genomic sequence and lower-case stretches: the 6-mer index, the index of
+    the other bytes and the classification tables against the reference's strstr() / matrices."""
+    from pintron_amd import synth
+    g, e = synth.make_small_exons(seed)
+    ref_dir, my_dir = tmp_path / "ref", tmp_path / "mine"
+    for d in (ref_dir, my_dir):
+        d.mkdir()
+        (d / "genomic.txt").write_text(g)
+        (d / "ests.txt").write_text(e)
+    subprocess.run([os.path.join(O.REF_DIR, "est-fact-core")], cwd=ref_dir, check=True, stderr=subprocess.DEVNULL)
+    run(bins["estfact_sched_check"], my_dir, {"PINTRON_THREADS": "3"})
+    for f in FILES:
+        assert filecmp.cmp(my_dir / f, ref_dir / f, shallow=False), f
+    assert os.path.getsize(my_dir / "raw-multifasta-out.txt") > 10000
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
 def test_long_transcripts_match_compiled_reference(bins, tmp_path):
     """Exons of several kb (full-length mRNAs): the host logic has no size limits of its own."""
     from pintron_amd import synth
