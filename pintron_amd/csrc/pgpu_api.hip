@@ -52,6 +52,7 @@ struct pgpu_ctx {
   hipEvent_t ev_wait = nullptr;      // pgpu_ctx_wait (pairing / MEG stages)
   long wait_poll_us = 20;
   bool align_coop = true;    // ALIGN with 65 .. 4096 rows on four waves (PGPU_ALIGN_COOP=0: one wave, as before)
+  bool align_band = true;    // ALIGN above 64 rows: inside a band on one wave first (PGPU_ALIGN_BAND=0: always the whole matrix)
   bool lcf_sa = true;        // longest common factors of genomic prefixes from the suffix array (PGPU_LCF_SA=0: always the DP kernel)
   int poison = -1;           // PGPU_POISON=<0..255>: fill strings + workspace of every DP plan with that byte first
   // pinned staging for the device->host result copies (pageable copies block and spin inside HIP)
@@ -258,6 +259,7 @@ extern "C" int pgpu_init(int device, pgpu_ctx** out) {
   { const char* f = getenv("PGPU_WAIT"); if (f) ctx->wait_poll_us = atol(f); }
   { const char* f = getenv("PGPU_ALIGN_COOP"); if (f && f[0] == '0') ctx->align_coop = false; }
   { const char* f = getenv("PGPU_LCF_SA"); if (f && f[0] == '0') ctx->lcf_sa = false; }
+  { const char* f = getenv("PGPU_ALIGN_BAND"); if (f && f[0] == '0') ctx->align_band = false; }
   { const char* f = getenv("PGPU_POISON"); if (f && f[0]) ctx->poison = atoi(f) & 255; }
   { const char* f = getenv("PGPU_PACK"); if (f && atoi(f) == 0) ctx->packed = false; }
   { const char* f = getenv("PGPU_MERGED"); if (f && atoi(f) >= 0 && atoi(f) <= 2) ctx->merged = atoi(f); }
@@ -430,7 +432,9 @@ extern "C" int pgpu_dp_plan_create_parts(pgpu_ctx* ctx, const pgpu_index* idx, c
     switch (in.kind) {
       case PGPU_DP_ALIGN:
         if (la > PGPU_MAX_ROWS_LEV || lb > PGPU_MAX_COLS) continue;
-        k.family = KF_ALIGN; k.R = row_class(la); k.size = (uint64_t)la * lb; break;
+        k.family = KF_ALIGN; k.R = row_class(la); k.size = (uint64_t)la * lb;
+        k.j.tail = ctx->align_band ? 1u : 0u;          /* (ALIGN has no tail: the kernel's switch for the banded attempt) */
+        break;
       case PGPU_DP_GAP:
         if (lb > PGPU_MAX_GAP_SIDE || la > PGPU_MAX_GAP_SIDE || ((uint64_t)la + 1) * ((uint64_t)lb + 1) > PGPU_MAX_GAP_CELLS) continue;
         // beyond 2048 rows: the anti-diagonal kernel over HBM (slow, but the reference computes these too)

@@ -1155,6 +1155,140 @@ __device__ __forceinline__ void align_traceback_coop(const DevJob& job, DevResul
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// ComputeAlignMatrix + TracebackAlignment (src/compute-alignments.c:85-207) inside a BAND, on one wave.
+// An exon and its stretch of the genomic sequence differ by a few per cent, so the alignment lies next to
+// the main diagonal.  Lane s owns the diagonal column - row = s - k (k = ALIGN_BAND_K, 2k+1 <= 64) and the
+// wave walks down the rows exactly as kband_band_sweep does (lane s takes row r at time 2r + s; diagonal =
+// its own previous value, up = the right neighbour's previous row, left = the left neighbour's same row),
+// with the N wildcard and the reference's preference diagonal < up < left recorded per cell.
+// Why the answer is the full matrix's: M[i][j] >= |i - j|, so a cell whose true value is <= k lies inside
+// the band together with every optimal path that ends in it -- its banded value is the true one; a cell
+// with a true value > k gets a banded value >= the true one, hence > k.  If the banded M[n][m] is <= k it
+// is the true score, every cell of the reference's traceback has a value <= the score, and at such a cell
+// the candidates that reach the minimum have true (= banded) neighbour values, all others are larger in
+// both matrices (a neighbour outside the band is worth >= k + 1): the same first minimum in the order
+// diagonal, up, left, i.e. the same direction.  A banded score > k says nothing: the caller sweeps the
+// whole matrix.  Directions: 2 bits per cell, one 32-bit word per lane and 16 rows, [row / 16][lane].
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t ALIGN_BAND_K = 31u;
+__device__ __forceinline__ bool align_band_fits(uint32_t n, uint32_t m) {
+  return n > 0u && m > 0u && (n > m ? n - m : m - n) <= ALIGN_BAND_K;
+}
+
+// returns the banded M[n][m] in every lane; dirs: ((n >> 4) + 1) * 64 words
+__device__ __noinline__ uint32_t align_band_sweep(const uint8_t* __restrict__ a, const uint32_t n,
+                                                  const uint8_t* __restrict__ b, const uint32_t m,
+                                                  const uint32_t lane, uint32_t* __restrict__ dirs) {
+  constexpr uint32_t k = ALIGN_BAND_K, W = 2u * k + 1u;
+  const bool used = lane < W;
+  const bool odd = (lane & 1u) != 0u;
+  const int off = (int)lane - (int)k;            // column - row on this lane's diagonal
+  const uint32_t half = lane >> 1;               // iteration q works on row r = q - half
+  const uint32_t up_mask = (lane + 1u < W) ? 0u : BAND_INF, left_mask = lane > 0u ? 0u : BAND_INF;
+  uint32_t val = (uint32_t)(off < 0 ? -off : off);
+  // rows of this lane: 1 <= r <= n with 1 <= r + off <= m
+  const uint32_t r_lo = off < 0 ? (uint32_t)(1 - off) : 1u;
+  const int hi_i = (int)m - off < (int)n ? (int)m - off : (int)n;
+  const bool any_row = used && hi_i >= (int)r_lo;
+  const uint32_t span = any_row ? (uint32_t)hi_i - r_lo : 0xFFFFFFFFu;   // r - r_lo <= span: active
+  const uint32_t nq = n + k;                     // lane 2k takes row n in iteration n + k
+  auto row_char = [&](uint32_t q) -> uint32_t {
+    const uint32_t r = q - half;
+    return (any_row && r - r_lo <= span) ? (uint32_t)a[r - 1u] : 0u;
+  };
+  auto col_char = [&](uint32_t q) -> uint32_t {
+    const uint32_t r = q - half;
+    return (any_row && r - r_lo <= span) ? (uint32_t)b[(uint32_t)(off + (int)r) - 1u] : 1u;
+  };
+  uint32_t dw = 0u;                              // directions of the rows of the current group of 16
+  uint32_t ca[4], cb[4], can[4], cbn[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { ca[j] = row_char(1u + j); cb[j] = col_char(1u + j); }
+  for (uint32_t q0 = 1; q0 <= nq; q0 += 4) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { can[j] = row_char(q0 + 4u + j); cbn[j] = col_char(q0 + 4u + j); }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t r = q0 + j - half;          // wraps for the lanes whose first row lies ahead
+      const bool active = any_row && (r - r_lo <= span);
+      const uint32_t mism = (ca[j] == cb[j] || is_n(ca[j]) || is_n(cb[j])) ? 0u : 1u;
+#pragma unroll
+      for (int par = 0; par < 2; ++par) {
+        const uint32_t upv = (wave_shl1(val) | up_mask) + 1u, leftv = (wave_shr1(val) | left_mask) + 1u;
+        uint32_t nv = val + mism, d = 0u;
+        if (nv > upv) { nv = upv; d = 1u; }
+        if (nv > leftv) { nv = leftv; d = 2u; }
+        const bool mine = active && odd == (par == 1);
+        val = mine ? nv : val;
+        dw |= mine ? d << (2u * (r & 15u)) : 0u;
+      }
+      // the word of rows 16 g .. 16 g + 15 is complete after row 16 g + 15, or after the lane's last row
+      if (active && ((r & 15u) == 15u || r - r_lo == span)) { dirs[(r >> 4) * 64u + lane] = dw; dw = 0u; }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { ca[j] = can[j]; cb[j] = cbn[j]; }
+  }
+  return (uint32_t)__shfl((int)val, (int)(m + k - n));
+}
+
+// the traceback over the band's directions (same walk, same output as align_traceback_wave)
+__device__ __forceinline__ void align_band_traceback(const DevJob& job, DevResult* res, const uint32_t* __restrict__ dirs,
+                                                     uint8_t* __restrict__ strs, const uint32_t lane,
+                                                     uint8_t* win, uint8_t* path) {
+  constexpr uint32_t k0 = ALIGN_BAND_K;
+  const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)job.la), m = (uint32_t)__builtin_amdgcn_readfirstlane((int)job.lb), cap = n + m + 1;
+  uint8_t* ea = strs + job.str_off;
+  uint8_t* ga = ea + cap;
+  constexpr uint32_t WB = TB_WIN_BYTES / 256u;             // groups of 16 rows per window
+  const uint32_t* w32 = reinterpret_cast<const uint32_t*>(win);
+  uint32_t i = n, j = m, k = 0, np = 0;
+  uint32_t i0 = n, j0 = m, pos = cap - 1;
+  if (lane == 0) { ea[pos] = 0; ga[pos] = 0; }
+  uint32_t g_lo = 1u, g_hi = 0u;                           // empty window (groups of 16 rows)
+  while (i > 0 && j > 0) {
+    const uint32_t g = i >> 4;
+    if (g < g_lo || g > g_hi) {                            // bring in the groups (g - WB, g]
+      g_hi = g; g_lo = g + 1 >= WB ? g + 1 - WB : 0;
+      const uint32_t bytes = (g_hi - g_lo + 1) * 256u;
+      const uint8_t* src = reinterpret_cast<const uint8_t*>(dirs) + (size_t)g_lo * 256u;
+      for (uint32_t off = lane * 16u; off < bytes; off += 64u * 16u)
+        *reinterpret_cast<uint4*>(win + off) = *reinterpret_cast<const uint4*>(src + off);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    uint32_t d = (w32[(g - g_lo) * 64u + (j + k0 - i)] >> (2u * (i & 15u))) & 3u;
+    d = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);  // the walk is wave-uniform: keep it scalar
+    path[np] = (uint8_t)d;
+    ++np;
+    i -= d < 2u ? 1u : 0u;                                 // 0: diagonal, 1: up, 2: left
+    j -= d != 1u ? 1u : 0u;
+    if (np == TB_PATH) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      tb_flush(path, np, job.a, job.b, i0, j0, pos, ea, ga, lane);
+      pos -= np; k += np; np = 0; i0 = i; j0 = j;
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  tb_flush(path, np, job.a, job.b, i0, j0, pos, ea, ga, lane);
+  pos -= np; k += np;
+  for (uint32_t q = lane; q < i; q += 64) { ea[pos - 1 - q] = job.a[i - 1 - q]; ga[pos - 1 - q] = '-'; }
+  pos -= i; k += i;
+  for (uint32_t q = lane; q < j; q += 64) { ea[pos - 1 - q] = '-'; ga[pos - 1 - q] = job.b[j - 1 - q]; }
+  pos -= j; k += j;
+  if (lane == 0) {
+    res->v[1] = (int32_t)k;
+    res->str[0] = job.str_off + pos;
+    res->str[1] = job.str_off + cap + pos;
+  }
+}
+
 // one job on the first four waves of a workgroup; smem: hand-off (3 x 128 words), then the traceback's
 // window (TB_WIN_BYTES, 16-aligned) and path (TB_PATH)
 constexpr size_t ALIGN_COOP_LDS = (COOP_W - 1) * 128 * sizeof(uint32_t) + TB_WIN_BYTES + TB_PATH;
@@ -1176,6 +1310,24 @@ __device__ __forceinline__ void align_coop_body(const DevJob& job, DevResult* re
     own_stores_visible();
     align_traceback_wave(job, res, ws, strs, lane, win, path);      // its identity branch
     return;
+  }
+  // first inside a band on wave 0 (job.tail: the host's switch); the other waves wait for its verdict
+  if (job.tail != 0u && align_band_fits(n, m)) {
+    uint32_t* bdirs = reinterpret_cast<uint32_t*>(ws + job.ws_off);
+    if (w == 0) {
+      const uint32_t score = align_band_sweep(job.a, n, job.b, m, lane, bdirs);
+      if (lane == 0) hand[0] = score;
+    }
+    __syncthreads();
+    const uint32_t score = hand[0];
+    __syncthreads();                     // (hand is the sweep's hand-off buffer below)
+    if (score <= ALIGN_BAND_K) {
+      if (w != 0) return;
+      if (lane == 0) { res->status = 0; res->v[0] = (int32_t)score; res->v[5] = 0; }
+      own_stores_visible();
+      align_band_traceback(job, res, bdirs, strs, lane, win, path);
+      return;
+    }
   }
   uint32_t cur[R], minv[R], minpos[R];
   AffixBest best = AFFIX_NONE;

@@ -273,6 +273,7 @@ typedef struct shared {
   struct out_chunk* chunks;              /* under mu */
   struct out_chunk* spare_chunks;        /* chunks of the previous step, reused (their pages stay mapped) */
   unsigned long long prof_cyc[EFP_N], prof_susp[EFP_N], prof_jobs[EFP_N];   /* PINTRON_PROFILE, summed over the workers (under mu) */
+  double prof_t0; double prof_sleep_bins[64];      /* when in the step the workers slept (5 ms bins, seconds summed over the workers) */
 } shared;
 
 typedef struct out_chunk { struct out_chunk* next; size_t cap, used; char data[]; } out_chunk;
@@ -291,6 +292,7 @@ typedef struct lane {
 typedef struct worker {
   shared* sh;
   size_t index;                          /* of this worker among the step's workers */
+  double sleep_bins[64];
   ef_ctx sched;
   void* tsan_sched;          /* the worker thread's own context, for ThreadSanitizer */
   fiber* free_fibers;
@@ -726,6 +728,11 @@ static void* worker_main(void* arg) {
         worker_sleep(&w->wake, seen);
       }
       w->stats.dp_s += now_s() - tw;
+      if (ef_prof_on) {
+        const double t1 = now_s();
+        int b = (int)((tw - sh->prof_t0) / 0.005); if (b < 0) b = 0; if (b > 63) b = 63;
+        w->sleep_bins[b] += t1 - tw;
+      }
       ef_phase(EFP_SCHED);
       if (li < 0) break;
     }
@@ -802,6 +809,7 @@ static void* worker_main(void* arg) {
     ef_phase(EFP_SCHED);
     pthread_mutex_lock(&sh->mu);
     for (int k = 0; k < EFP_N; ++k) { sh->prof_cyc[k] += ef_prof.cyc[k]; sh->prof_susp[k] += ef_prof.susp[k]; sh->prof_jobs[k] += ef_prof.jobs[k]; }
+    for (int k = 0; k < 64; ++k) sh->prof_sleep_bins[k] += w->sleep_bins[k];
     pthread_mutex_unlock(&sh->mu);
   }
   return NULL;
@@ -1104,9 +1112,35 @@ ef_session* ef_session_open(int argc, char** argv) {
     size_t want = env_size("PINTRON_PRE_CHUNKS", 10);
     if (want > PRE_CHUNKS) want = PRE_CHUNKS;
     sh->n_pre = sh->n_units < want ? (int)sh->n_units : (int)want;
+    /* PINTRON_PRE_RAMP="w0,w1,...": relative sizes of the ranges (their number then follows from the list).  The
+     * workers can only start once the first range is back, so it is small, and every later one is larger than the
+     * one before by about what the prefetch stage is faster than the workers. */
+    double wts[PRE_CHUNKS]; int nw = 0;
+    const char* ramp = getenv("PINTRON_PRE_RAMP");
+    if (ramp && ramp[0]) {
+      for (const char* q = ramp; *q && nw < PRE_CHUNKS;) {
+        char* end = NULL;
+        const double v = strtod(q, &end);
+        if (end == q) break;
+        if (v > 0) wts[nw++] = v;
+        if (*end != ',' && *end != ':') break;
+        q = end + 1;
+      }
+    }
+    if (nw > 0 && (size_t)nw <= sh->n_units) sh->n_pre = nw;
+    else { nw = sh->n_pre; for (int k = 0; k < nw; ++k) wts[k] = 1.0; }
+    double tot = 0, acc = 0;
+    for (int k = 0; k < nw; ++k) tot += wts[k];
     for (int cidx = 0; cidx <= sh->n_pre; ++cidx) {
-      const size_t u = sh->n_units * (size_t)cidx / (size_t)sh->n_pre;
+      size_t u = cidx == sh->n_pre ? sh->n_units : (size_t)((double)sh->n_units * (acc / tot));
+      if (cidx > 0 && cidx < sh->n_pre) {                      /* never an empty range */
+        size_t prev_u = 0;
+        while (prev_u < sh->n_units && sh->units[prev_u].first < sh->pre_lo[cidx - 1]) ++prev_u;
+        if (u <= prev_u) u = prev_u + 1;
+      }
+      if (u > sh->n_units) u = sh->n_units;
       sh->pre_lo[cidx] = u < sh->n_units ? sh->units[u].first : in->n;
+      if (cidx < sh->n_pre) acc += wts[cidx];
     }
   }
   sh->svc.n_threads = boot.n_svc;
@@ -1284,6 +1318,7 @@ int ef_session_step(ef_session* s, ef_sched_stats* stats_out) {
   free_unit_buffers(sh, false);
   for (int c = 0; c < PRE_CHUNKS; ++c) { free(sh->pre_tri[c]); free(sh->pre_first[c]); sh->pre_tri[c] = NULL; sh->pre_first[c] = NULL; }
   sh->next_unit = 0; sh->failed = 0; sh->ready_entries = 0;
+  sh->prof_t0 = t0; memset(sh->prof_sleep_bins, 0, sizeof sh->prof_sleep_bins);
   memset(s->pre_kernel_ms, 0, sizeof s->pre_kernel_ms);
   s->pre_meg_ms = 0;
   s->pre_t0 = t0; s->pre_wall = 0;
@@ -1324,6 +1359,9 @@ int ef_session_step(ef_session* s, ef_sched_stats* stats_out) {
       fprintf(stderr, "*   %-14s %8.4f s  %6.2f  %6.2f\n", nm[k], sec, (double)sh->prof_susp[k] / (double)sh->n_units, (double)sh->prof_jobs[k] / (double)sh->n_units);
       ts += sh->prof_susp[k]; tj += sh->prof_jobs[k]; if (k != EFP_SLEEP && k != EFP_WAIT_PREFETCH) tot += sec;
     }
+    fprintf(stderr, "*   asleep waiting for batches, ms per worker in each 5 ms of the step:");
+    for (int k = 0; k < 64 && k * 0.005 < now_s() - t0; ++k) fprintf(stderr, " %.1f", 1e3 * sh->prof_sleep_bins[k] / (double)w_started);
+    fprintf(stderr, "\n");
     fprintf(stderr, "*   %-14s %8.4f s  %6.2f  %6.2f\n", "all but sleeps", tot, (double)ts / (double)sh->n_units, (double)tj / (double)sh->n_units);
   }
   if (pre_started) pthread_join(s->pre_thread, NULL);

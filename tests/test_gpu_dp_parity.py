@@ -248,6 +248,42 @@ def test_kband_band_on_lanes(gpu_ctx, O):
     run_and_check(gpu_ctx, O, cases)
 
 
+def test_align_inside_a_band(gpu_ctx, O):
+    """ALIGN above 64 rows first runs inside a band of half-width 31 on one wave (pgpu_dp_kernels.hip:
+    align_band_sweep) and falls back to the whole matrix when the banded score exceeds 31: scores on both
+    sides of the bound, length differences up to and beyond the band, gaps that push the path to the band's
+    edge, ties between diagonal / up / left (low-complexity strings), wildcard characters, strings whose
+    lengths sit on the 16-row groups of the direction words."""
+    rng = random.Random(4242)
+    cases = []
+    for n in (65, 66, 79, 80, 81, 95, 96, 97, 128, 200, 250, 255, 256, 257, 300, 511, 512, 513, 600, 1000, 2000):
+        for rate in (0.0, 0.005, 0.03, 0.08, 0.12, 0.2, 0.5):
+            a = D.rand_seq(rng, n, rng.choice([0.0, 0.0, 0.01]))
+            b = D.mutate(rng, a, rate)
+            cases.append(D.Case(D.ALIGN, a, b))
+            cases.append(D.Case(D.ALIGN, b, a) if len(b) > 64 else D.Case(D.ALIGN, a, b[::-1]))
+        a = D.rand_seq(rng, n)
+        for d in (1, 15, 30, 31, 32, 33, 60):                     # length differences around the band's half-width
+            if n > d + 64:
+                cases.append(D.Case(D.ALIGN, a, a[d:]))            # one gap of d at the start
+                cases.append(D.Case(D.ALIGN, a[:n - d], a))        # ... at the end
+                cases.append(D.Case(D.ALIGN, a[:n // 2] + a[n // 2 + d:], a))   # ... in the middle
+                cases.append(D.Case(D.ALIGN, a, a[:n // 3] + D.rand_seq(rng, d) + a[n // 3:]))
+        # a deletion and an insertion of the same size far apart: the path leaves the diagonal by g and comes back
+        for g in (5, 16, 29, 31, 32, 40):
+            if n > 2 * g + 80:
+                b = a[:20] + a[20 + g:n - 30] + D.rand_seq(rng, g) + a[n - 30:]
+                cases.append(D.Case(D.ALIGN, a, b))
+        # low complexity: many co-optimal alignments, the tie order decides
+        lc = (b"AC" * n)[:n]
+        cases.append(D.Case(D.ALIGN, lc, lc[1:] + b"A"))
+        cases.append(D.Case(D.ALIGN, b"A" * n, b"A" * (n - 7)))
+        cases.append(D.Case(D.ALIGN, b"A" * (n - 3), b"A" * n))
+        cases.append(D.Case(D.ALIGN, D.mutate(rng, lc, 0.05), lc))
+        cases.append(D.Case(D.ALIGN, b"N" * n, D.rand_seq(rng, n + 5)))
+    run_and_check(gpu_ctx, O, cases)
+
+
 def test_results_to_device_and_launch_modes(gpu_ctx, O):
     """pgpu_dp_plan_results_to_device hands the COMPLETE table to device memory (the LCF answers are
     decoded on the host from the kernel's keys); and the three launch modes of the library (PGPU_MERGED
