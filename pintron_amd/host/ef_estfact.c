@@ -96,6 +96,9 @@ ef_est* ef_compute_est_fact(const ef_seq* gen, const ef_seq* est, ef_backend* be
   size_t inc = 0, prev_tp = 0, prev_te = 0, tp, te;
   ef_est* fe = NULL;
   bool expired;
+  ef_ahead ahead;                                /* answers asked ahead for this EST (estfact.h) */
+  if (ef_ahead_on) ef_ahead_init(&ahead);
+  be->ahead = ef_ahead_on ? &ahead : NULL;
   do {
     ef_meg* V = NULL;
     bool same;
@@ -143,6 +146,7 @@ ef_est* ef_compute_est_fact(const ef_seq* gen, const ef_seq* est, ef_backend* be
     ef_meg_free(V);
     ef_phase(EFP_OTHER);
   } while (expired);
+  be->ahead = NULL;
   return fe;
 }
 

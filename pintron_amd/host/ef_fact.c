@@ -47,20 +47,70 @@ void ef_est_free(ef_est* e) {
   free(e);
 }
 
+/* ---- questions asked ahead (estfact.h: ef_ahead) ------------------------------------------------ */
+static void ahead_note(ef_ahead* ah, const ef_dp_req* q) {
+  for (int k = 0; k < ah->n_pending; ++k) if (ef_req_same(&ah->q[ah->n + k], q)) return;
+  if (ah->n + ah->n_pending < EF_AHEAD_MAX) ah->q[ah->n + ah->n_pending++] = *q;
+}
+
+int ef_dp_many_ahead(ef_backend* be, const ef_dp_req* reqs, ef_dp_res* res, size_t n) {
+  ef_ahead* ah = be->ahead;
+  enum { CAP = 32 };
+  if (n > CAP) return ah->collecting ? EF_DP_PENDING : ef_backend_ask(be, reqs, res, n);
+  size_t miss[CAP], nm = 0;
+  for (size_t k = 0; k < n; ++k) {
+    const int32_t* v = ef_ahead_find(ah, &reqs[k]);
+    if (v) memcpy(res[k].v, v, sizeof res[k].v);
+    else miss[nm++] = k;
+  }
+  if (ef_prof_on) { ef_prof.ahead_hits += n - nm; ef_prof.ahead_misses += ah->collecting ? 0 : nm; }
+  if (nm == 0) return 0;
+  if (ah->collecting) {
+    for (size_t k = 0; k < nm; ++k) if (ef_req_keepable(&reqs[miss[k]])) ahead_note(ah, &reqs[miss[k]]);
+    return EF_DP_PENDING;
+  }
+  if (nm == n) return ef_backend_ask(be, reqs, res, n);
+  ef_dp_req mq[CAP]; ef_dp_res mr[CAP];
+  for (size_t k = 0; k < nm; ++k) mq[k] = reqs[miss[k]];
+  memset(mr, 0, nm * sizeof(ef_dp_res));
+  const int rc = ef_backend_ask(be, mq, mr, nm);
+  if (rc != 0) return rc;
+  for (size_t k = 0; k < nm; ++k) res[miss[k]] = mr[k];
+  return 0;
+}
+
+int ef_ahead_flush(ef_backend* be) {
+  ef_ahead* ah = be->ahead;
+  if (!ah || ah->n_pending == 0) return 0;
+  const bool was = ah->collecting;
+  ah->collecting = false;
+  const int np = ah->n_pending;
+  ef_dp_res r[EF_AHEAD_MAX];
+  memset(r, 0, (size_t)np * sizeof(ef_dp_res));
+  const int rc = ef_backend_ask(be, ah->q + ah->n, r, (size_t)np);
+  if (rc == 0)
+    for (int k = 0; k < np; ++k) ef_ahead_keep_next(ah, r[k].v);
+  if (ef_prof_on) ef_prof.ahead_asked += (unsigned long long)np;
+  ah->n_pending = 0;
+  ah->collecting = was;
+  return rc;
+}
+
+/* one question; 0 = answered, EF_DP_PENDING = noted (collect mode) */
 static int run_dp(ef_backend* be, int kind, const char* a, size_t la, const char* b, size_t lb,
-                  uint32_t p0, uint32_t p1, uint32_t p2, uint32_t tail, ef_dp_res* res) {
-  ef_dp_req rq = { kind, a, la, b, lb, p0, p1, p2, tail };
-  memset(res, 0, sizeof(*res));
-  if (be->dp(be->self, &rq, res) != 0) {
+                  uint32_t p0, uint32_t p1, uint32_t p2, uint32_t tail, bool temp, ef_dp_res* res) {
+  ef_dp_req rq = { kind, a, la, b, lb, p0, p1, p2, tail, temp ? 1u : 0u };
+  const int rc = ef_dp_one(be, &rq, res);
+  if (rc != 0 && rc != EF_DP_PENDING) {
     fprintf(stderr, "* FATAL dynamic-programming backend failed (kind %d, %zu x %zu)\n", kind, la, lb);
     abort();
   }
-  return 0;
+  return rc;
 }
 
 uint32_t ef_edit_distance(ef_backend* be, const char* a, size_t la, const char* b, size_t lb) {
   ef_dp_res r;
-  run_dp(be, EF_DP_ED, a, la, b, lb, 0, 0, 0, 0, &r);
+  run_dp(be, EF_DP_ED, a, la, b, lb, 0, 0, 0, 0, true, &r);      /* (the callers pass copies) */
   return (uint32_t)r.v[0];
 }
 
@@ -727,8 +777,10 @@ static bool check_gap_errors(ef_list* fact, const char* est, const char* gen, co
       if (d->EST_end + 1 < 0 || view_len(est, d->EST_end + 1, (int)gapP) != gapP) p = pc = ef_real_substring(d->EST_end + 1, (int)gapP, est);
       if (d->GEN_end + 1 < 0 || (int)gapT < 0 || (size_t)(d->GEN_end + 1) + gapT > ef_genomic_len(gen)) t = tc = ef_real_substring(d->GEN_end + 1, (int)gapT, gen);
       ef_dp_res r;
-      run_dp(be, EF_DP_BORDERS, p, gapP, t, gapT, 0, (uint32_t)gapP, (uint32_t)max_errs, 0, &r);
+      const int asked = run_dp(be, EF_DP_BORDERS, p, gapP, t, gapT, 0, (uint32_t)gapP, (uint32_t)max_errs, 0, pc || tc, &r);
       free(pc); free(tc);
+      if (asked == EF_DP_PENDING) { d = a; continue; }           /* collect mode: noted; the next gap does not depend on this one */
+      if (ef_collecting(be)) { d = a; continue; }                /* ... known already: nothing is changed in this mode */
       ok = r.v[0] != 0;
       if (ok) {
         tot += (unsigned)r.v[4];
@@ -740,6 +792,7 @@ static bool check_gap_errors(ef_list* fact, const char* est, const char* gen, co
     }
     d = a;
   }
+  if (ef_collecting(be)) return true;
   if (ok && tot > threshold_ed) ok = false;
   if (ok) {
     it = efl_begin(fact);
@@ -924,6 +977,15 @@ ef_est* ef_get_est_factorizations(const ef_seq* est_info, ef_meg* V, const ef_co
   }
   ef_phase(EFP_GAPERR);
   /* FILTER 4: gap errors (:416-433) */
+  if (be->ahead) {
+    /* the border refinements of all gaps of all candidates do not depend on each other (a gap reads and writes
+     * only the two exon ends that face it): asked in one request, found by the loop below */
+    ef_ahead_collect(be, true);
+    ef_iter it = efl_begin(flist);
+    while (efi_has_next(&it)) check_gap_errors((ef_list*)efi_next(&it), EST, GEN, cfg, be);
+    ef_ahead_collect(be, false);
+    if (ef_ahead_flush(be) != 0) { fprintf(stderr, "* FATAL dynamic-programming backend failed\n"); abort(); }
+  }
   {
     ef_iter it = efl_begin(flist);
     while (efi_has_next(&it)) {
@@ -938,6 +1000,41 @@ ef_est* ef_get_est_factorizations(const ef_seq* est_info, ef_meg* V, const ef_co
   ef_phase(EFP_INTRON);
   /* intron refinement (:446-490) */
   {
+    /* The gap alignments of the introns are asked together, from the exons as they are now: refining an intron
+     * moves the two exon ends that face it, which changes the strings of the NEXT intron only when the exon
+     * between them is shorter than the 30-character windows -- every alignment is taken at its turn when its
+     * strings are still the same and asked again otherwise (ef_refine_intron). */
+    enum { GAP_AHEAD_MAX = 24 };
+    ef_gap_ahead* pre = NULL; size_t n_pre = 0;
+    if (be->ahead && be->dp_many) {
+      size_t total = 0;
+      ef_iter it = efl_begin(flist);
+      while (efi_has_next(&it)) { const size_t k = efl_size((ef_list*)efi_next(&it)); total += k ? k - 1 : 0; }
+      if (total >= 2 && total <= GAP_AHEAD_MAX) {
+        pre = (ef_gap_ahead*)malloc(total * sizeof(ef_gap_ahead));
+        ef_dp_req rq[GAP_AHEAD_MAX]; ef_dp_res rs[GAP_AHEAD_MAX];
+        it = efl_begin(flist);
+        while (efi_has_next(&it)) {
+          ef_list* f = (ef_list*)efi_next(&it);
+          if (efl_empty(f)) continue;
+          ef_iter fi = efl_begin(f);
+          const ef_factor* donor = (const ef_factor*)efi_next(&fi);
+          while (efi_has_next(&fi)) {
+            const ef_factor* acc = (const ef_factor*)efi_next(&fi);
+            ef_gap_window_build(cfg, gen_info, est_info, donor, acc, &pre[n_pre].w);
+            pre[n_pre].donor = *donor; pre[n_pre].acceptor = *acc;
+            const ef_dp_req q = { EF_DP_GAP, pre[n_pre].w.seq_est, pre[n_pre].w.le, pre[n_pre].w.seq_gen, pre[n_pre].w.lg, 0, 0, 0, 0, 1 };
+            rq[n_pre++] = q;
+            donor = acc;
+          }
+        }
+        memset(rs, 0, n_pre * sizeof(ef_dp_res));
+        if (be->dp_many(be->self, rq, rs, n_pre) != 0) { fprintf(stderr, "* FATAL gap alignment backend failed\n"); abort(); }
+        for (size_t k = 0; k < n_pre; ++k) pre[k].res = rs[k];
+        if (ef_prof_on) ef_prof.ahead_asked += n_pre;
+      }
+    }
+    size_t at = 0;
     ef_iter it = efl_begin(flist);
     while (efi_has_next(&it)) {
       ef_list* f = (ef_list*)efi_next(&it);
@@ -947,7 +1044,8 @@ ef_est* ef_get_est_factorizations(const ef_seq* est_info, ef_meg* V, const ef_co
       bool first = true;
       while (efi_has_next(&fi)) {
         ef_factor* acc = (ef_factor*)efi_next(&fi);
-        ef_refine_intron(cfg, gen_info, est_info, donor, acc, first, be);
+        ef_refine_intron(cfg, gen_info, est_info, donor, acc, first, be, pre && at < n_pre ? &pre[at] : NULL);
+        ++at;
         first = false;
         donor = acc;
       }
@@ -958,6 +1056,8 @@ ef_est* ef_get_est_factorizations(const ef_seq* est_info, ef_meg* V, const ef_co
         if (e1->EST_start == e2->EST_start) free(efl_pop_front(f));
       }
     }
+    for (size_t k = 0; k < n_pre; ++k) { ef_gap_window_release(&pre[k].w); ef_dp_res_release(&pre[k].res); }
+    free(pre);
   }
   ef_phase(EFP_TAIL);
   /* tail correction and polyA (:573-585) -- on the ORIGINAL EST sequence */

@@ -21,11 +21,13 @@
 static size_t zmin(size_t a, size_t b) { return a < b ? a : b; }
 static size_t zmax(size_t a, size_t b) { return a > b ? a : b; }
 
-static void dp(ef_backend* be, int kind, const char* a, size_t la, const char* b, size_t lb,
-               uint32_t p0, uint32_t p1, uint32_t p2, uint32_t tail, ef_dp_res* r) {
-  ef_dp_req rq = { kind, a, la, b, lb, p0, p1, p2, tail };
-  memset(r, 0, sizeof(*r));
-  if (be->dp(be->self, &rq, r) != 0) { fprintf(stderr, "* FATAL dynamic-programming backend failed (kind %d)\n", kind); abort(); }
+/* one question over the sequences themselves; 0 = answered, EF_DP_PENDING = noted (collect mode, estfact.h: ef_ahead) */
+static int dp(ef_backend* be, int kind, const char* a, size_t la, const char* b, size_t lb,
+              uint32_t p0, uint32_t p1, uint32_t p2, uint32_t tail, ef_dp_res* r) {
+  ef_dp_req rq = { kind, a, la, b, lb, p0, p1, p2, tail, 0 };
+  const int rc = ef_dp_one(be, &rq, r);
+  if (rc != 0 && rc != EF_DP_PENDING) { fprintf(stderr, "* FATAL dynamic-programming backend failed (kind %d)\n", kind); abort(); }
+  return rc;
 }
 
 /* compute_edit_distance (src/compute-alignments.c:240-249) as a request: false when the strings are
@@ -36,8 +38,10 @@ static bool ed_request(ef_dp_req* q, const char* a, size_t la, const char* b, si
   *q = r;
   return true;
 }
-static void dp_many(ef_backend* be, const ef_dp_req* q, ef_dp_res* r, size_t n) {
-  if (ef_dp_many(be, q, r, n) != 0) { fprintf(stderr, "* FATAL dynamic-programming backend failed\n"); abort(); }
+static int dp_many(ef_backend* be, const ef_dp_req* q, ef_dp_res* r, size_t n) {
+  const int rc = ef_dp_many(be, q, r, n);
+  if (rc != 0 && rc != EF_DP_PENDING) { fprintf(stderr, "* FATAL dynamic-programming backend failed\n"); abort(); }
+  return rc;
 }
 
 /* valid bytes after t[len] (0..2) when t points into the NUL-terminated string s */
@@ -122,7 +126,7 @@ static void recover_affixes(const ef_seq* gen, ef_est* e, ef_backend* be) {
       for (size_t i = 0; i < glen; ++i) gf[i] = G[ff->GEN_start - 1 - i];
       ef[elen] = gf[glen] = '\0';
       if (ef[0] != gf[0]) {
-        const ef_dp_req x = { EF_DP_AFFIX, ef, elen, gf, glen, 0, 0, 0, 0 };
+        const ef_dp_req x = { EF_DP_AFFIX, ef, elen, gf, glen, 0, 0, 0, 0, 1 };     /* reversed copies */
         sp = (int)nq; q[nq++] = x;
       }
     }
@@ -173,13 +177,14 @@ static bool analyze_small_exon(ef_factor** pprev, ef_factor** pcurr, ef_factor* 
   /* the reference takes the "suffix" BEFORE the window start (allefact - esufflen, :1017-1018) */
   if (estart >= esufflen && gstart >= gsufflen &&
       ed_request(&q3[n3], allefact - esufflen, esufflen, allgfact - gsufflen, gsufflen)) s_suff = (int)n3++;
-  dp_many(be, q3, r3, n3);
+  if (dp_many(be, q3, r3, n3) == EF_DP_PENDING) return false;
   const size_t orig_ed = s_orig >= 0 ? (size_t)(uint32_t)r3[s_orig].v[0] : 0;
   const size_t ed_pref = s_pref >= 0 ? (size_t)(uint32_t)r3[s_pref].v[0] : 0;
   const size_t ed_suff = s_suff >= 0 ? (size_t)(uint32_t)r3[s_suff].v[0] : 0;
   ef_dp_res r;
   const uint32_t max_errs = (uint32_t)(orig_ed + ed_pref + ed_suff);
-  dp(be, EF_DP_BORDERS, allefact, allelen, allgfact, allglen, 0, (uint32_t)allelen, max_errs, tail_of(G, allgfact, allglen), &r);
+  if (dp(be, EF_DP_BORDERS, allefact, allelen, allgfact, allglen, 0, (uint32_t)allelen, max_errs, tail_of(G, allgfact, allglen), &r) == EF_DP_PENDING) return false;
+  if (ef_collecting(be)) return false;                  /* every answer is known: nothing is changed in this mode */
   if (!r.v[0]) return false;
   const size_t off_p = (size_t)r.v[1], off_t1 = (size_t)r.v[2], off_t2 = (size_t)r.v[3];
   const double prev_avg = (ef_burset_adaptor(G, (size_t)(prev->GEN_end + 1), (size_t)curr->GEN_start) +
@@ -258,7 +263,7 @@ static void small_exon_at_prefix(ef_factor* p1, ef_iter* it, const ef_seq* gen, 
   { const ef_dp_req x = { EF_DP_LCF, G, (size_t)p1->GEN_start, epfact, eplen, 0, 0, 0, 0 }; q2[0] = x; }
   const bool need_ed = ed_request(&q2[1], E + p1->EST_start, e1plen, G + p1->GEN_start, e1plen);
   if (need_ed) n2 = 2;
-  dp_many(be, q2, r2, n2);
+  if (dp_many(be, q2, r2, n2) == EF_DP_PENDING) return;
   ef_dp_res r = r2[0];
   const size_t cflen = (size_t)r.v[0], pg = (size_t)r.v[1], pe = (size_t)r.v[2];
   if (cflen < LB_SMALL_EXON) return;
@@ -268,8 +273,9 @@ static void small_exon_at_prefix(ef_factor* p1, ef_iter* it, const ef_seq* gen, 
   const size_t allelen = zmin((size_t)(p1->EST_end + 1), (size_t)(p1->EST_start + UB_SMALL_EXON)) - pe;
   const size_t allglen = zmin((size_t)(p1->GEN_end + 1), (size_t)(p1->GEN_start + UB_SMALL_EXON)) - pg;
   if (allelen < 2 * LB_SMALL_EXON || allelen > 4096) return;     /* outside what the reference can evaluate */
-  dp(be, EF_DP_BORDERS, E + pe, allelen, G + pg, allglen, LB_SMALL_EXON, (uint32_t)(allelen - LB_SMALL_EXON), edp,
-     tail_of(G, G + pg, allglen), &r);
+  if (dp(be, EF_DP_BORDERS, E + pe, allelen, G + pg, allglen, LB_SMALL_EXON, (uint32_t)(allelen - LB_SMALL_EXON), edp,
+         tail_of(G, G + pg, allglen), &r) == EF_DP_PENDING) return;
+  if (ef_collecting(be)) return;
   if (!r.v[0]) return;
   const size_t off_p = (size_t)r.v[1], off_t1 = (size_t)r.v[2], off_t2 = (size_t)r.v[3];
   if ((int)off_t2 - (int)off_t1 < cfg->min_intron_length) return;
@@ -305,7 +311,8 @@ static void small_exon_between(ef_factor* p1, ef_factor* p2, ef_iter* it, const 
   if (ed_request(&q4[n4], e2p, e2plen, g2p, g2plen)) s_ped = (int)n4++;
   if (s_sed >= 0) { const ef_dp_req x = { EF_DP_LCF, e1s, e1slen, g1s, g1slen, 0, 0, 0, 0 }; s_l1 = (int)n4; q4[n4++] = x; }
   if (s_ped >= 0) { const ef_dp_req x = { EF_DP_LCF, e2p, e2plen, g2p, g2plen, 0, 0, 0, 0 }; s_l2 = (int)n4; q4[n4++] = x; }
-  dp_many(be, q4, r4, n4);
+  if (dp_many(be, q4, r4, n4) == EF_DP_PENDING) return;
+  if (ef_collecting(be)) return;                       /* (no further question follows) */
   const size_t sed = s_sed >= 0 ? (size_t)(uint32_t)r4[s_sed].v[0] : 0;
   const size_t ped = s_ped >= 0 ? (size_t)(uint32_t)r4[s_ped].v[0] : 0;
   bool go = false;
@@ -553,6 +560,21 @@ void ef_refine_est_factorizations(const ef_seq* gen, ef_est* e, const ef_config*
   ef_remove_duplicated_factorizations(e->factorizations);
   ef_phase(EFP_REF_AFFIX);
   recover_affixes(gen, e, be);
+  if (be->ahead) {
+    /* what the two small-exon passes below are going to ask first (edit distances, common factors), for all exons
+     * and introns of all factorizations in one request; then, with those answers, their border refinements in a
+     * second one.  The passes themselves follow and find the answers (a pass that changes an exon makes the
+     * questions of its neighbours different ones: those are asked when their turn comes, as before). */
+    ef_phase(EFP_REF_FALSE_SMALL);
+    for (int round = 0; round < 2; ++round) {
+      ef_ahead_collect(be, true);
+      remove_false_small_exons(gen, e, be);
+      search_new_small_exons(gen, e, cfg, be);
+      ef_ahead_collect(be, false);
+      if (be->ahead->n_pending == 0) break;
+      if (ef_ahead_flush(be) != 0) { fprintf(stderr, "* FATAL dynamic-programming backend failed\n"); abort(); }
+    }
+  }
   ef_phase(EFP_REF_FALSE_SMALL);
   remove_false_small_exons(gen, e, be);
   ef_remove_duplicated_factorizations(e->factorizations);

@@ -269,7 +269,7 @@ static bool shift_generic(const char* est, const char* gen, const gap_aln* al, b
     for (int i = 0; i < CYCLES; ++i) {
       sp[i] = -1;
       if (variant1 && cut_factor[i] != NULL) {
-        const ef_dp_req x = { EF_DP_ED, cut_factor[i], strlen(cut_factor[i]), prev_match[i], strlen(prev_match[i]), 0, 0, 0, 0 };
+        const ef_dp_req x = { EF_DP_ED, cut_factor[i], strlen(cut_factor[i]), prev_match[i], strlen(prev_match[i]), 0, 0, 0, 0, 1 };
         sp[i] = (int)nq; q[nq++] = x;
       }
       for (int j = 0; j < CYCLES; ++j) {
@@ -277,7 +277,7 @@ static bool shift_generic(const char* est, const char* gen, const gap_aln* al, b
         const char *a = NULL, *b = NULL;
         if (ext_cut[i] != NULL && ext_match[j] != NULL) { a = ext_cut[i]; b = ext_match[j]; }
         else if (cut_factor[i] != NULL && match_str[j] != NULL) { a = cut_factor[i]; b = match_str[j]; }
-        if (a) { const ef_dp_req x = { EF_DP_ED, a, strlen(a), b, strlen(b), 0, 0, 0, 0 }; sx[i][j] = (int)nq; q[nq++] = x; }
+        if (a) { const ef_dp_req x = { EF_DP_ED, a, strlen(a), b, strlen(b), 0, 0, 0, 0, 1 }; sx[i][j] = (int)nq; q[nq++] = x; }
       }
     }
     if (ef_dp_many(be, q, rs, nq) != 0) { fprintf(stderr, "* FATAL edit-distance backend failed\n"); abort(); }
@@ -379,17 +379,15 @@ static size_t append_substring(char* dst, size_t n, int index, int length, const
   return n;
 }
 
-/* refine_intron (:47-265) */
-bool ef_refine_intron(const ef_config* cfg, const ef_seq* gen_info, const ef_seq* est_info, ef_factor* donor,
-                      ef_factor* acceptor, bool first_intron, ef_backend* be) {
+/* The two strings of the gap alignment of one intron (:60-116): concatenations of real_substring() pieces --
+ * donor suffix + unaligned EST gap + acceptor prefix on the EST, and donor suffix + intron prefix + intron
+ * suffix + acceptor prefix on the genomic sequence -- appended straight into two buffers (same clamping, same
+ * stop at the terminator). */
+void ef_gap_window_build(const ef_config* cfg, const ef_seq* gen_info, const ef_seq* est_info, const ef_factor* donor,
+                         const ef_factor* acceptor, ef_gap_window* w) {
   const int sp_est = cfg->suffpref_length_on_est, sp_int = cfg->suffpref_length_for_intron, sp_gen = cfg->suffpref_length_on_gen;
   const char* G = gen_info->seq;
   const char* E = est_info->seq;
-
-  /* The two strings of the gap alignment are concatenations of real_substring() pieces
-   * (:60-116): donor suffix + unaligned EST gap + acceptor prefix on the EST, and donor suffix +
-   * intron prefix + intron suffix + acceptor prefix on the genomic sequence.  The pieces are
-   * appended straight into the two buffers (same clamping, same stop at the terminator). */
   int dsl_gen = donor->GEN_start;
   if (donor->GEN_end - sp_gen + 1 >= dsl_gen) dsl_gen = donor->GEN_end - sp_gen + 1;
   int dsl_est = donor->EST_start;
@@ -407,20 +405,53 @@ bool ef_refine_intron(const ef_config* cfg, const ef_seq* gen_info, const ef_seq
   size_t cap_e = 1, cap_g = 1;
   for (int k = 0; k < 3; ++k) cap_e += piece_e[k][1] > 0 ? (size_t)piece_e[k][1] : 0;
   for (int k = 0; k < 4; ++k) cap_g += piece_g[k][1] > 0 ? (size_t)piece_g[k][1] : 0;
-  char buf_e[1024], buf_g[1024];
-  char* seq_est = cap_e <= sizeof buf_e ? buf_e : (char*)malloc(cap_e);
-  char* seq_gen = cap_g <= sizeof buf_g ? buf_g : (char*)malloc(cap_g);
+  w->seq_est = cap_e <= sizeof w->buf_e ? w->buf_e : (char*)malloc(cap_e);
+  w->seq_gen = cap_g <= sizeof w->buf_g ? w->buf_g : (char*)malloc(cap_g);
   size_t le = 0, lg = 0;
-  for (int k = 0; k < 3; ++k) le = append_substring(seq_est, le, piece_e[k][0], piece_e[k][1], E);
-  for (int k = 0; k < 4; ++k) lg = append_substring(seq_gen, lg, piece_g[k][0], piece_g[k][1], G);
-  seq_est[le] = '\0'; seq_gen[lg] = '\0';
+  for (int k = 0; k < 3; ++k) le = append_substring(w->seq_est, le, piece_e[k][0], piece_e[k][1], E);
+  for (int k = 0; k < 4; ++k) lg = append_substring(w->seq_gen, lg, piece_g[k][0], piece_g[k][1], G);
+  w->seq_est[le] = '\0'; w->seq_gen[lg] = '\0';
+  w->le = le; w->lg = lg; w->dsl_est = dsl_est; w->dsl_gen = dsl_gen;
+  w->deleted_intron_dim = acceptor->GEN_start - donor->GEN_end - 1 - 2 * sp_int;
+}
+void ef_gap_window_release(ef_gap_window* w) {
+  if (w->seq_est != w->buf_e) free(w->seq_est);
+  if (w->seq_gen != w->buf_g) free(w->seq_gen);
+  w->seq_est = w->seq_gen = NULL;
+}
 
-  const int deleted_intron_dim = acceptor->GEN_start - donor->GEN_end - 1 - 2 * sp_int;
-
-  ef_dp_req rq = { EF_DP_GAP, seq_est, le, seq_gen, lg, 0, 0, 0, 0 };
+/* refine_intron (:47-265).  `ahead` (may be NULL): a gap alignment asked before its turn -- its two strings and
+ * the answer; it is taken when the strings of this intron, built from the exons as they are NOW, are the same. */
+bool ef_refine_intron(const ef_config* cfg, const ef_seq* gen_info, const ef_seq* est_info, ef_factor* donor,
+                      ef_factor* acceptor, bool first_intron, ef_backend* be, ef_gap_ahead* ahead) {
+  const char* G = gen_info->seq;
+  const char* E = est_info->seq;
+  ef_gap_window w;
+  w.seq_est = w.seq_gen = NULL;
   ef_dp_res rs;
   memset(&rs, 0, sizeof rs);
-  if (be->dp(be->self, &rq, &rs) != 0) { fprintf(stderr, "* FATAL gap alignment backend failed\n"); abort(); }
+  int dsl_est, dsl_gen, deleted_intron_dim;
+  /* the same two exons as when the alignment was asked: the same strings, nothing to build */
+  const bool same_exons = ahead && ahead->res.s0 && memcmp(&ahead->donor, donor, sizeof *donor) == 0 &&
+                          memcmp(&ahead->acceptor, acceptor, sizeof *acceptor) == 0;
+  if (same_exons) {
+    dsl_est = ahead->w.dsl_est; dsl_gen = ahead->w.dsl_gen; deleted_intron_dim = ahead->w.deleted_intron_dim;
+    rs = ahead->res;                             /* the rows are ours now */
+    ahead->res.s0 = ahead->res.s1 = NULL;
+    if (ef_prof_on) ++ef_prof.ahead_hits;
+  } else {
+    ef_gap_window_build(cfg, gen_info, est_info, donor, acceptor, &w);
+    dsl_est = w.dsl_est; dsl_gen = w.dsl_gen; deleted_intron_dim = w.deleted_intron_dim;
+    if (ahead && ahead->res.s0 && ahead->w.le == w.le && ahead->w.lg == w.lg &&
+        memcmp(ahead->w.seq_est, w.seq_est, w.le) == 0 && memcmp(ahead->w.seq_gen, w.seq_gen, w.lg) == 0) {
+      rs = ahead->res;
+      ahead->res.s0 = ahead->res.s1 = NULL;
+      if (ef_prof_on) ++ef_prof.ahead_hits;
+    } else {
+      ef_dp_req rq = { EF_DP_GAP, w.seq_est, w.le, w.seq_gen, w.lg, 0, 0, 0, 0, 1 };
+      if (be->dp(be->self, &rq, &rs) != 0) { fprintf(stderr, "* FATAL gap alignment backend failed\n"); abort(); }
+    }
+  }
   gap_aln al;
   al.est_row = rs.s0; al.gen_row = rs.s1;      /* one zero-padded block (ef_dp_res), released at `done` */
   al.dim = rs.v[0]; al.factor_cut = rs.v[1]; al.intron_start = rs.v[2]; al.intron_end = rs.v[3];
@@ -428,8 +459,7 @@ bool ef_refine_intron(const ef_config* cfg, const ef_seq* gen_info, const ef_seq
   al.new_acceptor_factor_left = dsl_est + al.factor_cut;
   al.new_donor_right_on_gen = dsl_gen + al.intron_start - 1;
   al.new_acceptor_left_on_gen = dsl_gen + al.intron_end + deleted_intron_dim + 1;
-  if (seq_est != buf_e) free(seq_est);
-  if (seq_gen != buf_g) free(seq_gen);
+  if (w.seq_est) ef_gap_window_release(&w);
 
   bool result = false;
   if (al.new_acceptor_factor_left == donor->EST_start) {

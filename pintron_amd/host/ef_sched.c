@@ -273,6 +273,7 @@ typedef struct shared {
   struct out_chunk* chunks;              /* under mu */
   struct out_chunk* spare_chunks;        /* chunks of the previous step, reused (their pages stay mapped) */
   unsigned long long prof_cyc[EFP_N], prof_susp[EFP_N], prof_jobs[EFP_N];   /* PINTRON_PROFILE, summed over the workers (under mu) */
+  unsigned long long prof_ahead[3];
   double prof_t0; double prof_sleep_bins[64];      /* when in the step the workers slept (5 ms bins, seconds summed over the workers) */
 } shared;
 
@@ -810,6 +811,7 @@ static void* worker_main(void* arg) {
     pthread_mutex_lock(&sh->mu);
     for (int k = 0; k < EFP_N; ++k) { sh->prof_cyc[k] += ef_prof.cyc[k]; sh->prof_susp[k] += ef_prof.susp[k]; sh->prof_jobs[k] += ef_prof.jobs[k]; }
     for (int k = 0; k < 64; ++k) sh->prof_sleep_bins[k] += w->sleep_bins[k];
+    sh->prof_ahead[0] += ef_prof.ahead_asked; sh->prof_ahead[1] += ef_prof.ahead_hits; sh->prof_ahead[2] += ef_prof.ahead_misses;
     pthread_mutex_unlock(&sh->mu);
   }
   return NULL;
@@ -1073,7 +1075,7 @@ ef_session* ef_session_open(int argc, char** argv) {
   const double t_loaded = now_s();
   if (load_rc == 0 && !getenv("PINTRON_NO_FIBER_POOL")) {
     s->sh.stack_size = env_size("PINTRON_FIBER_STACK_KB", 256) * 1024;
-    size_t want = env_size("PINTRON_THREADS", host_core_share()) * env_size("PINTRON_FIBERS", 1024);
+    size_t want = env_size("PINTRON_THREADS", host_core_share()) * env_size("PINTRON_FIBERS", 768);
     if (want > s->in.n) want = s->in.n;                 /* never more fibres than sequences */
     if (want >= 64) {
       for (int t = 0; t < 2; ++t) {
@@ -1155,7 +1157,7 @@ ef_session* ef_session_open(int argc, char** argv) {
   /* the workers hide the GPU latency with lanes, not with oversubscription */
   s->nthreads = env_size("PINTRON_THREADS", host_core_share());
   if (s->nthreads > sh->n_units) s->nthreads = sh->n_units ? sh->n_units : 1;
-  sh->max_fibers = env_size("PINTRON_FIBERS", 1024);
+  sh->max_fibers = env_size("PINTRON_FIBERS", 768);
   sh->stack_size = env_size("PINTRON_FIBER_STACK_KB", 256) * 1024;
   sh->kernel_timing = env_flag("PINTRON_KERNEL_TIMING");
   sh->gen_len = strlen(in->gen->seq);
@@ -1318,7 +1320,7 @@ int ef_session_step(ef_session* s, ef_sched_stats* stats_out) {
   free_unit_buffers(sh, false);
   for (int c = 0; c < PRE_CHUNKS; ++c) { free(sh->pre_tri[c]); free(sh->pre_first[c]); sh->pre_tri[c] = NULL; sh->pre_first[c] = NULL; }
   sh->next_unit = 0; sh->failed = 0; sh->ready_entries = 0;
-  sh->prof_t0 = t0; memset(sh->prof_sleep_bins, 0, sizeof sh->prof_sleep_bins);
+  sh->prof_t0 = t0; memset(sh->prof_sleep_bins, 0, sizeof sh->prof_sleep_bins); memset(sh->prof_ahead, 0, sizeof sh->prof_ahead);
   memset(s->pre_kernel_ms, 0, sizeof s->pre_kernel_ms);
   s->pre_meg_ms = 0;
   s->pre_t0 = t0; s->pre_wall = 0;
@@ -1359,6 +1361,8 @@ int ef_session_step(ef_session* s, ef_sched_stats* stats_out) {
       fprintf(stderr, "*   %-14s %8.4f s  %6.2f  %6.2f\n", nm[k], sec, (double)sh->prof_susp[k] / (double)sh->n_units, (double)sh->prof_jobs[k] / (double)sh->n_units);
       ts += sh->prof_susp[k]; tj += sh->prof_jobs[k]; if (k != EFP_SLEEP && k != EFP_WAIT_PREFETCH) tot += sec;
     }
+    fprintf(stderr, "*   asked ahead: %.2f jobs / unit, found there %.2f, asked in turn (while answers were kept) %.2f\n",
+            (double)sh->prof_ahead[0] / (double)sh->n_units, (double)sh->prof_ahead[1] / (double)sh->n_units, (double)sh->prof_ahead[2] / (double)sh->n_units);
     fprintf(stderr, "*   asleep waiting for batches, ms per worker in each 5 ms of the step:");
     for (int k = 0; k < 64 && k * 0.005 < now_s() - t0; ++k) fprintf(stderr, " %.1f", 1e3 * sh->prof_sleep_bins[k] / (double)w_started);
     fprintf(stderr, "\n");

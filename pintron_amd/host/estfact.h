@@ -250,7 +250,8 @@ enum { EFP_OTHER = 0, EFP_MEG, EFP_EMBED, EFP_ENDPOINTS, EFP_EXTERNAL, EFP_DUST,
        EFP_REF_AFFIX, EFP_REF_FALSE_SMALL, EFP_REF_NEW_SMALL, EFP_REF_CLEAN, EFP_SCHED_LAUNCH, EFP_SCHED_COLLECT, EFP_SCHED_START, EFP_WAIT_PREFETCH,
        EFP_NS_PREFIX, EFP_NS_BETWEEN_ASK, EFP_NS_BETWEEN_CLASS, EFP_NS_BETWEEN_SEARCH, EFP_TMP1, EFP_TMP2, EFP_TMP3, EFP_N };
 extern int ef_prof_on;
-typedef struct { unsigned long long cyc[EFP_N], susp[EFP_N], jobs[EFP_N]; unsigned long long last; int dummy; int* cur; } ef_prof_state;
+typedef struct { unsigned long long cyc[EFP_N], susp[EFP_N], jobs[EFP_N]; unsigned long long last; int dummy; int* cur;
+                 unsigned long long ahead_hits, ahead_misses, ahead_asked; } ef_prof_state;
 extern _Thread_local ef_prof_state ef_prof;
 static inline unsigned long long ef_prof_now(void) {
 #if defined(__x86_64__)
@@ -279,6 +280,8 @@ typedef struct {
   const char* a; size_t la;      /* first operand  (EST side / s1 / p)       */
   const char* b; size_t lb;      /* second operand (genomic side / s2 / t)   */
   uint32_t p0, p1, p2, tail;     /* kind-specific, as in pgpu_dp_job         */
+  uint32_t temp;                 /* an operand lies in a buffer of the caller's (not in the EST's or the genomic
+                                    sequence): the question cannot be asked ahead (see ef_ahead) */
 } ef_dp_req;                     /* operands that point into the genomic sequence are recognised
                                     by address and sent as PGPU_JOB_*_GENOMIC (no copy) */
 typedef struct {
@@ -296,6 +299,30 @@ static inline void ef_dp_res_rows(ef_dp_res* r, size_t cap) {
 }
 static inline void ef_dp_res_release(ef_dp_res* r) { free(r->s0); r->s0 = r->s1 = NULL; }
 
+/* ---- questions asked ahead ---------------------------------------------------------------------
+ * The per-EST code asks its dynamic programs where the reference calls them, one dependent step after the
+ * other, and every question that goes to the device suspends the EST (ef_sched.c).  Many of them do not depend
+ * on each other's answers -- the border refinements of all gaps of all candidate factorizations, the edit
+ * distances and common factors of the small-exon searches of all introns -- so the code that is about to ask
+ * them runs once in COLLECT mode first: it computes its questions from the current state exactly as it will
+ * later, a question whose answer is not known yet is noted and the routine that asked returns without changing
+ * anything; the noted questions then go out in ONE request, their answers stay with the EST, and the real run
+ * finds them (ef_dp_many / ef_dp_one look here first).  A question is recognised by its identity -- kind,
+ * operand addresses, lengths, parameters -- and only questions over the EST's and the genomic sequence
+ * (immutable while the EST is processed; ef_dp_req.temp == 0) are kept, so an answer found here is the answer
+ * the backend would give: a guess that turns out wrong (the state changed in between) costs a wasted job,
+ * never a different result.  Answers with alignment rows (ALIGN, GAP) are not kept. */
+#define EF_AHEAD_MAX 96
+#define EF_DP_PENDING 1          /* collect mode: at least one answer is not known yet */
+#define EF_AHEAD_SLOTS 256       /* hash slots of the kept answers (a power of two, > 2 x EF_AHEAD_MAX) */
+typedef struct {
+  int n, n_pending;
+  bool collecting;
+  unsigned char slot[EF_AHEAD_SLOTS];            /* entry + 1 by ef_req_hash (linear probing), 0 = free */
+  ef_dp_req q[EF_AHEAD_MAX]; int32_t v[EF_AHEAD_MAX][6];     /* [0, n): kept answers; [n, n + n_pending): noted questions */
+} ef_ahead;
+static inline void ef_ahead_init(ef_ahead* ah) { ah->n = ah->n_pending = 0; ah->collecting = false; memset(ah->slot, 0, sizeof ah->slot); }
+
 typedef struct ef_backend {
   void* self;
   /* pairings of one pattern; *out is malloc'ed by the backend, freed by the caller */
@@ -310,15 +337,52 @@ typedef struct ef_backend {
    * device behind the pairings (record layout: include/pintron_gpu.h, pgpu_pairing_plan_run_meg);
    * NULL (or a NULL hook) = not available, the caller builds the graph from the pairings */
   const void* (*meg)(void* self, const char* pattern, size_t m, const ef_config* cfg);
+  ef_ahead* ahead;               /* the answers asked ahead for the EST being processed, or NULL */
 } ef_backend;
 
-static inline int ef_dp_many(ef_backend* be, const ef_dp_req* reqs, ef_dp_res* res, size_t n) {
-  if (n == 0) return 0;
-  memset(res, 0, n * sizeof(ef_dp_res));
+static inline bool ef_req_same(const ef_dp_req* x, const ef_dp_req* y) {
+  return x->kind == y->kind && x->a == y->a && x->b == y->b && x->la == y->la && x->lb == y->lb &&
+         x->p0 == y->p0 && x->p1 == y->p1 && x->p2 == y->p2 && x->tail == y->tail;
+}
+static inline bool ef_req_keepable(const ef_dp_req* q) { return q->temp == 0 && q->kind != EF_DP_ALIGN && q->kind != EF_DP_GAP; }
+static inline unsigned ef_req_hash(const ef_dp_req* q) {
+  uint64_t h = (uint64_t)(uintptr_t)q->a * 0x9E3779B97F4A7C15ull ^ (uint64_t)(uintptr_t)q->b * 0xC2B2AE3D27D4EB4Full;
+  h ^= ((uint64_t)q->la << 32 | (uint64_t)q->lb) * 0x165667B19E3779F9ull + (uint64_t)q->kind;
+  return (unsigned)(h >> 40) & (EF_AHEAD_SLOTS - 1);
+}
+static inline const int32_t* ef_ahead_find(const ef_ahead* ah, const ef_dp_req* q) {
+  if (ah->n == 0 || !ef_req_keepable(q)) return NULL;
+  for (unsigned s = ef_req_hash(q); ah->slot[s]; s = (s + 1) & (EF_AHEAD_SLOTS - 1))
+    if (ef_req_same(&ah->q[ah->slot[s] - 1], q)) return ah->v[ah->slot[s] - 1];
+  return NULL;
+}
+/* the noted question at q[n] becomes a kept answer */
+static inline void ef_ahead_keep_next(ef_ahead* ah, const int32_t* v) {
+  memcpy(ah->v[ah->n], v, 6 * sizeof(int32_t));
+  unsigned s = ef_req_hash(&ah->q[ah->n]);
+  while (ah->slot[s]) s = (s + 1) & (EF_AHEAD_SLOTS - 1);
+  ah->slot[s] = (unsigned char)(++ah->n);
+}
+static inline int ef_backend_ask(ef_backend* be, const ef_dp_req* reqs, ef_dp_res* res, size_t n) {
   if (be->dp_many) return be->dp_many(be->self, reqs, res, n);
   for (size_t k = 0; k < n; ++k) { const int rc = be->dp(be->self, &reqs[k], &res[k]); if (rc != 0) return rc; }
   return 0;
 }
+/* n independent questions: 0 = answered (res filled), EF_DP_PENDING (collect mode only) = noted, not answered,
+ * anything else = the backend failed */
+int ef_dp_many_ahead(ef_backend* be, const ef_dp_req* reqs, ef_dp_res* res, size_t n);     /* ef_fact.c */
+static inline int ef_dp_many(ef_backend* be, const ef_dp_req* reqs, ef_dp_res* res, size_t n) {
+  if (n == 0) return 0;
+  memset(res, 0, n * sizeof(ef_dp_res));
+  if (be->ahead && (be->ahead->n || be->ahead->collecting)) return ef_dp_many_ahead(be, reqs, res, n);
+  return ef_backend_ask(be, reqs, res, n);
+}
+static inline int ef_dp_one(ef_backend* be, const ef_dp_req* req, ef_dp_res* res) { return ef_dp_many(be, req, res, 1); }
+/* collect mode on / off; ef_ahead_flush asks what has been noted (one request) and keeps the answers */
+static inline void ef_ahead_collect(ef_backend* be, bool on) { if (be->ahead) be->ahead->collecting = on; }
+static inline bool ef_collecting(const ef_backend* be) { return be->ahead && be->ahead->collecting; }
+int ef_ahead_flush(ef_backend* be);
+extern int ef_ahead_on;            /* PINTRON_AHEAD=0 switches the asking ahead off (read once by ef_config_load) */
 
 /* ---- factorizations (include/types.h:160-180) ------------------------------------------------ */
 typedef struct { int EST_start, EST_end, GEN_start, GEN_end; } ef_factor;   /* 0-based inclusive */
@@ -344,8 +408,17 @@ void ef_refine_est_factorizations(const ef_seq* gen, ef_est* e, const ef_config*
 void ef_remove_factorizations_with_very_small_exons(ef_list* facts);
 void ef_remove_duplicated_factorizations(ef_list* facts);
 /* refine_intron (src/refine-intron.c:47-265) */
+typedef struct {                 /* the two strings of one intron's gap alignment (:60-116) */
+  char* seq_est; char* seq_gen; size_t le, lg;
+  int dsl_est, dsl_gen, deleted_intron_dim;
+  char buf_e[512], buf_g[512];
+} ef_gap_window;
+typedef struct { ef_gap_window w; ef_dp_res res; ef_factor donor, acceptor; } ef_gap_ahead;    /* ... asked before its turn (for these two exons), with the answer */
+void ef_gap_window_build(const ef_config* cfg, const ef_seq* gen, const ef_seq* est, const ef_factor* donor,
+                         const ef_factor* acceptor, ef_gap_window* w);
+void ef_gap_window_release(ef_gap_window* w);
 bool ef_refine_intron(const ef_config* cfg, const ef_seq* gen, const ef_seq* est, ef_factor* donor,
-                      ef_factor* acceptor, bool first_intron, ef_backend* be);
+                      ef_factor* acceptor, bool first_intron, ef_backend* be, ef_gap_ahead* ahead);
 /* intron classification (src/classify-intron.c:95): 0 = U12, 1 = U2, 2 = not classified */
 int ef_classify_intron(const ef_seq* gen, int start, int end);
 /* Burset frequencies (src/refine-intron.c:346-556) */
