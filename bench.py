@@ -11,7 +11,11 @@ step ends with the text of the six output files in host memory (what est-fact wr
 raw-multifasta-out.txt etc.) plus the packed factorization records; for N > 1 the packed records are
 gathered to rank 0 over RCCL inside the step.
 Not in the step: reading genomic.txt/ests.txt, strand/polyA preparation, index construction (done
-once, reported as load_s / index_s), writing the files.
+once, reported as load_s / index_s), writing the files.  What a user who brings a NEW batch gets is in
+the same line: `fresh_batch` (two distinct batches alternate; reading and preparing the input, building the index,
+uploading the patterns and the step are all inside the timed region, every output md5-checked against the
+reference's) and `oneshot` (one est-fact process, start to files on disk).  `other_workloads`: short legs of
+the other single-GPU shares of BASELINE.json (C5 share, C2), md5-checked, each with its own roofline.
 
 The output of the timed steps is checked: a bounded sample of the same workload is run through the
 reference CPU est-fact (oracle/_ref/est-fact-core, the cpu_baseline) and through this code, and the
@@ -165,6 +169,136 @@ def cpu_reference_all_cores(n_proc, base_seed, workload="C3", sample=CPU_SAMPLE)
     return wall if ok else None
 
 
+def kernels_of(stats, steps):
+    """per-kernel sums of the sessions' statistics, per step"""
+    kernels = {}
+    for s in (x for per_step in stats for x in per_step):
+        for k in range(s.n_kernels):
+            ks = s.kernels[k]
+            d = kernels.setdefault(ks.name.decode(), dict(ms=0.0, launches=0, jobs=0, cells=0, algo_bytes=0))
+            d["ms"] += ks.ms / steps; d["launches"] += ks.launches / steps
+            d["jobs"] += ks.jobs / steps; d["cells"] += ks.cells / steps
+            d["algo_bytes"] += ks.algo_bytes / steps
+    return kernels
+
+
+def roofline_of(kernels, n_est, wl):
+    """`roofline` object of the dominant kernel + the per-kernel table"""
+    name, dom = max(kernels.items(), key=lambda kv: kv[1]["ms"])
+    per_launch_ms = dom["ms"] / max(dom["launches"], 1)
+    ach = dom["algo_bytes"] / (dom["ms"] * 1e-3) / 1e9 if dom["ms"] and dom["algo_bytes"] else None
+    roof = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": ach / HBM_PEAK_GBS if ach else None,
+            "traffic": pmc_traffic(name, n_est / max(dom["launches"], 1), wl),
+            "avg_launch_ms": per_launch_ms, "launches_per_step": dom["launches"],
+            "algo_bytes_per_launch": dom["algo_bytes"] / max(dom["launches"], 1)}
+    # integer DP: the arithmetic bound is VALU issue, not MFMA.  Chip peak = 256 CU x 4 SIMD x 32
+    # lanes/cycle x 2.4 GHz lane-ops/s (MI355X_MICROARCH.md); a unit-cost cell needs >= 6 VALU ops
+    if dom["cells"] and dom["ms"]:
+        peak_cells = 256 * 4 * 32 * 2.4e9 / 6.0
+        ach_cells = dom["cells"] / (dom["ms"] * 1e-3)
+        roof["valu"] = {"achieved": ach_cells / 1e9, "peak": peak_cells / 1e9, "unit": "Gcells/s",
+                        "frac": ach_cells / peak_cells, "ops_per_cell_assumed": 6}
+    table = [{"name": n, "ms_per_step": round(k["ms"], 3), "launches": round(k["launches"], 1),
+              "jobs": int(k["jobs"]),
+              "algo_GBs": round(k["algo_bytes"] / (k["ms"] * 1e-3) / 1e9, 1) if k["ms"] and k["algo_bytes"] else None,
+              # cells (reference loop bounds) per second of this kernel's own stream time
+              "Gcells_s": round(k["cells"] / (k["ms"] * 1e-3) / 1e9, 1) if k["ms"] and k["cells"] else None}
+             for n, k in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"])]
+    return roof, table
+
+
+def gold_md5(name, n, seed):
+    gold_path = os.path.join(ROOT, "tests", "golden", "bench_md5.json")
+    if not os.path.exists(gold_path):
+        return None
+    return json.load(open(gold_path)).get("%s:%d:seed%d" % (name, n, seed))
+
+
+def other_workload_leg(L, synth, wl, steps=5, warmup=2):
+    """A short leg of another single-GPU share of BASELINE.json (its own session, closed afterwards): the same
+    measurement as the headline -- steps timed between synchronisations, output md5 against the reference's,
+    roofline of its dominant kernel -- in the default command's line, so that it is timed where the headline is."""
+    import torch
+    n, seed = PER_GPU[wl], synth.CONFIGS[wl]["seed"]
+    work = tempfile.mkdtemp(prefix="pintron_bench_%s_" % wl.lower())
+    try:
+        synth.write_files(synth.make(wl, n_est=n, seed=seed), work)
+        sess = Session(L, work)
+        try:
+            for _ in range(warmup):
+                sess.step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            stats = [[sess.step()] for _ in range(steps)]
+            torch.cuda.synchronize()
+            step_s = (time.perf_counter() - t0) / steps
+            st = stats[-1][0]
+            md5 = hashlib.md5(sess.records()).hexdigest()
+            gold = gold_md5(wl, sess.n_ests(), seed)
+            if gold and md5 != gold["raw-multifasta-out.txt"]:
+                raise SystemExit("bench: the timed step's raw-multifasta-out of %s differs from the reference's" % wl)
+            leg = {"workload": "%s: %d ESTs per GPU (seed %d)" % (wl, sess.n_ests(), seed), "steps": steps, "warmup": warmup,
+                   "ms_per_step": step_s * 1e3, "value": int(st.aligned) / step_s, "unit": "aligned ESTs/s",
+                   "input_ests_per_s": sess.n_ests() / step_s,
+                   "timed_output": {"md5": md5, "reference_md5": gold["raw-multifasta-out.txt"] if gold else None,
+                                    "identical_to_reference": bool(gold) and md5 == gold["raw-multifasta-out.txt"]},
+                   "phases_s": {"prefetch_pairings": st.prefetch_s, "workers_wall": st.workers_s,
+                                "host_cpu_per_thread": st.host_s / st.threads, "dp_batches_per_thread": st.dp_s / st.threads},
+                   "suspensions_per_est": st.suspensions_per_unit,
+                   "kernel_busy_union_ms": sum(x[0].dp_busy_union_ms for x in stats) / steps}
+            kernels = kernels_of(stats, steps)
+            if kernels:
+                leg["roofline"], leg["kernels"] = roofline_of(kernels, sess.n_ests(), wl)
+                leg["kernels"] = leg["kernels"][:4]
+            return leg
+        finally:
+            sess.close()
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
+def fresh_batch_leg(L, synth, wl, n, seeds, rounds=2):
+    """What a user who brings a new batch gets, inside one process: the batches of `seeds` alternate, and for each
+    of them reading + preparing the input, building the index, uploading the patterns, the step itself and the
+    release of the session are inside the timed region (the input files are written before).  Every output is
+    compared with the reference's checksum for that batch."""
+    import torch
+    dirs = []
+    for sd in seeds:
+        d = tempfile.mkdtemp(prefix="pintron_bench_fresh_")
+        synth.write_files(synth.make(wl, n_est=n, seed=sd), d)
+        dirs.append(d)
+    checks, times, aligned = [], [], 0
+    try:
+        torch.cuda.synchronize()
+        for r in range(rounds):
+            for sd, d in zip(seeds, dirs):
+                t0 = time.perf_counter()
+                sess = Session(L, d)
+                st = sess.step()
+                torch.cuda.synchronize()
+                t_step = time.perf_counter() - t0
+                md5 = hashlib.md5(sess.records()).hexdigest()          # (checking is outside the timed region)
+                sess.close()
+                times.append(t_step)
+                aligned = int(st.aligned)
+                gold = gold_md5(wl, n, sd)
+                ok = bool(gold) and md5 == gold["raw-multifasta-out.txt"]
+                if gold and not ok:
+                    raise SystemExit("bench: fresh batch %s:%d:seed%d differs from the reference's output" % (wl, n, sd))
+                checks.append({"batch": "%s:%d:seed%d" % (wl, n, sd), "seconds": t_step, "identical_to_reference": ok if gold else None})
+    finally:
+        for d in dirs:
+            shutil.rmtree(d, ignore_errors=True)
+    warm = times[len(seeds):] or times                 # the first visit of each batch also pages the code in
+    ms = 1e3 * sum(warm) / len(warm)
+    return {"ms_per_step": ms, "value": aligned / (ms * 1e-3), "unit": "aligned ESTs/s", "input_ests_per_s": n / (ms * 1e-3),
+            "what": "two distinct batches alternate; per batch: read + prepare ests.txt / genomic.txt, build the index, upload, "
+                    "one step, close -- all timed; the first round (first visit of each batch) is not averaged",
+            "batches": checks}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -174,6 +308,7 @@ def main():
     ap.add_argument("--genes", type=int, default=None, help="C4 only: number of genes (default 8 = BASELINE.json configs[3]; 1 = one GPU's share)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / parity leg")
     ap.add_argument("--no-oneshot", action="store_true", help="skip the one-process start-to-files measurement")
+    ap.add_argument("--no-extra", action="store_true", help="skip the fresh-batch leg and the other workloads' legs (N = 1, default workload only)")
     ap.add_argument("--workload", choices=("C2", "C3", "C4", "C5"), default="C3",
                     help="C3 (default, the metric's configuration): one 200 kb gene x --ests per GPU; "
                          "C4: 8 genes x 200 kb, --ests ESTs each (62 500 = BASELINE.json configs[3]), gene g on rank g mod N; "
@@ -265,17 +400,11 @@ def main():
         total_est, total_aligned = int(tn[0].item()), int(tn[1].item())
     if rank == 0:
         st = stats[-1][-1]
-        kernels = {}
-        for s in (x for per_step in stats for x in per_step):
-            for k in range(s.n_kernels):
-                ks = s.kernels[k]
-                d = kernels.setdefault(ks.name.decode(), dict(ms=0.0, launches=0, jobs=0, cells=0, algo_bytes=0))
-                d["ms"] += ks.ms / args.steps; d["launches"] += ks.launches / args.steps
-                d["jobs"] += ks.jobs / args.steps; d["cells"] += ks.cells / args.steps
-                d["algo_bytes"] += ks.algo_bytes / args.steps
+        kernels = kernels_of(stats, args.steps)
         step_s = dt / args.steps
         out = {
             "metric": "ESTs aligned/sec (whole node) + DP Mcells/s; bit-exact factorizations vs ref",
+            "metric_version": 2,          # since round 3 `value` counts ALIGNED ESTs (the metric's wording); input ESTs/s is beside it
             # the metric says "ESTs ALIGNED per second": the ESTs that got at least one factorization (what
             # processed-ests.txt lists); the input rate is beside it
             "value": total_aligned / step_s, "unit": "aligned ESTs/s", "input_ests_per_s": total_est / step_s,
@@ -299,6 +428,11 @@ def main():
             "phases_s": {"load_once": st.load_s, "index_once": st.index_s, "prefetch_pairings": st.prefetch_s,
                          "workers_wall": st.workers_s, "host_cpu_per_thread": st.host_s / st.threads,
                          "dp_batches_per_thread": st.dp_s / st.threads},
+            # times an EST gave up its thread to wait for answers from the device, per input EST
+            "suspensions_per_est": st.suspensions_per_unit,
+            # the kernels' ms_per_step below are sums over launches that overlap in time (several service streams);
+            # this is the time the device spent in DP kernels with all launches on one time line: <= ms_per_step
+            "kernel_busy_union_ms": sum(x.dp_busy_union_ms for per_step in stats for x in per_step) / args.steps,
         }
         # the text the LAST TIMED step left on rank 0 against the reference's checksum for the very same
         # batch (tools/make_bench_md5.py ran the reference object code on it in the build container)
@@ -333,27 +467,14 @@ def main():
                                   "what": "est-fact process start -> six files on disk, same %d-EST batch" % n_est,
                                   "md5_equals_timed_step": hashlib.md5(raw).hexdigest() == out["timed_output_md5"]}
         if kernels:
-            name, dom = max(kernels.items(), key=lambda kv: kv[1]["ms"])
-            per_launch_ms = dom["ms"] / max(dom["launches"], 1)
-            ach = dom["algo_bytes"] / (dom["ms"] * 1e-3) / 1e9 if dom["ms"] and dom["algo_bytes"] else None
-            out["roofline"] = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": ach / HBM_PEAK_GBS if ach else None,
-                               "traffic": pmc_traffic(name, n_est / max(dom["launches"], 1), wl),
-                               "avg_launch_ms": per_launch_ms, "launches_per_step": dom["launches"],
-                               "algo_bytes_per_launch": dom["algo_bytes"] / max(dom["launches"], 1)}
-            # integer DP: the arithmetic bound is VALU issue, not MFMA.  Chip peak = 256 CU x 4 SIMD x 32
-            # lanes/cycle x 2.4 GHz lane-ops/s (MI355X_MICROARCH.md); a unit-cost cell needs >= 6 VALU ops
-            if dom["cells"] and dom["ms"]:
-                peak_cells = 256 * 4 * 32 * 2.4e9 / 6.0
-                ach_cells = dom["cells"] / (dom["ms"] * 1e-3)
-                out["roofline"]["valu"] = {"achieved": ach_cells / 1e9, "peak": peak_cells / 1e9, "unit": "Gcells/s",
-                                           "frac": ach_cells / peak_cells, "ops_per_cell_assumed": 6}
-            out["kernels"] = [{"name": n, "ms_per_step": round(k["ms"], 3), "launches": round(k["launches"], 1),
-                               "jobs": int(k["jobs"]),
-                               "algo_GBs": round(k["algo_bytes"] / (k["ms"] * 1e-3) / 1e9, 1) if k["ms"] and k["algo_bytes"] else None,
-                               # cells (reference loop bounds) per second of this kernel's own stream time
-                               "Gcells_s": round(k["cells"] / (k["ms"] * 1e-3) / 1e9, 1) if k["ms"] and k["cells"] else None}
-                              for n, k in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"])]
+            out["roofline"], out["kernels"] = roofline_of(kernels, n_est, wl)
+        if world == 1 and wl == "C3" and args.ests == PER_GPU["C3"] and not args.no_extra:
+            # the resident sessions above are done: their HBM and threads go before the other legs start
+            for sess in sessions:
+                sess.close()
+            sessions = []
+            out["fresh_batch"] = fresh_batch_leg(L, synth, "C3", args.ests, [synth.CONFIGS["C3"]["seed"], 1003])
+            out["other_workloads"] = [other_workload_leg(L, synth, w2) for w2 in ("C5", "C2")]
         if world == 1 and not args.no_cpu:
             # bounded sample of the same workload: reference CPU est-fact vs this code, byte for byte
             cpu_n = min(CPU_SAMPLE_OF[wl], n_est)

@@ -301,6 +301,10 @@ typedef struct {
   int32_t  pad;
   uint64_t jobs, cells, algo_bytes;
   double   ms;              /* HIP-event duration of the last launch */
+  double   t0_ms;           /* its start on the device's time line: milliseconds since an event the library recorded
+                               when the first context of the process came up -- the same line for every context on
+                               the device, so the launches of several contexts can be merged into the time the device
+                               was busy (bench.py: kernel_busy_union_ms); -1 when timing is off */
 } pgpu_group_info;
 int pgpu_dp_plan_n_groups(const pgpu_dp_plan* plan);
 int pgpu_dp_plan_group_info(const pgpu_dp_plan* plan, int i, pgpu_group_info* out);

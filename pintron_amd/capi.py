@@ -26,7 +26,7 @@ class DpResult(C.Structure):
 class GroupInfo(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("kind", C.c_int32), ("pad", C.c_int32),
                 ("jobs", C.c_uint64), ("cells", C.c_uint64), ("algo_bytes", C.c_uint64),
-                ("ms", C.c_double)]
+                ("ms", C.c_double), ("t0_ms", C.c_double)]
 
 
 class PairingParams(C.Structure):
@@ -373,7 +373,7 @@ class Plan:
             g = GroupInfo()
             L.pgpu_dp_plan_group_info(self.h, i, C.byref(g))
             out.append(dict(name=g.name.decode(), kind=g.kind, jobs=g.jobs, cells=g.cells,
-                            algo_bytes=g.algo_bytes, ms=g.ms))
+                            algo_bytes=g.algo_bytes, ms=g.ms, t0_ms=g.t0_ms))
         return out
 
     def close(self):

@@ -9,6 +9,7 @@
 #include <time.h>
 #include <new>
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "pgpu_internal.h"
@@ -233,6 +234,23 @@ static bool aux_stream(pgpu_ctx* ctx, int i) {
   return true;
 }
 
+// One timing event per device, recorded once when the first context of the process comes up: the start of every
+// kernel group is reported relative to it (pgpu_group_info.t0_ms), so that a caller with several contexts
+// (the host program's service threads) can lay the launches of all of them on ONE time line and tell the time
+// the device was busy from the sum of the launches' durations.
+static hipEvent_t g_base_event[64];
+static std::mutex g_base_mu;
+static hipEvent_t base_event(int device, hipStream_t st) {
+  if (device < 0 || device >= 64) return nullptr;
+  std::lock_guard<std::mutex> lk(g_base_mu);
+  if (!g_base_event[device]) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) == hipSuccess && hipEventRecord(e, st) == hipSuccess && hipEventSynchronize(e) == hipSuccess) g_base_event[device] = e;
+    else if (e) hipEventDestroy(e);
+  }
+  return g_base_event[device];
+}
+
 extern "C" int pgpu_init(int device, pgpu_ctx** out) {
   if (!out) return PGPU_EINVAL;
   *out = nullptr;
@@ -264,6 +282,7 @@ extern "C" int pgpu_init(int device, pgpu_ctx** out) {
   { const char* f = getenv("PGPU_PACK"); if (f && atoi(f) == 0) ctx->packed = false; }
   { const char* f = getenv("PGPU_MERGED"); if (f && atoi(f) >= 0 && atoi(f) <= 2) ctx->merged = atoi(f); }
   { const char* f = getenv("PGPU_STREAMS"); const int v = f ? atoi(f) : 0; if (v >= 1 && v <= pgpu_ctx::NAUX) { ctx->n_aux = v; ctx->packed = false; } }
+  base_event(device, ctx->stream);
   *out = ctx;
   return PGPU_OK;
 }
@@ -307,6 +326,7 @@ struct Group {
   uint64_t cells_big = 0, algo_big = 0;     // share of the first n_big jobs
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   float ms = 0.f;
+  float t0_ms = -1.f;          // start of the last launch on the device's time line (base_event), -1: unknown
   std::string name;
 };
 
@@ -864,6 +884,7 @@ extern "C" int pgpu_dp_plan_sync(pgpu_ctx* ctx, pgpu_dp_plan* p) {
       float ms = 0.f;
       if (!g.launched) continue;            // everything of this group ran inside the merged launch
       if (g.ev0 && g.ev1 && hipEventElapsedTime(&ms, g.ev0, g.ev1) == hipSuccess) g.ms = ms;
+      if (g.ev0) { hipEvent_t b = base_event(ctx->device, ctx->stream); float t0 = 0.f; g.t0_ms = (b && hipEventElapsedTime(&t0, b, g.ev0) == hipSuccess) ? t0 : -1.f; }
       p->ms[g.kind] += g.ms;
       p->launches[g.kind] += 1;
     }
@@ -932,7 +953,7 @@ extern "C" int pgpu_dp_plan_group_info(const pgpu_dp_plan* p, int i, pgpu_group_
   memset(out, 0, sizeof(*out));
   snprintf(out->name, sizeof(out->name), "%s", g.name.c_str());
   out->kind = g.kind; out->jobs = g.count; out->cells = g.cells; out->algo_bytes = g.algo_bytes;
-  out->ms = g.ms;
+  out->ms = g.ms; out->t0_ms = g.t0_ms;
   return PGPU_OK;
 }
 

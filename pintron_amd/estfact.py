@@ -27,7 +27,8 @@ class SchedStats(C.Structure):
                                           "pairing_batches", "pairing_requests")] + \
                [(n, C.c_double) for n in ("load_s", "index_s", "prefetch_s", "workers_s", "host_s",
                                           "pairing_s", "dp_s")] + \
-               [("n_kernels", C.c_int), ("kernels", KernelStat * 64)]
+               [("n_kernels", C.c_int), ("kernels", KernelStat * 64), ("dp_busy_union_ms", C.c_double),
+                ("suspensions_per_unit", C.c_double)]
 
 
 def load_host_lib(path=None):

@@ -214,6 +214,7 @@ typedef struct service_thread {          /* one submitter: own context (stream, 
   struct service* sv;
   pgpu_ctx* ctx;
   ef_sched_stats stats;                  /* batches, jobs, kernel timings */
+  double* iv; size_t n_iv, cap_iv;       /* [start, end) of every timed kernel launch on the device's time line (ms) */
   double phase_s[6];                     /* idle, idle+merge, create, launch, sync, fetch+stats */
 } service_thread;
 
@@ -294,6 +295,7 @@ typedef struct worker {
   shared* sh;
   size_t index;                          /* of this worker among the step's workers */
   double sleep_bins[64];
+  size_t suspensions;                    /* times a fibre of this worker gave up the thread for an answer */
   ef_ctx sched;
   void* tsan_sched;          /* the worker thread's own context, for ThreadSanitizer */
   fiber* free_fibers;
@@ -319,6 +321,7 @@ static int fiber_dp_many(void* self, const ef_dp_req* reqs, ef_dp_res* res, size
   fiber* f = (fiber*)self;
   if (n == 0) return 0;
   f->reqs = reqs; f->ress = res; f->nreq = n; f->state = F_WAIT_DP;
+  ++f->w->suspensions;
   if (ef_prof_on) { ef_prof.susp[f->phase]++; ef_prof.jobs[f->phase] += n; }
   if (EF_TSAN) tsan_to(f->w->tsan_sched);
   ctx_switch(&f->ctx, &f->w->sched);
@@ -606,6 +609,10 @@ static void* service_main(void* arg) {
         snprintf(ks.name, sizeof ks.name, "%s", gi.name);
         ks.ms = gi.ms; ks.launches = 1; ks.jobs = gi.jobs; ks.cells = gi.cells; ks.algo_bytes = gi.algo_bytes;
         kstat_add(&me->stats, &ks);
+        if (gi.t0_ms >= 0 && gi.ms > 0) {
+          if (me->n_iv + 2 > me->cap_iv) { me->cap_iv = me->cap_iv ? me->cap_iv * 2 : 4096; me->iv = (double*)realloc(me->iv, me->cap_iv * sizeof(double)); }
+          me->iv[me->n_iv++] = gi.t0_ms; me->iv[me->n_iv++] = gi.t0_ms + gi.ms;
+        }
       }
     }
     if (plan) pgpu_dp_plan_destroy(me->ctx, plan);
@@ -1111,7 +1118,10 @@ ef_session* ef_session_open(int argc, char** argv) {
   if (!getenv("PINTRON_NO_PREFETCH") && in->n > 0) {
     /* ranges of whole units with about the same number of entries (the workers wait for the first one only;
      * small first ranges -- 1/32, 1/32, 1/16, then eighths -- were tried and lost 2.5 %: profiles/r03_sweep_chunks.txt) */
+    /* ... and a range is a dozen kernel launches and two waits: a small batch is cut into fewer (a thousand ESTs in ten
+     * ranges spent 24 of their 28 ms there) */
     size_t want = env_size("PINTRON_PRE_CHUNKS", 10);
+    if (!getenv("PINTRON_PRE_CHUNKS")) { const size_t by_size = sh->n_units / 4096 + 1; if (by_size < want) want = by_size; }
     if (want > PRE_CHUNKS) want = PRE_CHUNKS;
     sh->n_pre = sh->n_units < want ? (int)sh->n_units : (int)want;
     /* PINTRON_PRE_RAMP="w0,w1,...": relative sizes of the ranges (their number then follows from the list).  The
@@ -1311,6 +1321,11 @@ static run_mark run_mark_now(void) {
   return m;
 }
 
+static int cmp_interval(const void* x, const void* y) {
+  const double a = *(const double*)x, b = *(const double*)y;
+  return a < b ? -1 : a > b ? 1 : 0;
+}
+
 int ef_session_step(ef_session* s, ef_sched_stats* stats_out) {
   shared* sh = &s->sh;
   const double t0 = now_s();
@@ -1335,6 +1350,7 @@ int ef_session_step(ef_session* s, ef_sched_stats* stats_out) {
   for (int k = 0; k < sv->n_threads; ++k) {
     memset(&sv->threads[k].stats, 0, sizeof(ef_sched_stats));
     memset(sv->threads[k].phase_s, 0, sizeof sv->threads[k].phase_s);
+    sv->threads[k].n_iv = 0;
     sv->threads[k].sv = sv;
   }
   int sv_started = 0;
@@ -1383,6 +1399,23 @@ int ef_session_step(ef_session* s, ef_sched_stats* stats_out) {
     st.dp_batches += ss->dp_batches; st.dp_jobs += ss->dp_jobs;
     for (int k = 0; k < ss->n_kernels; ++k) kstat_add(&st, &ss->kernels[k]);
   }
+  {                                       /* the launches of all service threads on one time line */
+    size_t n = 0;
+    for (int t = 0; t < sv_started; ++t) n += sv->threads[t].n_iv / 2;
+    if (n) {
+      double* a = (double*)malloc(2 * n * sizeof(double));
+      size_t k = 0;
+      for (int t = 0; t < sv_started; ++t) { memcpy(a + k, sv->threads[t].iv, sv->threads[t].n_iv * sizeof(double)); k += sv->threads[t].n_iv; }
+      qsort(a, n, 2 * sizeof(double), cmp_interval);
+      double busy = 0, lo = a[0], hi = a[1];
+      for (size_t i = 1; i < n; ++i) {
+        if (a[2 * i] > hi) { busy += hi - lo; lo = a[2 * i]; hi = a[2 * i + 1]; }
+        else if (a[2 * i + 1] > hi) hi = a[2 * i + 1];
+      }
+      st.dp_busy_union_ms = busy + (hi - lo);
+      free(a);
+    }
+  }
   for (size_t t = 0; t < w_started; ++t) {
     st.units += ws[t].stats.units;
     st.pairing_batches += ws[t].stats.pairing_batches; st.pairing_requests += ws[t].stats.pairing_requests;
@@ -1421,6 +1454,7 @@ int ef_session_step(ef_session* s, ef_sched_stats* stats_out) {
       kstat_add(&st, &ks);
     }
   }
+  { size_t su = 0; for (size_t t = 0; t < w_started; ++t) su += ws[t].suspensions; st.suspensions_per_unit = sh->n_units ? (double)su / (double)sh->n_units : 0.0; }
   st.load_s = s->load_s; st.index_s = s->index_s; st.prefetch_s = s->pre_wall; st.workers_s = now_s() - t1;
   for (size_t u = 0; u < sh->n_units; ++u) if (sh->units[u].len[1]) ++st.aligned;
   if (stats_out) *stats_out = st;
@@ -1586,6 +1620,7 @@ void ef_session_close(ef_session* s) {
     sh->fiber_pool = nx;
   }
   free(sh->units);
+  for (int k = 0; k < MAX_SERVICES; ++k) { free(sh->svc.threads[k].iv); sh->svc.threads[k].iv = NULL; sh->svc.threads[k].n_iv = sh->svc.threads[k].cap_iv = 0; }
   for (int c = 0; c < PRE_CHUNKS && s->ctx0; ++c) {
     free(sh->pre_tri[c]); free(sh->pre_first[c]);
     if (sh->pre_meg[c] && sh->pre_own[c]) pgpu_host_free(s->ctx0, sh->pre_meg[c]);

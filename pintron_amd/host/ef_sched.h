@@ -17,6 +17,11 @@ typedef struct {
   double host_s, pairing_s, dp_s;         /* summed over threads: fibres / pairing batches / DP batches */
   int n_kernels;                          /* filled when PINTRON_KERNEL_TIMING is set */
   ef_kernel_stat kernels[EF_MAX_KERNELS];
+  /* PINTRON_KERNEL_TIMING: the time the device spent in the DP batches' kernels with the launches of all service
+   * threads laid on one time line (union of their [start, end) intervals) -- the kernels' `ms` are sums over
+   * launches that overlap in time, this is what can be compared with the step's wall time; 0 = not measured */
+  double dp_busy_union_ms;
+  double suspensions_per_unit;            /* times an EST gave up its thread to wait for answers, per input EST */
 } ef_sched_stats;
 
 /* session = inputs of the current directory loaded, genomic index and all prepared sequences
