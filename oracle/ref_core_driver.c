@@ -89,6 +89,69 @@ void ref_core_default_config(struct _configuration* c) {
   c->max_single_factorization_time = 900;
 }
 
+/* TEST INFRASTRUCTURE: the options of the run, for the tests that pin est-fact under non-default options.
+ * configuration.c (which needs the gengetopt-generated options.h) is not built here, so what it does with the
+ * parsed options is restated: `ref-options.ini` in the current directory (or the file PINTRON_REF_OPTIONS names),
+ * in the format the reference itself saves its configuration in (config-dump.ini, written by
+ * cmdline_parser_file_save: `long-option-name="value"`, a flag as its bare name), is applied over the defaults
+ * with the checks of check_and_copy (src/configuration.c:45-176); a value it would refuse ends the program with
+ * status 3.  The option -> field mapping is check_and_copy's. */
+static void bad_option(const char* name, const char* value) {
+  fprintf(stderr, "est-fact-core: option '%s' refused (value '%s')\n", name, value ? value : "");
+  exit(3);
+}
+static void ref_core_config_from_file(struct _configuration* c, const char* path) {
+  FILE* f = fopen(path, "r");
+  if (!f) return;
+  char line[1024];
+  while (fgets(line, sizeof line, f)) {
+    char* p = line;
+    while (*p == ' ' || *p == '\t') ++p;
+    if (*p == '#' || *p == '\n' || *p == '\0') continue;
+    char* e = p;
+    while (*e && *e != '=' && *e != ' ' && *e != '\t' && *e != '\n') ++e;
+    char name[128];
+    snprintf(name, sizeof name, "%.*s", (int)(e - p), p);
+    while (*e == ' ' || *e == '\t' || *e == '=') ++e;
+    char* v = e;
+    size_t vl = strlen(v);
+    while (vl && (v[vl - 1] == '\n' || v[vl - 1] == '\r' || v[vl - 1] == ' ' || v[vl - 1] == '\t')) v[--vl] = '\0';
+    if (vl >= 2 && v[0] == '"' && v[vl - 1] == '"') { v[vl - 1] = '\0'; ++v; }
+    const long iv = strtol(v, NULL, 10);
+    const double dv = strtod(v, NULL);
+#define OPT(n) (strcmp(name, n) == 0)
+    if (OPT("config-file")) continue;
+    else if (OPT("min-factor-length")) { if (iv <= 0) bad_option(name, v); c->min_factor_len = (unsigned)iv; }
+    else if (OPT("min-intron-length")) { if (iv < 0) bad_option(name, v); c->min_intron_length = (int)iv; }
+    else if (OPT("max-intron-length")) { if (iv < 0) bad_option(name, v); c->max_intron_length = (int)iv; }
+    else if (OPT("min-string-depth-rate")) { if (dv < 0.0 || dv > 1.0) bad_option(name, v); c->min_string_depth_rate = dv; }
+    else if (OPT("max-prefix-discarded-rate")) { if (dv < 0.0 || dv > 1.0) bad_option(name, v); c->max_prefix_discarded_rate = dv; }
+    else if (OPT("max-suffix-discarded-rate")) { if (dv < 0.0 || dv > 1.0) bad_option(name, v); c->max_suffix_discarded_rate = dv; }
+    else if (OPT("max-prefix-discarded")) { if (iv < 0) bad_option(name, v); c->max_prefix_discarded = (int)iv; }
+    else if (OPT("max-suffix-discarded")) { if (iv < 0) bad_option(name, v); c->max_suffix_discarded = (int)iv; }
+    else if (OPT("min-distance-of-splice-sites")) { if (iv < 0) bad_option(name, v); c->max_site_difference = (unsigned)iv; }
+    else if (OPT("max-no-of-factorizations")) { if (iv < 0) bad_option(name, v); c->max_number_of_factorizations = (int)iv; }
+    else if (OPT("max-difference-of-coverage")) { if (dv < 0.0 || dv > 1.0) bad_option(name, v); c->max_coverage_diff = dv; }
+    else if (OPT("max-difference-of-no-of-exons")) { if (iv < -1) bad_option(name, v); c->max_exonNUM_diff = (int)iv; }
+    else if (OPT("max-difference-of-gap-length")) { if (iv < -1) bad_option(name, v); c->max_gapLength_diff = (int)iv; }
+    else if (OPT("complexity-threshold")) { if (dv <= 0.0) bad_option(name, v); c->complexity_threshold = dv; }
+    else if (OPT("retain-externals")) {
+      if (!strcmp(v, "true")) c->retain_externals = 1; else if (!strcmp(v, "false")) c->retain_externals = 0; else bad_option(name, v);
+    }
+    else if (OPT("max-pairings-in-CMEG")) { if (iv < 0) bad_option(name, v); c->max_pairings_in_MEG = (unsigned)iv; }
+    else if (OPT("max-shortest-pairing-frequence")) { if (dv < 0.0 || dv > 1.0) bad_option(name, v); c->max_freq_shortest_pairing = dv; }
+    else if (OPT("suff-pref-length-intron")) { if (iv <= 0) bad_option(name, v); c->suffpref_length_for_intron = (int)iv; }
+    else if (OPT("suff-pref-length-est")) { if (iv <= 0) bad_option(name, v); c->suffpref_length_on_est = (int)iv; }
+    else if (OPT("suff-pref-length-genomic")) { if (iv <= 0) bad_option(name, v); c->suffpref_length_on_gen = (int)iv; }
+    else if (OPT("no-transitive-reduction")) c->trans_red = false;
+    else if (OPT("no-short-edge-compaction")) c->short_edge_comp = false;
+    else if (OPT("max-single-factorization-time")) { if (iv < 0) bad_option(name, v); c->max_single_factorization_time = (unsigned)iv; }
+    else { fprintf(stderr, "est-fact-core: unknown option '%s' in %s\n", name, path); exit(3); }
+#undef OPT
+  }
+  fclose(f);
+}
+
 static char* dup_or_null(const char* s) { return s ? alloc_and_copy(s) : NULL; }
 
 /* main-est-fact.c:70-88: the reverse-complement sibling of a sequence whose strand is not fixed;
@@ -211,6 +274,7 @@ int main(void) {
   ref_core_default_config(&cfg);
   const char* l = getenv("PINTRON_REF_MIN_FACTOR_LEN");
   if (l && atoi(l) > 0) cfg.min_factor_len = (unsigned)atoi(l);
+  ref_core_config_from_file(&cfg, getenv("PINTRON_REF_OPTIONS") ? getenv("PINTRON_REF_OPTIONS") : "ref-options.ini");
 
   /* main-est-fact.c:116-135 */
   FILE* fgen = must_open("genomic.txt", "r");
