@@ -8,8 +8,9 @@
  * PINTRON_RECORDS_FILE=<path> is set, sessions hand it out as output 6, and `bench.py --gpus N`
  * gathers it to rank 0 over RCCL.
  *
- * Layout (little-endian, unaligned), one group per EST that has at least one factorization, in
- * input order:
+ * Layout (little-endian, unaligned), one group per ALIGNED EST -- per entry of processed-ests.txt, in the
+ * same (input) order; n_factorizations is 0 for an EST whose factorizations --retain-externals=false all
+ * dropped (src/io-multifasta.c:204,217-222: it has no line in raw-multifasta-out.txt) --:
  *   u32 est_index            position of the EST in ests.txt (0-based)
  *   u32 n_factorizations
  *   per factorization:  u8 polya, u8 polyad, u16 n_exons,

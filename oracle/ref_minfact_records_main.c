@@ -53,6 +53,7 @@ plist factorizations_from_records(const void* records, size_t len, const char* p
     while (*ep && *ep != '\n') ++ep;
     if (*ep) ++ep;
     if (hl == 0 || h[0] != '>') { fprintf(stderr, "processed-ests.txt does not match the records\n"); exit(1); }
+    if (e.n_factorizations == 0) continue;      /* an aligned EST with nothing to print (--retain-externals=false): not in the text either */
     char* id = (char*)malloc(hl); memcpy(id, h + 1, hl - 1); id[hl - 1] = '\0';
     /* read_factorizations starts a new EST when the header differs from the previous one */
     if (cur == NULL || strcmp(cur->info->EST_id, id) != 0) {

@@ -46,7 +46,7 @@ void ef_write_multifasta_output(const ef_seq* gen, const ef_est* e, ef_sink* f, 
 
 /* The same factorizations as packed binary records, for consumers that do not want to parse text
  * (min-factorization reads "%d %d %d %d", #polya=, #polyad= and groups by
- * header, src/io-factorizations.c:128-231).  Little-endian, per EST with at least one record:
+ * header, src/io-factorizations.c:128-231).  Little-endian, per aligned EST (= per entry of processed-ests.txt):
  *   u32 est_index (position in ests.txt), u32 n_factorizations, then per factorization
  *   u8 polya, u8 polyad, u16 n_exons, then per exon 4 x i32: EST_start, EST_end, GEN_start, GEN_end
  *   exactly as printed (1-based, genomic coordinates shifted by the removed N prefix).
@@ -83,10 +83,11 @@ void ef_write_factorization_records(const ef_seq* gen, const ef_est* e, ef_sink*
     head[0] = (unsigned char)polya; head[1] = (unsigned char)polyad; memcpy(head + 2, &n_exons, 2);
     ++n_fact;
   }
-  if (n_fact) {
-    memcpy(b, &est_index, 4); memcpy(b + 4, &n_fact, 4);
-    ef_sink_write(f, (const char*)b, len);
-  }
+  /* one group per ALIGNED EST = per entry of processed-ests.txt, also when --retain-externals=false left none of
+   * its factorizations to print (n_factorizations 0): the groups and the entries of that file stay in step, which
+   * is what lets a reader print the text from the two (ef_records.c) */
+  memcpy(b, &est_index, 4); memcpy(b + 4, &n_fact, 4);
+  ef_sink_write(f, (const char*)b, len);
   free(b);
 }
 

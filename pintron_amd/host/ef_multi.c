@@ -129,8 +129,17 @@ static void* watchdog_main(void* arg) {
   return NULL;
 }
 
-/* what a rank tells the others after its step: status, then the byte sizes of its six files */
-typedef struct { uint64_t failed; uint64_t size[6]; } shard_note;
+/* what a rank tells the others after its step: status, the byte sizes of its six files (size[0], the text of
+ * raw-multifasta-out, is not sent: rank 0 prints it from the records) and of its packed factorization records */
+typedef struct { uint64_t failed; uint64_t size[6]; uint64_t rec_size; } shard_note;
+
+/* rank 0: the raw-multifasta-out text of every rank's records, printed side by side (one thread per part) */
+typedef struct { const ef_seq* gen; const char* rec; size_t rl; const char* pests; size_t pl; ef_sink out; int rc; } print_job;
+static void* print_main(void* arg) {
+  print_job* j = (print_job*)arg;
+  j->rc = ef_raw_text_from_records(j->gen, j->rec, j->rl, j->pests, j->pl, &j->out);
+  return NULL;
+}
 
 /* this rank's part of a side file, in place (the file was created and sized by rank 0) */
 static int write_part(const char* path, uint64_t off, const char* data, size_t len) {
@@ -190,15 +199,17 @@ static int run_shard(int argc, char** argv, int rank, int world, const char* id_
   const char* dsw = getenv("PINTRON_SHARD_DIAGNOSTICS");
   const int diagnostics = !(dsw && dsw[0] == '0' && dsw[1] == '\0');
   char* text[6] = { NULL, NULL, NULL, NULL, NULL, NULL };
+  char* records = NULL;
   shard_note mine;
   memset(&mine, 0, sizeof mine);
   mine.failed = rc != 0;
-  for (int k = 0; k < 6 && rc == 0; ++k) {
+  for (int k = 1; k < 6 && rc == 0; ++k) {              /* (0, the text of raw-multifasta-out, stays where it is) */
     if (k >= 2 && !diagnostics) continue;
     size_t len = 0;
     text[k] = ef_session_output(s, k, &len);
     mine.size[k] = len;
   }
+  if (rc == 0) { size_t len = 0; records = ef_session_output(s, 6, &len); mine.rec_size = len; }
   /* 1. status and sizes, to every rank */
   shard_note* notes = (shard_note*)calloc((size_t)world, sizeof(shard_note));
   int grc = pgpu_allgather(ctx, comm, &mine, sizeof mine, notes);
@@ -206,28 +217,48 @@ static int run_shard(int argc, char** argv, int rank, int world, const char* id_
   int any_failed = rc != 0;
   for (int r = 0; r < world && grc == PGPU_OK; ++r) if (notes[r].failed) { any_failed = 1; if (rc == 0) fprintf(stderr, "* FATAL rank %d: rank %d failed, giving up\n", rank, r); }
   if (!any_failed) {
-    /* 2. the records and the processed ESTs: one payload per rank = [raw-multifasta text | processed-ests text] */
-    const uint64_t pay = mine.size[0] + mine.size[1];
+    /* 2. ONE gather: per rank [packed factorization records | processed-ests text] -- what north_star calls "the
+     * per-EST factorization records" and the sequences they refer to.  raw-multifasta-out.txt is printed on rank 0
+     * from them (ef_records.c): the text itself, eight times the bytes, does not travel. */
+    const uint64_t pay = mine.rec_size + mine.size[1];
     char* send = (char*)malloc(pay + 1);
-    memcpy(send, text[0], mine.size[0]); memcpy(send + mine.size[0], text[1], mine.size[1]);
+    memcpy(send, records, mine.rec_size); memcpy(send + mine.rec_size, text[1], mine.size[1]);
     uint64_t total = 0;
-    for (int r = 0; r < world; ++r) total += notes[r].size[0] + notes[r].size[1];
+    for (int r = 0; r < world; ++r) total += notes[r].rec_size + notes[r].size[1];
     char* all = rank == 0 ? (char*)malloc(total + 1) : NULL;
     uint64_t* counts = (uint64_t*)calloc((size_t)world, sizeof(uint64_t));
     grc = pgpu_gather(ctx, comm, send, pay, all, rank == 0 ? total : 0, counts);
     if (grc != PGPU_OK) { fprintf(stderr, "* FATAL rank %d: gather: %s\n", rank, pgpu_last_error(ctx)); rc = 1; }
+    if (getenv("PINTRON_VERBOSE"))
+      fprintf(stderr, "* rank %d/%d: gather payload %llu bytes (records %llu + processed ESTs %llu); rank 0 receives %llu\n", rank, world,
+              (unsigned long long)pay, (unsigned long long)mine.rec_size, (unsigned long long)mine.size[1], (unsigned long long)total);
     if (rank == 0 && grc == PGPU_OK) {
-      for (int k = 0; k < 2 && rc == 0; ++k) {
-        FILE* f = fopen(names[k], "wb");
-        if (!f) { fprintf(stderr, "* FATAL cannot create %s\n", names[k]); rc = 1; break; }
-        uint64_t at = 0;
-        for (int r = 0; r < world; ++r) {
-          const char* part = all + at + (k == 1 ? notes[r].size[0] : 0);
-          if (notes[r].size[k] && fwrite(part, 1, notes[r].size[k], f) != notes[r].size[k]) rc = 1;
-          at += notes[r].size[0] + notes[r].size[1];
-        }
-        if (fclose(f) != 0) rc = 1;
+      print_job* pj = (print_job*)calloc((size_t)world, sizeof(print_job));
+      pthread_t* pth = (pthread_t*)calloc((size_t)world, sizeof(pthread_t));
+      char* started = (char*)calloc((size_t)world, 1);
+      uint64_t at = 0;
+      for (int r = 0; r < world; ++r) {
+        pj[r].gen = (const ef_seq*)ef_session_genomic(s); pj[r].rec = all + at; pj[r].rl = (size_t)notes[r].rec_size;
+        pj[r].pests = all + at + notes[r].rec_size; pj[r].pl = (size_t)notes[r].size[1];
+        at += notes[r].rec_size + notes[r].size[1];
+        started[r] = r + 1 < world && pthread_create(&pth[r], NULL, print_main, &pj[r]) == 0;
+        if (!started[r]) print_main(&pj[r]);
       }
+      for (int r = 0; r < world; ++r) if (started[r]) pthread_join(pth[r], NULL);
+      FILE* f = fopen(names[0], "wb");
+      if (!f) { fprintf(stderr, "* FATAL cannot create %s\n", names[0]); rc = 1; }
+      for (int r = 0; r < world && f; ++r) {
+        if (pj[r].rc != 0) { fprintf(stderr, "* FATAL the records of rank %d do not fit its processed ESTs\n", r); rc = 1; }
+        else if (pj[r].out.len && fwrite(pj[r].out.mem, 1, pj[r].out.len, f) != pj[r].out.len) rc = 1;
+      }
+      if (f && fclose(f) != 0) rc = 1;
+      for (int r = 0; r < world; ++r) free(pj[r].out.mem);
+      f = rc == 0 ? fopen(names[1], "wb") : NULL;
+      if (rc == 0 && !f) { fprintf(stderr, "* FATAL cannot create %s\n", names[1]); rc = 1; }
+      for (int r = 0; r < world && f; ++r)
+        if (pj[r].pl && fwrite(pj[r].pests, 1, pj[r].pl, f) != pj[r].pl) rc = 1;
+      if (f && fclose(f) != 0) rc = 1;
+      free(pj); free(pth); free(started);
     }
     free(counts); free(all); free(send);
     /* 3. the side files, in place: rank 0 creates them at their final size, then every rank writes its part */
@@ -260,6 +291,7 @@ static int run_shard(int argc, char** argv, int rank, int world, const char* id_
   if (getenv("PINTRON_VERBOSE"))
     fprintf(stderr, "* rank %d/%d: %zu ESTs (%zu aligned), %zu DP jobs\n", rank, world, st.units, st.aligned, st.dp_jobs);
   for (int k = 0; k < 6; ++k) free(text[k]);
+  free(records);
   pgpu_comm_destroy(ctx, comm);
   ef_session_close(s);
   return (rc || any_failed) ? 1 : 0;

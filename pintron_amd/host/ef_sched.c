@@ -1595,6 +1595,7 @@ char* ef_session_records(ef_session* s, size_t* len) { return ef_session_output(
 
 size_t ef_session_n_ests(const ef_session* s) { return s->sh.n_units; }
 struct pgpu_ctx* ef_session_context(ef_session* s) { return s->ctx0; }
+const void* ef_session_genomic(ef_session* s) { return s->in.gen; }
 
 void ef_session_close(ef_session* s) {
   if (!s) return;

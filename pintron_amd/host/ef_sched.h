@@ -47,6 +47,7 @@ void ef_session_close(ef_session* s);
  * g mod N, each leaving its files in its own directory. */
 int ef_main_multi(int argc, char** argv);
 struct pgpu_ctx* ef_session_context(ef_session* s);
+const void* ef_session_genomic(ef_session* s);       /* the genomic record (const ef_seq*, estfact.h) of the session */
 
 /* set by a program that ends right after ef_run_batched: the session is not taken apart */
 extern int ef_leave_without_cleanup;

@@ -436,6 +436,8 @@ uint32_t ef_compute_edit_distance(ef_backend* be, const char* a, size_t la, cons
 /* write_multifasta_output (src/io-multifasta.c:187-246) */
 void ef_write_multifasta_output(const ef_seq* gen, const ef_est* e, ef_sink* f, char retain_externals);
 void ef_write_factorization_records(const ef_seq* gen, const ef_est* e, ef_sink* f, char retain_externals, uint32_t est_index);
+/* ... and the text back from the records + the processed-ests text of the same ESTs (ef_records.c); 0, or -1 when they do not fit */
+int ef_raw_text_from_records(const ef_seq* gen, const void* rec, size_t rl, const char* pests, size_t pl, ef_sink* out);
 /* compute_est_fact (src/compute-est-fact.c:192-293) without the diagnostics side files */
 typedef struct { ef_sink *fmeg, *fpmeg, *ftmeg, *fintronic; } ef_side_files;
 ef_est* ef_compute_est_fact(const ef_seq* gen, const ef_seq* est, ef_backend* be, const ef_config* cfg,

@@ -244,6 +244,31 @@ def test_c_program_shards_one_gene_over_ranks(bins, tmp_path):
     assert not [p for p in os.listdir(tmp_path) if p.startswith(".pintron-comm-id")], "rendezvous files left behind"
 
 
+def test_c_program_gathers_records_not_text(bins, tmp_path):
+    """What travels in `est-fact --gpus=N` is [packed factorization records | processed ESTs] per rank; rank 0
+    prints raw-multifasta-out.txt from them (pintron_amd/host/ef_records.c, the format of
+    src/io-multifasta.c:187-229).  The gathered bytes are reported under PINTRON_VERBOSE: far fewer than the text;
+    and the printing obeys --retain-externals=false like the single process (src/io-multifasta.c:204,217-222)."""
+    import re
+    from pintron_amd import synth
+    w = synth.make("C2", n_est=300, seed=21)
+    for opts, tag in (([], "dflt"), (["--retain-externals=false"], "noext")):
+        one, many = tmp_path / (tag + "1"), tmp_path / (tag + "3")
+        for d in (one, many):
+            synth.write_files(w, str(d))
+        e = dict(os.environ, TMPDIR=str(tmp_path), PINTRON_THREADS="2", PINTRON_VERBOSE="1")
+        subprocess.run([bins["estfact_sched_check"]] + opts, cwd=one, env=e, check=True, stderr=subprocess.DEVNULL)
+        r = subprocess.run([bins["estfact_sched_check"], "--gpus=3"] + opts, cwd=many, env=e, check=True, stderr=subprocess.PIPE, text=True)
+        for f in FILES:
+            assert filecmp.cmp(one / f, many / f, shallow=False), (tag, f)
+        got = [int(m.group(1)) for m in re.finditer(r"rank 0 receives (\d+)", r.stderr)]
+        assert len(got) == 3 and len(set(got)) == 1
+        raw, pests = os.path.getsize(one / "raw-multifasta-out.txt"), os.path.getsize(one / "processed-ests.txt")
+        assert raw > 10000
+        assert got[0] - pests < raw // 6, "the records are a fraction of the text"
+        assert got[0] < raw + pests
+
+
 def test_c_program_ranks_read_only_their_part_of_the_file(bins, tmp_path):
     """A rank of a sharded run reads and parses only its byte range of ests.txt, cut at record starts by a rule
     every rank applies to the file on its own (ef_read_multifasta_part): whatever the layout -- text before the

@@ -21,7 +21,7 @@ OUT = os.path.join(ROOT, "gpurun_out", "scratch", "tsan")
 shutil.rmtree(OUT, ignore_errors=True)
 os.makedirs(OUT)
 host = [os.path.join(H, f) for f in ("ef_io.c", "ef_meg.c", "ef_config.c", "ef_fact.c", "ef_refine_intron.c",
-                                      "ef_factref.c", "ef_classify.c", "ef_estfact.c")]
+                                      "ef_factref.c", "ef_classify.c", "ef_estfact.c", "ef_records.c")]
 orc = [os.path.join(O, f) for f in ("pairing_oracle.c", "dp_oracle.c", "dp_oracle_batch.c")]
 exe = os.path.join(OUT, "estfact_sched_tsan")
 subprocess.run(["gcc", "-std=gnu99", "-O1", "-g", "-fsanitize=thread", "-fno-omit-frame-pointer", "-pthread", "-o", exe,
