@@ -336,7 +336,11 @@ def main():
     os.environ["PINTRON_GPU_DEVICE"] = str(dev_index)
     os.environ.setdefault("PINTRON_KERNEL_TIMING", "1")
     dist = None
-    torch.cuda.set_device(dev_index)
+    # (without a GPU only the CPU tests get past the next lines -- gloo + the check build of the host library,
+    # PINTRON_ESTFACT_LIB; the product library refuses to open a session when there is no gfx950 device)
+    have_gpu = backend == "nccl" or torch.cuda.is_available()
+    if have_gpu:
+        torch.cuda.set_device(dev_index)
     if world > 1:
         import torch.distributed as dist
         if backend == "nccl":
@@ -353,9 +357,8 @@ def main():
     else:
         # C4: eight independent est-fact problems; gene g runs on rank g mod N (strong scaling)
         n_genes = args.genes or synth.CONFIGS["C4"]["genes"]
+        # (a rank without a gene -- fewer genes than ranks -- takes part in every collective with nothing to send)
         genes = [("C4", synth.CONFIGS["C4"]["seed"] + g, args.ests) for g in range(n_genes) if g % world == rank]
-        if not genes:
-            raise SystemExit("bench: rank %d has no gene (%d genes over %d ranks)" % (rank, n_genes, world))
     works, sessions = [], []
     for name, seed, n in genes:
         work = tempfile.mkdtemp(prefix="pintron_bench_r%d_" % rank)
@@ -364,21 +367,27 @@ def main():
         sessions.append(Session(L, work))
     n_est = sum(s.n_ests() for s in sessions)
 
+    gathered = {}
+
     def step():
         sts = [sess.step() for sess in sessions]
         if world > 1:
             # the only exchange of the sharded path: the factorization records of the rank's ESTs
             # (packed: 16 B per exon + 4 B per factorization, everything downstream stages parse out
             # of raw-multifasta-out.txt) -> rank 0 over RCCL.  ONE gather per step whatever the number
-            # of genes on the rank (ranks with different gene counts issue the same collectives)
+            # of genes on the rank (ranks with different gene counts, or none, issue the same collectives)
             recs = [sess.output_tensor(RECORDS) for sess in sessions]
-            gather_tensor(recs[0] if len(recs) == 1 else torch.cat(recs), dist, rank, world, xdev)
+            mine = torch.empty(0, dtype=torch.uint8) if not recs else (recs[0] if len(recs) == 1 else torch.cat(recs))
+            parts = gather_tensor(mine, dist, rank, world, xdev)
+            if parts is not None:
+                gathered["parts"] = parts
         return sts
 
     def fence():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if have_gpu:
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
@@ -393,7 +402,7 @@ def main():
         dt = float(tt.item())
 
     total_est = n_est
-    n_aligned = total_aligned = int(sum(x.aligned for x in stats[-1]))
+    n_aligned = total_aligned = int(sum(x.aligned for x in stats[-1])) if stats[-1] else 0
     if world > 1:
         tn = torch.tensor([n_est, n_aligned], dtype=torch.int64, device=xdev)
         dist.all_reduce(tn)
@@ -466,6 +475,14 @@ def main():
                 out["oneshot"] = {"seconds": t_one, "ESTs_per_s": n_est / t_one,
                                   "what": "est-fact process start -> six files on disk, same %d-EST batch" % n_est,
                                   "md5_equals_timed_step": hashlib.md5(raw).hexdigest() == out["timed_output_md5"]}
+        if world > 1 and "parts" in gathered:
+            # what rank 0 holds after the last step's gather: the record groups of every rank (one per aligned EST)
+            from pintron_amd.estfact import parse_factorization_records
+            sizes = [int(p.numel()) for p in gathered["parts"]]
+            groups = sum(len(parse_factorization_records(bytes(p.cpu().numpy().tobytes()))) for p in gathered["parts"])
+            out["gathered"] = {"bytes_per_rank": sizes, "est_groups": groups, "equals_aligned": groups == total_aligned}
+            if groups != total_aligned:
+                raise SystemExit("bench: rank 0 received %d record groups for %d aligned ESTs" % (groups, total_aligned))
         if kernels:
             out["roofline"], out["kernels"] = roofline_of(kernels, n_est, wl)
         if world == 1 and wl == "C3" and args.ests == PER_GPU["C3"] and not args.no_extra:

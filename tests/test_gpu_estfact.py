@@ -347,6 +347,23 @@ def test_gather_entry_point_on_rccl(exe, tmp_path):
     assert out.returncode == 0 and "gather ok" in out.stdout, out.stderr[-2000:]
 
 
+def test_more_ranks_than_gpus_is_refused_before_anything_starts(exe, tmp_path):
+    """`est-fact --gpus=8` on a box with fewer GPUs: refused by the parent before a rank is started or the GPU runtime
+    is touched (pintron_amd/host/ef_multi.c: visible_gpu_count), with a message that says why; nothing is written."""
+    import time
+    import torch
+    have = torch.cuda.device_count()
+    if have >= 8:
+        pytest.skip("this box has 8 GPUs")
+    from pintron_amd import synth
+    synth.write_files(synth.make("C2", n_est=50), str(tmp_path))
+    t0 = time.time()
+    r = subprocess.run([exe, "--gpus=8"], cwd=tmp_path, stderr=subprocess.PIPE, text=True, timeout=60)
+    assert r.returncode != 0 and time.time() - t0 < 5
+    assert "--gpus=8" in r.stderr and "visible" in r.stderr
+    assert not os.path.exists(tmp_path / "raw-multifasta-out.txt")
+
+
 def test_c_program_many_genes_and_shards(exe, tmp_path):
     """`est-fact --genes=FILE` (gene g on rank g mod N) on the GPU, and -- on a node with at least two
     GPUs -- `est-fact --gpus=2`: the C program shards one gene over two ranks and rank 0 writes the
