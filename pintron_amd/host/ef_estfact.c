@@ -91,6 +91,11 @@ void ef_write_factorization_records(const ef_seq* gen, const ef_est* e, ef_sink*
   free(b);
 }
 
+static unsigned long long mono_us(void) {
+  struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (unsigned long long)ts.tv_sec * 1000000ull + (unsigned long long)(ts.tv_nsec / 1000);
+}
+
 /* compute_est_fact (src/compute-est-fact.c:192-293) */
 ef_est* ef_compute_est_fact(const ef_seq* gen, const ef_seq* est, ef_backend* be, const ef_config* cfg,
                             const ef_side_files* side) {
@@ -103,6 +108,7 @@ ef_est* ef_compute_est_fact(const ef_seq* gen, const ef_seq* est, ef_backend* be
   do {
     ef_meg* V = NULL;
     bool same;
+    const unsigned long long t_meg0 = mono_us();
     do {
       ef_phase(EFP_MEG);
       V = ef_build_meg(est, be, cfg, &inc);
@@ -111,6 +117,7 @@ ef_est* ef_compute_est_fact(const ef_seq* gen, const ef_seq* est, ef_backend* be
       if (same) { ++inc; ef_meg_free(V); }
     } while (same);
     prev_tp = tp; prev_te = te;
+    const unsigned long long t_meg1 = mono_us();
     /* internal_get_EST_factorizations (:154-190); NULL = budget spent ("timeout expired") */
     fe = ef_get_est_factorizations(est, V, cfg, gen, be);
     expired = fe == NULL;
@@ -134,11 +141,13 @@ ef_est* ef_compute_est_fact(const ef_seq* gen, const ef_seq* est, ef_backend* be
         ef_intronic_edges_write(side->fintronic, V);
       }
       if (side->fpmeg) { ef_write_single_est_info(side->fpmeg, est); ef_meg_write(side->fpmeg, V); }
-      /* "<meg us> <composition us> <#factorizations>": the two timings are inherently not
-       * reproducible; written as 0 */
+      /* "<meg us> <composition us> <#factorizations>" (src/compute-est-fact.c:265-268: the intervals of its
+       * two per-EST timers): the microseconds this EST spent from asking for its MEG to having it, and from there
+       * to its refined factorizations -- in the batched program the second includes the time the EST waited for
+       * the device's answers among the other ESTs */
       if (side->ftmeg) {
-        char line[48];
-        snprintf(line, sizeof line, "0 0 %zu\n", efl_size(fe->factorizations));
+        char line[96];
+        snprintf(line, sizeof line, "%llu %llu %zu\n", t_meg1 - t_meg0, mono_us() - t_meg1, efl_size(fe->factorizations));
         ef_sink_puts(side->ftmeg, line);
       }
     }
@@ -249,6 +258,38 @@ void ef_free_inputs(ef_inputs* in) {
   ef_genomic_epoch_bump();                   /* its address may come back with another gene behind it */
 }
 
+/* info-pid-<pid>.log (src/main-est-fact.c:106-115,181,221,233,243,290,333; log_info, src/util.c:222-268): one line per
+ * phase boundary, "label <TAB> seconds since the epoch <TAB> the process's /proc/self/statm line".  The marks are taken
+ * where the phases end in this program (reading and the GPU start-up run side by side here, so the times need not be
+ * in the reference's order; the LINES are) and written with the other files. */
+static struct { const char* label; unsigned long sec; char statm[96]; } info_marks[16];
+static int n_info_marks;
+static pthread_mutex_t info_mu = PTHREAD_MUTEX_INITIALIZER;
+void ef_info_mark(const char* label) {
+  struct timespec ts; clock_gettime(CLOCK_REALTIME, &ts);
+  char statm[96] = "NaN";
+  FILE* f = fopen("/proc/self/statm", "r");
+  if (f) { if (fgets(statm, sizeof statm, f)) { size_t n = strlen(statm); while (n && (statm[n - 1] == '\n' || statm[n - 1] == ' ')) statm[--n] = '\0'; } fclose(f); }
+  pthread_mutex_lock(&info_mu);
+  int k = 0;
+  while (k < n_info_marks && strcmp(info_marks[k].label, label) != 0) ++k;       /* a later run of the process: the newest mark */
+  if (k < 16) {
+    info_marks[k].label = label; info_marks[k].sec = (unsigned long)ts.tv_sec;
+    snprintf(info_marks[k].statm, sizeof info_marks[k].statm, "%s", statm);
+    if (k == n_info_marks) ++n_info_marks;
+  }
+  pthread_mutex_unlock(&info_mu);
+}
+static void info_write(FILE* f, int upto_label) {
+  static const char* order[7] = { "start", "data-io-end", "gst-construction-begin", "gst-preprocessing-begin",
+                                  "gst-preprocessing-end", "est-processing-end", "end" };
+  pthread_mutex_lock(&info_mu);
+  for (int o = 0; o < upto_label; ++o)
+    for (int k = 0; k < n_info_marks; ++k)
+      if (!strcmp(info_marks[k].label, order[o])) fprintf(f, "%s\t%lu\t%s\n", order[o], info_marks[k].sec, info_marks[k].statm);
+  pthread_mutex_unlock(&info_mu);
+}
+
 int ef_open_outputs(ef_outputs* o) {
   char buf[64];
   snprintf(buf, sizeof buf, "info-pid-%u.log", (unsigned)getpid());
@@ -266,12 +307,12 @@ int ef_open_outputs(ef_outputs* o) {
     fprintf(stderr, "* FATAL Cannot create an output file! Terminating\n");
     return 1;
   }
-  fprintf(o->flog, "start\n");
   return 0;
 }
 
 void ef_close_outputs(ef_outputs* o) {
-  fprintf(o->flog, "end\n");
+  ef_info_mark("end");
+  info_write(o->flog, 7);
   fclose(o->flog); fclose(o->fout.f); fclose(o->fests.f);
   fclose(o->fmeg.f); fclose(o->fpmeg.f); fclose(o->ftmeg.f); fclose(o->fintronic.f);
 }
@@ -328,12 +369,17 @@ static double wall_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC
 int ef_run(int argc, char** argv, ef_backend* (*open_backend)(const ef_seq* gen), void (*close_backend)(ef_backend*)) {
   ef_inputs in;
   const double t_start = wall_now();
+  ef_info_mark("start");
   int rc = ef_load_inputs(argc, argv, &in);
   if (rc) return rc;
   ef_outputs out;
   if (ef_open_outputs(&out)) return 1;
   const double t_loaded = wall_now();
+  ef_info_mark("data-io-end");
+  ef_info_mark("gst-construction-begin");
   ef_backend* be = open_backend(in.gen);
+  ef_info_mark("gst-preprocessing-begin");
+  ef_info_mark("gst-preprocessing-end");
   if (!be) { fprintf(stderr, "* FATAL cannot initialise the compute backend (no MI355X / library)\n"); return 1; }
   const double t_index = wall_now();
   /* per-EST loop (:249-291) */
@@ -354,6 +400,7 @@ int ef_run(int argc, char** argv, ef_backend* (*open_backend)(const ef_seq* gen)
     ef_est_free(fe);
   }
   const double t_done = wall_now();
+  ef_info_mark("est-processing-end");
   close_backend(be);
   ef_close_outputs(&out);
   ef_free_inputs(&in);

@@ -1031,6 +1031,7 @@ static void* gpu_boot_main(void* arg) {
       b->idx_rc = pgpu_index_load(b->ctx, path, b->gen, b->gen_len, &b->idx);
       loaded = b->idx_rc == PGPU_OK;
     }
+    ef_info_mark("gst-construction-begin");
     if (!loaded) {
       b->idx_rc = pgpu_index_build(b->ctx, b->gen, b->gen_len, &b->idx);
       /* of a sharded run only rank 0 saves (all ranks built the same index) */
@@ -1038,13 +1039,16 @@ static void* gpu_boot_main(void* arg) {
         fprintf(stderr, "* WARN the index could not be saved to %s\n", path);
     }
     b->t_index = now_s() - tb1;
+    ef_info_mark("gst-preprocessing-begin");            /* (the tables over the suffix array are part of the build here) */
     if (svc_started) pthread_join(svc_thread, NULL); else boot_service_contexts_main(b);
+    ef_info_mark("gst-preprocessing-end");
   }
   return NULL;
 }
 
 ef_session* ef_session_open(int argc, char** argv) {
   const double t_start = now_s();
+  ef_info_mark("start");
   /* the per-EST code allocates and frees a few hundred small blocks per EST on every worker; keep
    * the arenas from returning memory to the system and asking for it again between ESTs */
   mallopt(M_TRIM_THRESHOLD, 512 << 20);
@@ -1080,6 +1084,7 @@ ef_session* ef_session_open(int argc, char** argv) {
   load_rc = ef_load_ests(&s->in);
   ef_classify_init();
   const double t_loaded = now_s();
+  ef_info_mark("data-io-end");
   if (load_rc == 0 && !getenv("PINTRON_NO_FIBER_POOL")) {
     s->sh.stack_size = env_size("PINTRON_FIBER_STACK_KB", 256) * 1024;
     size_t want = env_size("PINTRON_THREADS", host_core_share()) * env_size("PINTRON_FIBERS", 768);
@@ -1460,6 +1465,7 @@ int ef_session_step(ef_session* s, ef_sched_stats* stats_out) {
   if (stats_out) *stats_out = st;
   ef_dp_trace_flush();
   pgpu_range_pop();
+  ef_info_mark("est-processing-end");
   free(ws); free(th);
   if (step_rusage) {
     const run_mark ru1 = run_mark_now();

@@ -459,6 +459,7 @@ int ef_load_ests(ef_inputs* in);
 extern int ef_shard_rank, ef_shard_world;   /* ef_load_ests keeps the rank's range of the input ESTs */
 void ef_free_inputs(ef_inputs* in);
 int ef_open_outputs(ef_outputs* o);
+void ef_info_mark(const char* label);       /* a phase boundary for info-pid-<pid>.log (ef_estfact.c) */
 void ef_close_outputs(ef_outputs* o);
 void ef_classify_init(void);     /* loads the PWM tables once (call before threads start) */
 /* per-gene tables of the intron classifier: the branch-point verdict of every intron end and the
