@@ -35,7 +35,7 @@ def test_header_symbols_exported(lib):
 def test_struct_layouts(lib):
     assert C.sizeof(lib.DpJob) == 48
     assert C.sizeof(lib.DpResult) == 48
-    assert C.sizeof(lib.GroupInfo) == 88
+    assert C.sizeof(lib.GroupInfo) == 96      # + t0_ms: the launch on the device time line
     assert lib.lib().pgpu_abi_version() == 1
 
 
