@@ -859,6 +859,76 @@ static bool detect_polyA(ef_list* fact, const char* gen, const char* est, bool* 
 /* ---------------------------------------------------------------------------------------------- */
 /* get_EST_factorizations (src/est-factorizations.c:126-594)                                       */
 /* ---------------------------------------------------------------------------------------------- */
+/* the cleaning steps of the candidate factorizations of one root (:203-262); the survivors join flist */
+static ef_list* clean_candidates(ef_list* cands, ef_list* flist, unsigned est_len, const char* GEN, const char* EST,
+                                 const ef_config* cfg, ef_backend* be) {
+  ef_iter ci = efl_begin(cands);
+  while (efi_has_next(&ci)) {
+    ef_list* f = (ef_list*)efi_next(&ci);
+    bool ok = not_source_sink(f, (int)est_len);
+    if (ok) ok = exon_start_end_ok(f);
+    if (ok) { ef_phase(EFP_ENDPOINTS); f = handle_endpoints(f, GEN, EST, be); if (efl_empty(f)) ok = false; }
+    if (ok) { ef_phase(EFP_EXTERNAL); f = ef_clean_external_exons(f, GEN, EST, be); if (efl_empty(f)) ok = false; }
+    if (ok) { ef_phase(EFP_DUST); f = clean_low_complexity(f, GEN, EST, cfg); if (efl_empty(f)) ok = false; }
+    if (ok) { ef_phase(EFP_NOISY); f = ef_clean_noisy_exons(f, GEN, EST, false, be); if (efl_empty(f)) ok = false; }
+    ef_phase(EFP_ADD);
+    if (ok) ok = est_coverage_ok(f, EST);
+    if (ok) {
+      bool added;
+      flist = ef_add_if_not_exists(f, flist, cfg, &added);
+      if (!added) ef_factorization_free(f);
+    } else {
+      ef_factorization_free(f);
+    }
+  }
+  efl_free(cands, NULL);
+  return flist;
+}
+
+/* A MEG that is ONE PATH from the source through every vertex to the sink -- what an EST that maps to one place
+ * gives, nine times out of ten -- has exactly one embedding per vertex, and the enumeration of
+ * get_subtree_embeddings (:597-762) from its first root, the source, comes down to folding update_embedding over
+ * the path from the sink backwards; every vertex is visited by that, so there is no other root.  The path is read
+ * off the device's record (vertices in position-list order + CSR, include/pintron_gpu.h) without building the
+ * list structure.  Returns false when the graph is not such a path (the caller enumerates as usual); *out = the
+ * source's embedding, or NULL when some vertex has none (update_embedding refused: no candidate at all). */
+static bool chain_embedding(const void* rec, const ef_config* cfg, const char* GEN, ef_work* wk, emb** out) {
+  const uint32_t* head = (const uint32_t*)rec;
+  const uint32_t nv = head[0];
+  if (nv < 2 || nv > 64) return false;
+  const int32_t* vt = (const int32_t*)((const char*)rec + 16);
+  const uint16_t* first = (const uint16_t*)((const char*)rec + 16 + 12 * (size_t)nv);
+  const uint8_t* tgt = (const uint8_t*)rec + 16 + 12 * (size_t)nv + 2 * ((size_t)nv + 1);
+  if (vt[0] != EF_SOURCE_START) return false;
+  uint8_t path[64];
+  uint64_t seen = 0;
+  uint32_t k = 0, n = 0;
+  for (;;) {                                           /* follow the only out-edge from the source */
+    if (seen >> k & 1u) return false;
+    seen |= 1ull << k; path[n++] = (uint8_t)k;
+    const uint32_t deg = (uint32_t)first[k + 1] - first[k];
+    if (deg == 0) break;
+    if (deg != 1) return false;
+    k = tgt[first[k]];
+    if (k >= nv) return false;
+  }
+  if (n != nv || vt[3 * (size_t)path[n - 1]] != EF_SINK_START) return false;      /* every vertex, ending in the sink */
+  wk->used += 2ull * nv;
+  ef_pairing node;
+  memset(&node, 0, sizeof node);
+  emb* e = emb_new(1);
+  { const int32_t* s3 = vt + 3 * (size_t)path[n - 1]; e->e[0].p = s3[0]; e->e[0].t = s3[1]; e->e[0].l = s3[2]; }
+  for (uint32_t q = n - 1; q-- > 0 && e;) {
+    const int32_t* v3 = vt + 3 * (size_t)path[q];
+    node.p = v3[0]; node.t = v3[1]; node.l = v3[2];
+    emb* nx = update_embedding(e, &node, GEN, cfg);
+    embedding_free(e);
+    e = nx;
+  }
+  *out = e;
+  return true;
+}
+
 ef_est* ef_get_est_factorizations(const ef_seq* est_info, ef_meg* V, const ef_config* cfg,
                                   const ef_seq* gen_info, ef_backend* be) {
   ef_phase(EFP_EMBED);
@@ -869,6 +939,19 @@ ef_est* ef_get_est_factorizations(const ef_seq* est_info, ef_meg* V, const ef_co
   const unsigned est_len = (unsigned)V->n - 2;
   ef_list* flist = efl_new();
   ef_work wk = { 0, work_limit(cfg) };
+  emb* chain = NULL;
+  if (V->rec && !V->v && ef_chain_fast_path && chain_embedding(V->rec, cfg, GEN, &wk, &chain)) {
+    if (ef_prof_on) ++ef_prof.chain_graphs;
+    if (chain) {
+      ef_list* embs = efl_new();
+      efl_push_back(embs, chain);
+      ef_list* cands = factorizations_from_embeddings(embs, cfg);
+      efl_free(embs, embedding_free);
+      flist = clean_candidates(cands, flist, est_len, GEN, EST, cfg, be);
+    }
+  } else {
+  if (ef_prof_on) ++ef_prof.other_graphs;
+  V = ef_meg_lists(V);                                 /* a graph known by its record only gets its lists now */
   EF_MEG_FOR_POS(V, i, 0, V->n) {
     ef_iter it = efl_begin(V->v[i]);
     while (efi_has_next(&it)) { ef_pairing* p = (ef_pairing*)efi_next(&it); p->visited = false; p->emb_memo = NULL; }
@@ -890,37 +973,18 @@ ef_est* ef_get_est_factorizations(const ef_seq* est_info, ef_meg* V, const ef_co
         free(est);
         return NULL;
       }
-      ef_list* cands = factorizations_from_embeddings(embs, cfg);
-      ef_iter ci = efl_begin(cands);
-      while (efi_has_next(&ci)) {
-        ef_list* f = (ef_list*)efi_next(&ci);
-        bool ok = not_source_sink(f, (int)est_len);
-        if (ok) ok = exon_start_end_ok(f);
-        if (ok) { ef_phase(EFP_ENDPOINTS); f = handle_endpoints(f, GEN, EST, be); if (efl_empty(f)) ok = false; }
-        if (ok) { ef_phase(EFP_EXTERNAL); f = ef_clean_external_exons(f, GEN, EST, be); if (efl_empty(f)) ok = false; }
-        if (ok) { ef_phase(EFP_DUST); f = clean_low_complexity(f, GEN, EST, cfg); if (efl_empty(f)) ok = false; }
-        if (ok) { ef_phase(EFP_NOISY); f = ef_clean_noisy_exons(f, GEN, EST, false, be); if (efl_empty(f)) ok = false; }
-        ef_phase(EFP_ADD);
-        if (ok) ok = est_coverage_ok(f, EST);
-        if (ok) {
-          bool added;
-          flist = ef_add_if_not_exists(f, flist, cfg, &added);
-          if (!added) ef_factorization_free(f);
-        } else {
-          ef_factorization_free(f);
-        }
-      }
-      efl_free(cands, NULL);
+      flist = clean_candidates(factorizations_from_embeddings(embs, cfg), flist, est_len, GEN, EST, cfg, be);
     }
-  }
-  {
-    unsigned long long hw = __atomic_load_n(&work_high_water, __ATOMIC_RELAXED);
-    while (wk.used > hw && !__atomic_compare_exchange_n(&work_high_water, &hw, wk.used, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) { }
   }
   /* release the memoised embeddings */
   EF_MEG_FOR_POS(V, i, 0, V->n) {
     ef_iter it = efl_begin(V->v[i]);
     while (efi_has_next(&it)) { ef_pairing* p = (ef_pairing*)efi_next(&it); if (p->emb_memo) { efl_free(p->emb_memo, embedding_free); p->emb_memo = NULL; } }
+  }
+  }
+  {
+    unsigned long long hw = __atomic_load_n(&work_high_water, __ATOMIC_RELAXED);
+    while (wk.used > hw && !__atomic_compare_exchange_n(&work_high_water, &hw, wk.used, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) { }
   }
 
   ef_phase(EFP_FILTERS);

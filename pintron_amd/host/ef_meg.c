@@ -29,7 +29,7 @@ static ef_list empty_position = { { &empty_position.sent, &empty_position.sent, 
 ef_meg* ef_meg_from_pairings(const ef_triple* tr, size_t n_tr, size_t m) {
   ef_meg* V = (ef_meg*)malloc(sizeof(ef_meg));
   V->n = m + 2;
-  V->rec = NULL; V->slab = false;
+  V->rec = NULL; V->slab = false; V->lists = NULL;
   /* one list per EST position, most of them empty: headers exist only for the positions that
    * hold a vertex (source, sink and the distinct p of the pairings) */
   V->v = (ef_list**)malloc(V->n * sizeof(ef_list*) + (n_tr + 2) * sizeof(ef_list));
@@ -72,7 +72,7 @@ ef_meg* ef_meg_from_record(const void* rec, size_t m) {
                        nv * sizeof(ef_pairing) + 2 * (size_t)nv * sizeof(ef_list) + ((size_t)nv + ne) * sizeof(ef_node);
   char* blk = (char*)malloc(bytes + 8);
   ef_meg* V = (ef_meg*)blk; blk += sizeof(ef_meg);
-  V->n = n; V->rec = rec; V->slab = true;
+  V->n = n; V->rec = rec; V->slab = true; V->lists = NULL;
   V->v = (ef_list**)blk; blk += nv * sizeof(ef_list*);
   V->act = (size_t*)blk; blk += nv * sizeof(size_t);
   ef_list* heads = (ef_list*)blk; blk += nv * sizeof(ef_list);
@@ -102,8 +102,21 @@ ef_meg* ef_meg_from_record(const void* rec, size_t m) {
   return V;
 }
 
+ef_meg* ef_meg_record_only(const void* rec, size_t m) {
+  ef_meg* V = (ef_meg*)calloc(1, sizeof(ef_meg));
+  V->n = m + 2; V->rec = rec; V->slab = true;
+  return V;
+}
+
+ef_meg* ef_meg_lists(ef_meg* V) {
+  if (V->v || !V->rec) return V;
+  if (!V->lists) V->lists = ef_meg_from_record(V->rec, V->n - 2);
+  return V->lists;
+}
+
 void ef_meg_free(ef_meg* V) {
   if (!V) return;
+  if (V->lists) ef_meg_free(V->lists);
   if (V->slab) { free(V); return; }
   EF_MEG_FOR_POS(V, i, 0, V->n) efl_clear(V->v[i], pairing_free);
   free(V->v); free(V->act);
@@ -205,6 +218,12 @@ void ef_build_edge_set(ef_meg* V, const ef_config* cfg) {
 
 void ef_meg_stats(ef_meg* V, size_t* pairings, size_t* edges) {
   *pairings = 0; *edges = 0;
+  if (V->rec && !V->v) {                    /* from the record: its vertices, and the end of its CSR offsets */
+    const uint32_t nv = ((const uint32_t*)V->rec)[0];
+    const uint16_t* first = (const uint16_t*)((const char*)V->rec + 16 + 12 * (size_t)nv);
+    *pairings = nv; *edges = first[nv];
+    return;
+  }
   EF_MEG_FOR_POS(V, i, 0, V->n) {
     ef_iter it = efl_begin(V->v[i]);
     while (efi_has_next(&it)) { const ef_pairing* p = (const ef_pairing*)efi_next(&it); ++*pairings; *edges += efl_size(p->adjs); }
@@ -503,7 +522,7 @@ ef_meg* ef_build_meg(const ef_seq* est, ef_backend* be, const ef_config* shared,
       cfg.min_factor_len -= (unsigned)*inc;
       if (too_complex && cfg.min_factor_len + *inc + 1 + 2 < m + 2) { ++*inc; continue; }
       too_complex = false;
-      V = ef_meg_from_record(rec, m);
+      V = ef_meg_record_only(rec, m);
       continue;
     }
     ef_triple* tr = NULL; size_t ntr = 0;

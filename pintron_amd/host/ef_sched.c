@@ -274,7 +274,7 @@ typedef struct shared {
   struct out_chunk* chunks;              /* under mu */
   struct out_chunk* spare_chunks;        /* chunks of the previous step, reused (their pages stay mapped) */
   unsigned long long prof_cyc[EFP_N], prof_susp[EFP_N], prof_jobs[EFP_N];   /* PINTRON_PROFILE, summed over the workers (under mu) */
-  unsigned long long prof_ahead[3];
+  unsigned long long prof_ahead[5];
   double prof_t0; double prof_sleep_bins[64];      /* when in the step the workers slept (5 ms bins, seconds summed over the workers) */
 } shared;
 
@@ -819,6 +819,7 @@ static void* worker_main(void* arg) {
     for (int k = 0; k < EFP_N; ++k) { sh->prof_cyc[k] += ef_prof.cyc[k]; sh->prof_susp[k] += ef_prof.susp[k]; sh->prof_jobs[k] += ef_prof.jobs[k]; }
     for (int k = 0; k < 64; ++k) sh->prof_sleep_bins[k] += w->sleep_bins[k];
     sh->prof_ahead[0] += ef_prof.ahead_asked; sh->prof_ahead[1] += ef_prof.ahead_hits; sh->prof_ahead[2] += ef_prof.ahead_misses;
+    sh->prof_ahead[3] += ef_prof.chain_graphs; sh->prof_ahead[4] += ef_prof.other_graphs;
     pthread_mutex_unlock(&sh->mu);
   }
   return NULL;
@@ -1384,6 +1385,7 @@ int ef_session_step(ef_session* s, ef_sched_stats* stats_out) {
     }
     fprintf(stderr, "*   asked ahead: %.2f jobs / unit, found there %.2f, asked in turn (while answers were kept) %.2f\n",
             (double)sh->prof_ahead[0] / (double)sh->n_units, (double)sh->prof_ahead[1] / (double)sh->n_units, (double)sh->prof_ahead[2] / (double)sh->n_units);
+    fprintf(stderr, "*   graphs that are one path (enumerated from the record): %llu of %llu\n", sh->prof_ahead[3], sh->prof_ahead[3] + sh->prof_ahead[4]);
     fprintf(stderr, "*   asleep waiting for batches, ms per worker in each 5 ms of the step:");
     for (int k = 0; k < 64 && k * 0.005 < now_s() - t0; ++k) fprintf(stderr, " %.1f", 1e3 * sh->prof_sleep_bins[k] / (double)w_started);
     fprintf(stderr, "\n");

@@ -138,7 +138,7 @@ typedef struct ef_pairing {
   ef_list* emb_memo;      /* embeddings of the subtree rooted here, once computed */
 } ef_pairing;
 
-typedef struct {
+typedef struct ef_meg_s {
   size_t n;          /* |P| + 2: [0] = source, [1+i] = position i, [n-1] = sink */
   ef_list** v;
   /* the positions that ever held a vertex, ascending (a few dozen of the ~600): vertices are only
@@ -150,6 +150,10 @@ typedef struct {
   /* a graph made from a record is read-only and lives in ONE block (this structure first): position
    * table, list headers, vertices and list nodes are carved from it and freed with it */
   bool slab;
+  /* ... and may be known by its record alone (v == NULL): statistics and the two texts come from the record, a
+   * graph that is one path is enumerated from it too (ef_fact.c: chain_embedding); the lists are built when
+   * somebody asks (ef_meg_lists) */
+  struct ef_meg_s* lists;
 } ef_meg;
 
 /* first index k with act[k] >= lo */
@@ -170,6 +174,9 @@ typedef struct { int32_t p, t, l; } ef_triple;
 ef_meg* ef_meg_from_pairings(const ef_triple* tr, size_t n_tr, size_t pattern_len);
 /* the same structure from a device-built MEG record (vertices in position-list order + CSR) */
 ef_meg* ef_meg_from_record(const void* rec, size_t pattern_len);
+ef_meg* ef_meg_record_only(const void* rec, size_t pattern_len);      /* ... without the lists (see ef_meg.lists) */
+ef_meg* ef_meg_lists(ef_meg* V);                                      /* V itself, or the graph with lists made for it */
+extern int ef_chain_fast_path;     /* PINTRON_CHAIN=0: every graph is enumerated through its lists (read once by ef_config_load) */
 void ef_meg_free(ef_meg* V);
 void ef_build_edge_set(ef_meg* V, const ef_config* cfg);               /* src/max-emb-graph.c:650 */
 void ef_simplify_meg(ef_meg* V, const ef_config* cfg);                 /* src/meg-simplification.c:314 */
@@ -251,7 +258,7 @@ enum { EFP_OTHER = 0, EFP_MEG, EFP_EMBED, EFP_ENDPOINTS, EFP_EXTERNAL, EFP_DUST,
        EFP_NS_PREFIX, EFP_NS_BETWEEN_ASK, EFP_NS_BETWEEN_CLASS, EFP_NS_BETWEEN_SEARCH, EFP_TMP1, EFP_TMP2, EFP_TMP3, EFP_N };
 extern int ef_prof_on;
 typedef struct { unsigned long long cyc[EFP_N], susp[EFP_N], jobs[EFP_N]; unsigned long long last; int dummy; int* cur;
-                 unsigned long long ahead_hits, ahead_misses, ahead_asked; } ef_prof_state;
+                 unsigned long long ahead_hits, ahead_misses, ahead_asked, chain_graphs, other_graphs; } ef_prof_state;
 extern _Thread_local ef_prof_state ef_prof;
 static inline unsigned long long ef_prof_now(void) {
 #if defined(__x86_64__)

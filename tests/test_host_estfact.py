@@ -38,6 +38,10 @@ def run(exe, cwd, env=None):
                                        ("estfact_sched_check", {"PINTRON_LANES": "1", "PINTRON_THREADS": "2"}),
                                        ("estfact_sched_check", {"PINTRON_LANES": "4", "PINTRON_SERVICES": "2", "PINTRON_FIBERS": "8"}),
                                        ("estfact_sched_check", {"PINTRON_ESTFACT_MODE": "direct"}),
+                                       # the two short cuts of the host code switched off: one-path graphs through the
+                                       # list structure, every question asked in its turn
+                                       ("estfact_sched_check", {"PINTRON_CHAIN": "0", "PINTRON_THREADS": "2"}),
+                                       ("estfact_sched_check", {"PINTRON_AHEAD": "0", "PINTRON_THREADS": "2"}),
                                        # MEG stage of the C-ABI: graphs beyond the device limits come back
                                        # "unavailable" and are built on the host; a library without the stage;
                                        # the stage switched off
