@@ -369,6 +369,7 @@ struct pgpu_dp_plan {
   // ... and, with the batch kernel, the one-job-per-workgroup BORDERS / AFFIX jobs
   bool batch = false;
   int bc_start = 0, bc_count = 0, ac_start = 0, ac_count = 0, lc_start = 0, lc_count = 0;   // BORDERS / AFFIX / ALIGN on several waves
+  int ab_start = 0, ab_count = 0;              // banded ALIGN jobs of the merged launch (the follow-up launch looks at them)
   uint32_t bc_max_rows = 0;
   // LCF: the kernel leaves one 64-bit key per job directly in front of the results; they come back in the
   // same copy and sync turns them into results (lcf_out[k] = caller index of the job of key k)
@@ -453,7 +454,12 @@ extern "C" int pgpu_dp_plan_create_parts(pgpu_ctx* ctx, const pgpu_index* idx, c
       case PGPU_DP_ALIGN:
         if (la > PGPU_MAX_ROWS_LEV || lb > PGPU_MAX_COLS) continue;
         k.family = KF_ALIGN; k.R = row_class(la); k.size = (uint64_t)la * lb;
-        k.j.tail = ctx->align_band ? 1u : 0u;          /* (ALIGN has no tail: the kernel's switch for the banded attempt) */
+        // exon against its stretch of the genomic sequence: the alignment hugs the diagonal.  Above 64 rows, lengths
+        // within the band's half-width: inside the band on ONE wave among the wave-per-job jobs (four to a workgroup
+        // instead of a workgroup each); the rare job the band cannot settle is finished by the follow-up launch
+        if (ctx->align_band && align_coop && ctx->merged >= 1 && la > 64u && la <= 4096u && (la > lb ? la - lb : lb - la) <= ALIGN_BAND_HALF)
+          k.family = KF_ALIGNB;
+        k.j.tail = 0u;
         break;
       case PGPU_DP_GAP:
         if (lb > PGPU_MAX_GAP_SIDE || la > PGPU_MAX_GAP_SIDE || ((uint64_t)la + 1) * ((uint64_t)lb + 1) > PGPU_MAX_GAP_CELLS) continue;
@@ -540,7 +546,7 @@ extern "C" int pgpu_dp_plan_create_parts(pgpu_ctx* ctx, const pgpu_index* idx, c
         ws += (size_t)((la + 4095u) / 4096u) * ((size_t)lb + 64) * 64 * align_entry_bytes(k.R);
         k.j.str_off = strs; strs += 2 * ((size_t)la + lb + 1);
       }
-    } else if (k.family == KF_ALIGN && k.R >= 2 && ctx->align_coop) {   // four waves: [step][256 lanes] entries
+    } else if ((k.family == KF_ALIGN || k.family == KF_ALIGNB) && k.R >= 2 && ctx->align_coop) {   // four waves: [step][256 lanes] entries (the band's words fit in there)
       k.j.ws_off = ws; ws += ((size_t)lb + 256) * 256 * align_coop_entry_bytes(k.R);
       k.j.str_off = strs; strs += 2 * ((size_t)la + lb + 1);
     } else if (k.family == KF_ALIGN) {
@@ -582,7 +588,7 @@ extern "C" int pgpu_dp_plan_create_parts(pgpu_ctx* ctx, const pgpu_index* idx, c
       // ALIGN, 3 B/cell for GAP; 8 B per row when row minima are produced
       // (BORDERS touches the first and the last t_win characters of t only)
       uint64_t job_bytes = la + (k.family == KF_BORDERS ? std::min<uint64_t>(lb, 2 * std::min<uint64_t>(la + k.j.p2, lb)) : lb);
-      if (k.family == KF_ALIGN) job_bytes += la * lb + 3 * (la + lb);     // + directions read back, two strings
+      if (k.family == KF_ALIGN || k.family == KF_ALIGNB) job_bytes += la * lb + 3 * (la + lb);     // + directions read back, two strings
       if (k.family == KF_GAP) job_bytes += 3 * la * lb + 3 * (la + lb);
       if (k.family == KF_BORDERS) job_bytes += 2 * 8 * la;
       // suffix-array search: s2, and per lane about eight table probes, a few suffix-array / sequence probes of the
@@ -590,7 +596,7 @@ extern "C" int pgpu_dp_plan_create_parts(pgpu_ctx* ctx, const pgpu_index* idx, c
       if (k.family == KF_LCFSA) job_bytes = lb + 64u * 96u;
       g.cells += job_cells; g.algo_bytes += job_bytes;
       g.max_rows = std::max(g.max_rows, (uint32_t)la);
-      if (k.R >= (k.family == KF_GAP ? 8u : 32u)) { ++g.n_big; g.cells_big += job_cells; g.algo_big += job_bytes; }   // (the slow GAP / BORDERS groups ignore it)
+      if (k.family != KF_ALIGNB && k.R >= (k.family == KF_GAP ? 8u : 32u)) { ++g.n_big; g.cells_big += job_cells; g.algo_big += job_bytes; }   // (the slow GAP / BORDERS groups ignore it)
       if (k.family == KF_LCF) {
         const uint32_t ch = (uint32_t)((la + lb + 254) / 256);   // ceil((la+lb-1)/256) diagonals
         g.max_chunks = std::max(g.max_chunks, ch);
@@ -601,7 +607,7 @@ extern "C" int pgpu_dp_plan_create_parts(pgpu_ctx* ctx, const pgpu_index* idx, c
     g.count = j - i;
     char nm[64];
     static const char* fam[] = {"lev_wave<ALIGN>", "gap_wave", "lev_wave<ED>", "lev_wave<KBAND>", "lcf",
-                                "borders_coop", "affix_coop", "lcf_sa", "lcf_small"};
+                                "borders_coop", "affix_coop", "lcf_sa", "lcf_small", "align_band"};
     if (g.family == KF_BORDERS && g.R == 1) snprintf(nm, sizeof nm, "lev_wave<BORDERS,R=1>");
     else if (g.family == KF_AFFIX && g.R == 1) snprintf(nm, sizeof nm, "lev_wave<AFFIX,R=1>");
     else if (g.family == KF_AFFIX && g.R == (int)ROW_CLASS_STRIPS) snprintf(nm, sizeof nm, "lev_wave<AFFIX,strips>");
@@ -621,7 +627,7 @@ extern "C" int pgpu_dp_plan_create_parts(pgpu_ctx* ctx, const pgpu_index* idx, c
   if (ctx->merged) {
     // the common row classes of the wave-per-job families run in one launch (wave_jobs_kernel); the
     // groups keep their BIG part (first n_big jobs).  Long-running families first.
-    static const int order_fam[8] = { KF_ALIGN, KF_GAP, KF_KBAND, KF_BORDERS, KF_AFFIX, KF_LCFSA, KF_LCFW, KF_ED };
+    static const int order_fam[9] = { KF_ALIGNB, KF_ALIGN, KF_GAP, KF_KBAND, KF_BORDERS, KF_AFFIX, KF_LCFSA, KF_LCFW, KF_ED };
     Group m{};
     m.family = KF_COUNT; m.kind = PGPU_DP_ALIGN; m.name = "wave_jobs";
     for (int f : order_fam)
@@ -634,6 +640,7 @@ extern "C" int pgpu_dp_plan_create_parts(pgpu_ctx* ctx, const pgpu_index* idx, c
         if (g.count <= big) continue;
         p->seg_family[p->n_segs] = f; p->seg_start[p->n_segs] = (int)(g.first + big); p->seg_count[p->n_segs] = (int)(g.count - big);
         ++p->n_segs;
+        if (f == KF_ALIGNB) { p->ab_start = (int)g.first; p->ab_count = (int)g.count; }
         m.count += g.count - big; m.cells += g.cells - (big ? g.cells_big : 0); m.algo_bytes += g.algo_bytes - (big ? g.algo_big : 0);
         g.in_merged = true;
         g.count = big; g.cells = big ? g.cells_big : 0; g.algo_bytes = big ? g.algo_big : 0;
@@ -824,6 +831,7 @@ extern "C" int pgpu_dp_plan_launch(pgpu_ctx* ctx, pgpu_dp_plan* p) {
           } else {
             launch_wave_jobs(p->d_jobs, p->n_segs, p->seg_family, p->seg_start, p->seg_count, p->d_results, p->d_ws, p->d_strs, p->lcf_ix, st);
           }
+          launch_align_fallback(p->d_jobs + p->ab_start, p->ab_count, p->d_results, p->d_ws, p->d_strs, st);
           break;
         case KF_ALIGN: case KF_ED: case KF_BORDERS: case KF_AFFIX: case KF_KBAND:
           launch_lev(g.family, g.R, g.max_rows, jobs, n, (int)g.n_big, p->d_results, p->d_ws, p->d_strs, st); break;
@@ -834,6 +842,12 @@ extern "C" int pgpu_dp_plan_launch(pgpu_ctx* ctx, pgpu_dp_plan* p) {
         case KF_LCF:
           launch_lcf(jobs, n, g.max_chunks, g.max_l2, p->d_keys + key_of[gi], st);
           break;
+        case KF_ALIGNB: {                     // (only when the merged launch had no segment left for it)
+          const int fam1 = g.family, start1 = (int)g.first, count1 = n;
+          launch_wave_jobs(p->d_jobs, 1, &fam1, &start1, &count1, p->d_results, p->d_ws, p->d_strs, p->lcf_ix, st);
+          launch_align_fallback(jobs, n, p->d_results, p->d_ws, p->d_strs, st);
+          break;
+        }
         case KF_LCFSA: case KF_LCFW: {       // a launch of their own only with PGPU_MERGED=0
           const int fam1 = g.family, start1 = (int)g.first, count1 = n;
           launch_wave_jobs(p->d_jobs, 1, &fam1, &start1, &count1, p->d_results, p->d_ws, p->d_strs, p->lcf_ix, st);

@@ -1171,7 +1171,7 @@ __device__ __forceinline__ void align_traceback_coop(const DevJob& job, DevResul
 // diagonal, up, left, i.e. the same direction.  A banded score > k says nothing: the caller sweeps the
 // whole matrix.  Directions: 2 bits per cell, one 32-bit word per lane and 16 rows, [row / 16][lane].
 // ---------------------------------------------------------------------------------------------
-constexpr uint32_t ALIGN_BAND_K = 31u;
+constexpr uint32_t ALIGN_BAND_K = ALIGN_BAND_HALF;
 __device__ __forceinline__ bool align_band_fits(uint32_t n, uint32_t m) {
   return n > 0u && m > 0u && (n > m ? n - m : m - n) <= ALIGN_BAND_K;
 }
@@ -1767,8 +1767,38 @@ __device__ __forceinline__ void wave_jobs_body(const int block, const int wave, 
     case KF_AFFIX:   lev_wave_body<1, MODE_AFFIX>(job, res, ws, lane); break;
     case KF_LCFSA:   lcfsa_wave_body(job, res, ix, lane); break;
     case KF_LCFW:    lcf_small_wave_body(job, res, lane); break;
+    case KF_ALIGNB: {                    // see align_band_sweep; the host chose the jobs (more than 64 rows, lengths within the band)
+      const uint32_t n = job.la, m = job.lb;
+      bool same = n == m;
+      if (same) for (uint32_t q = lane; q < n; q += 64) same = same && job.a[q] == job.b[q];
+      if (__all(same)) {                 // identity alignment, score 0 (compute-alignments.c:48-58)
+        if (lane == 0) { res->status = 0; res->v[0] = 0; res->v[1] = (int32_t)n; res->v[5] = 1; }
+        own_stores_visible();
+        align_traceback_wave(job, res, ws, strs, lane, s_win, s_path);      // its identity branch
+        break;
+      }
+      uint32_t* bdirs = reinterpret_cast<uint32_t*>(ws + job.ws_off);
+      const uint32_t score = align_band_sweep(job.a, n, job.b, m, lane, bdirs);
+      if (score > ALIGN_BAND_K) { if (lane == 0) res->status = ALIGN_BAND_RETRY; break; }
+      if (lane == 0) { res->status = 0; res->v[0] = (int32_t)score; res->v[5] = 0; }
+      own_stores_visible();
+      align_band_traceback(job, res, bdirs, strs, lane, s_win, s_path);
+      break;
+    }
     default: break;
   }
+}
+
+// follow-up of the merged launch: the banded ALIGN jobs whose score exceeded the band, on four waves each;
+// a workgroup whose job is settled (nearly all) ends at once
+__global__ __launch_bounds__(256)
+void align_fallback_kernel(const DevJob* __restrict__ jobs, int njobs, DevResult* __restrict__ results,
+                           uint8_t* __restrict__ ws, uint8_t* __restrict__ strs) {
+  __shared__ __attribute__((aligned(16))) uint8_t smem[ALIGN_COOP_LDS];
+  DevJob job = jobs[blockIdx.x];
+  if (results[job.out_idx].status != ALIGN_BAND_RETRY) return;
+  job.tail = 0;                          // the band has been tried
+  align_coop_dispatch(job, &results[job.out_idx], ws, strs, smem);
 }
 
 __global__ __launch_bounds__(256)
@@ -2092,6 +2122,11 @@ void launch_lev(int family, int R, uint32_t max_rows, const DevJob* jobs, int nj
       break;
     default: break;
   }
+}
+
+void launch_align_fallback(const DevJob* jobs, int njobs, DevResult* res, uint8_t* ws, uint8_t* strs, hipStream_t st) {
+  if (njobs <= 0) return;
+  hipLaunchKernelGGL(align_fallback_kernel, dim3(njobs), dim3(256), 0, st, jobs, njobs, res, ws, strs);
 }
 
 // segments: (family, first job, count) of the jobs the merged kernel runs, long poles first

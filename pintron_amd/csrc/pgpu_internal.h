@@ -27,6 +27,9 @@ enum KernelFamily {
   KF_ALIGN = 0, KF_GAP, KF_ED, KF_KBAND, KF_LCF, KF_BORDERS, KF_AFFIX,
   KF_LCFSA,            // find_longest_common_factor_dp answered from the suffix array (one wave per job; see lcfsa_wave_body)
   KF_LCFW,             // ... of two short strings (the small-exon search's exon ends): one wave per job, a lane per diagonal
+  KF_ALIGNB,           // ALIGN above 64 rows whose lengths differ by at most the band's half-width: inside the band on ONE
+                       // wave (align_band_sweep); a job whose banded score exceeds the band is left with status
+                       // ALIGN_BAND_RETRY and finished by the follow-up launch (launch_align_fallback) on four waves
   KF_COUNT
 };
 
@@ -35,7 +38,11 @@ void launch_lev(int mode_family, int R, uint32_t max_rows, const DevJob* jobs, i
                 uint8_t* ws, uint8_t* strs, hipStream_t st);     // ALIGN: matrix + traceback
 void launch_gap(const DevJob* jobs, int njobs, int n_big, DevResult* res, uint8_t* ws, uint8_t* strs, hipStream_t st);   // + traceback
 void launch_gap_slow(const DevJob* jobs, int njobs, DevResult* res, uint8_t* ws, uint8_t* strs, hipStream_t st);   // beyond 2048 rows
-constexpr int MAX_WAVE_SEGS = 8;
+constexpr int MAX_WAVE_SEGS = 10;
+constexpr int32_t ALIGN_BAND_RETRY = 1;     // DevResult.status of a banded ALIGN that has to be swept in full (never leaves the library)
+constexpr uint32_t ALIGN_BAND_HALF = 31u;   // half-width of the band (2k + 1 <= 64 lanes)
+// the whole-matrix sweep (four waves per job) for the jobs of [jobs, jobs + njobs) the band could not settle
+void launch_align_fallback(const DevJob* jobs, int njobs, DevResult* res, uint8_t* ws, uint8_t* strs, hipStream_t st);
 void launch_wave_jobs(const DevJob* jobs, int n_segs, const int* family, const int* start, const int* count,
                       DevResult* res, uint8_t* ws, uint8_t* strs, const LcfIndexView& ix, hipStream_t st);   // every wave-per-job family in one launch
 // one launch for the one-job-per-workgroup sweeps and the wave-per-job families of a batch; returns
