@@ -54,6 +54,7 @@ struct pgpu_ctx {
   long wait_poll_us = 20;
   bool align_coop = true;    // ALIGN with 65 .. 4096 rows on four waves (PGPU_ALIGN_COOP=0: one wave, as before)
   bool align_band = true;    // ALIGN above 64 rows: inside a band on one wave first (PGPU_ALIGN_BAND=0: always the whole matrix)
+  bool lcf_sa_n = true;      // ... also for an EST prefix with one N (PGPU_LCF_SA_N=0: those take the DP kernel, as before)
   bool lcf_sa = true;        // longest common factors of genomic prefixes from the suffix array (PGPU_LCF_SA=0: always the DP kernel)
   int poison = -1;           // PGPU_POISON=<0..255>: fill strings + workspace of every DP plan with that byte first
   // pinned staging for the device->host result copies (pageable copies block and spin inside HIP)
@@ -277,6 +278,7 @@ extern "C" int pgpu_init(int device, pgpu_ctx** out) {
   { const char* f = getenv("PGPU_WAIT"); if (f) ctx->wait_poll_us = atol(f); }
   { const char* f = getenv("PGPU_ALIGN_COOP"); if (f && f[0] == '0') ctx->align_coop = false; }
   { const char* f = getenv("PGPU_LCF_SA"); if (f && f[0] == '0') ctx->lcf_sa = false; }
+  { const char* f = getenv("PGPU_LCF_SA_N"); if (f && f[0] == '0') ctx->lcf_sa_n = false; }
   { const char* f = getenv("PGPU_ALIGN_BAND"); if (f && f[0] == '0') ctx->align_band = false; }
   { const char* f = getenv("PGPU_POISON"); if (f && f[0]) ctx->poison = atoi(f) & 255; }
   { const char* f = getenv("PGPU_PACK"); if (f && atoi(f) == 0) ctx->packed = false; }
@@ -481,11 +483,17 @@ extern "C" int pgpu_dp_plan_create_parts(pgpu_ctx* ctx, const pgpu_index* idx, c
         // the small-exon search's question -- a prefix of the genomic sequence against a few dozen EST
         // characters -- is answered from the suffix array when exact matching is all there is to it: both
         // strings upper-case ACGT (no N wildcard can fire) and s2 short enough for one lane per start
+        // ... or with ONE N in s2 (an EST with a stray N): the four strings with A, C, G, T in its place are searched
+        // by the same wave (lcfsa_wave_body; job.p0 = the N's place + 1).  More Ns, or anything else: the DP kernel
         if (lcf_sa && ag && !bg && in.a_off == 0 && la <= p->lcf_ix.first_bad && lb <= 64u) {
           const unsigned char* b = (const unsigned char*)parts[part_i].arena + in.b_off;
           bool acgt = true;
-          for (uint32_t q = 0; q < lb && acgt; ++q) acgt = b[q] == 'A' || b[q] == 'C' || b[q] == 'G' || b[q] == 'T';
-          if (acgt) k.family = KF_LCFSA;
+          uint32_t n_wild = 0, wild_at = 0;
+          for (uint32_t q = 0; q < lb && acgt; ++q) {
+            if (b[q] == 'N' || b[q] == 'n') { ++n_wild; wild_at = q; }
+            else acgt = b[q] == 'A' || b[q] == 'C' || b[q] == 'G' || b[q] == 'T';
+          }
+          if (acgt && n_wild <= (ctx->lcf_sa_n ? 1u : 0u)) { k.family = KF_LCFSA; k.j.p0 = n_wild ? wild_at + 1u : 0u; }
         }
         // two short strings: one wave (a lane per diagonal) instead of a workgroup and an atomic per job
         if (k.family == KF_LCF && ctx->lcf_sa && (uint64_t)la * lb <= 16384u && la + lb <= 4096u) k.family = KF_LCFW;

@@ -1642,9 +1642,10 @@ __device__ __forceinline__ uint32_t lcfsa_rmq(const LcfIndexView& ix, uint32_t l
   return min(lv[lo], lv[hi - (1u << j)]);
 }
 
-__device__ __forceinline__ void lcfsa_wave_body(const DevJob& job, DevResult* res, const LcfIndexView& ix, const uint32_t lane) {
-  const uint32_t G = job.la, l2 = job.lb;
-  const uint8_t* __restrict__ s2 = job.b;
+// the search for one string s2 of upper-case A, C, G, T: the wave's key (longest, then smallest start in T, then
+// smallest start in s2), the same in every lane; 0 = no common factor
+__device__ __forceinline__ unsigned long long lcfsa_wave_key(const uint32_t G, const uint8_t* s2, const uint32_t l2,
+                                                             const LcfIndexView& ix, const uint32_t lane) {
   const uint8_t* __restrict__ T = ix.T;
   uint32_t best = 0, bt = 0;
   if (lane < l2) {
@@ -1708,6 +1709,33 @@ __device__ __forceinline__ void lcfsa_wave_body(const DevJob& job, DevResult* re
   unsigned long long key = best ? ((unsigned long long)best << 40) | ((unsigned long long)(0x0FFFFFFFu - bt) << 8) | (63u - lane) : 0ull;
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) { const unsigned long long x = __shfl_xor(key, o); key = x > key ? x : key; }
+  return key;
+}
+
+// job.p0 = 0: s2 is upper-case ACGT.  job.p0 = q + 1: s2[q] is an N, the only character of s2 that is not ACGT.
+// Ns_ALWAYS_MATCH_FOR_LCS (src/factorization-refinement.c:74) makes that N equal to whatever the genomic sequence
+// holds there; the genomic prefix is ACGT only (the host checked), so the factors that run over the N are the exact
+// factors of the four strings s2 with A, C, G, T in its place, and the reference's first maximum -- longest, then
+// smallest start in T, then in s2 -- is the largest of the four keys.  `scratch`: 64 bytes of the wave's LDS.
+__device__ __forceinline__ void lcfsa_wave_body(const DevJob& job, DevResult* res, const LcfIndexView& ix, const uint32_t lane,
+                                                uint8_t* scratch) {
+  const uint32_t G = job.la, l2 = job.lb;
+  unsigned long long key;
+  if (job.p0 == 0u) key = lcfsa_wave_key(G, job.b, l2, ix, lane);
+  else {
+    key = 0ull;
+    const uint32_t q = job.p0 - 1u;
+    if (lane < l2) scratch[lane] = job.b[lane];
+    for (uint32_t c = 0; c < 4u; ++c) {
+      if (lane == 0) scratch[q] = (uint8_t)"ACGT"[c];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const unsigned long long k = lcfsa_wave_key(G, scratch, l2, ix, lane);
+      key = k > key ? k : key;
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
   if (lane == 0) {
     res->status = 0;
     res->v[0] = (int32_t)(key >> 40);
@@ -1765,7 +1793,7 @@ __device__ __forceinline__ void wave_jobs_body(const int block, const int wave, 
     case KF_ED:      lev_any_dispatch<MODE_ED, false>(job, res, ws, lane); break;
     case KF_BORDERS: lev_wave_body<1, MODE_BORDERS>(job, res, ws, lane, s_borders); break;
     case KF_AFFIX:   lev_wave_body<1, MODE_AFFIX>(job, res, ws, lane); break;
-    case KF_LCFSA:   lcfsa_wave_body(job, res, ix, lane); break;
+    case KF_LCFSA:   lcfsa_wave_body(job, res, ix, lane, reinterpret_cast<uint8_t*>(s_borders)); break;
     case KF_LCFW:    lcf_small_wave_body(job, res, lane); break;
     case KF_ALIGNB: {                    // see align_band_sweep; the host chose the jobs (more than 64 rows, lengths within the band)
       const uint32_t n = job.la, m = job.lb;

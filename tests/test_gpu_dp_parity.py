@@ -343,9 +343,10 @@ def test_lcf_from_the_suffix_array(O, merged, monkeypatch):
     the resident suffix array (lcfsa_wave_body) instead of the 46 x |prefix| matrix: same length, same first
     maximum (smallest start in the genomic, then in the EST) as the oracle on random sequences, planted
     factors, repeats (microsatellites, duplicated blocks: many suffixes share the pattern, so the range
-    minima decide), tiny alphabets, prefixes that cut an occurrence, empty operands -- and the jobs that do
-    not qualify (an N on either side, more than 64 characters, a prefix beyond the first non-ACGT character)
-    still get the matrix kernel's answer.  In every launch mode of the library."""
+    minima decide), tiny alphabets, prefixes that cut an occurrence, empty operands; an EST prefix with ONE N
+    (upper or lower case) is answered there too -- the four strings with A, C, G, T in its place -- and the jobs
+    that do not qualify (two Ns, an N in the genomic prefix, more than 64 characters, a prefix beyond the first
+    non-ACGT character) still get the matrix kernel's answer.  In every launch mode of the library."""
     import pintron_amd.capi as capi
     monkeypatch.setenv("PGPU_MERGED", merged)
     rng = random.Random(77 + int(merged))
@@ -387,6 +388,13 @@ def test_lcf_from_the_suffix_array(O, merged, monkeypatch):
                         k = min(k, n - p)
                         q = rng.randint(0, l2 - k)
                         s2[q:q + k] = mixed[p:p + k]
+                    # ONE wildcard in the EST prefix (the four substitutions are searched by the same wave): inside the
+                    # planted factor, at either end, lower case; now and then a second one (the matrix kernel's case)
+                    if len(s2) >= 1 and it % 3 == 1:
+                        s2 = bytearray(bytes(s2).replace(b"N", b"A"))
+                        s2[rng.choice([0, len(s2) - 1, rng.randrange(len(s2))])] = ord("n") if it % 6 == 1 else ord("N")
+                        if it % 15 == 1 and len(s2) >= 2:
+                            s2[rng.randrange(len(s2))] = ord("N")
                     cases.append(D.Case(D.LCF, mixed[:G], bytes(s2)))
                     jl.add(capi.LCF, mixed[:G], bytes(s2), a_gen_off=0)
                 out = capi.run_jobs(ctx, jl, idx)
