@@ -13,7 +13,7 @@ export TMPDIR=/tmp
 # call, seen in about one profiled run out of ten, never without the profiler): try up to 3 times
 for attempt in 1 2 3; do
   rm -rf gpurun_out/prof_bench
-  if rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_bench -o bench -- python3 bench.py --workload $W --steps 5 --warmup 1 --no-cpu --no-oneshot > gpurun_out/bench_under_rocprof_$TAG.json 2> gpurun_out/rocprof.err; then break; fi
+  if rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_bench -o bench -- python3 bench.py --workload $W --steps 5 --warmup 1 --no-cpu --no-oneshot --no-extra > gpurun_out/bench_under_rocprof_$TAG.json 2> gpurun_out/rocprof.err; then break; fi
   echo "rocprofv3 attempt $attempt failed"; tail -3 gpurun_out/rocprof.err
   [ $attempt = 3 ] && exit 1
 done
