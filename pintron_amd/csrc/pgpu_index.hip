@@ -601,8 +601,20 @@ static hipError_t build_lcf_tables(pgpu_index* idx, const char* genomic, hipStre
                                                hipGetErrorString(e_)); goto done; }          \
   } while (0)
 
+static double idx_now_ms() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
+
 extern "C" int pgpu_index_build(pgpu_ctx* ctx, const char* genomic, size_t len, pgpu_index** out) {
   if (!ctx || !out || (len && !genomic)) return PGPU_EINVAL;
+  const bool timing = getenv("PGPU_INDEX_TIMING") != nullptr;      // phases of the construction, to stderr
+  double t_mark = idx_now_ms();
+  int n_rounds = 0;
+  auto mark = [&](const char* what, hipStream_t s) {
+    if (!timing) return;
+    hipStreamSynchronize(s);
+    const double t = idx_now_ms();
+    fprintf(stderr, "* index build: %-28s %7.2f ms\n", what, t - t_mark);
+    t_mark = t;
+  };
   *out = nullptr;
   if (len >= (1u << 28)) return pgpu_ctx_fail(ctx, PGPU_ERANGE, "genomic longer than 2^28");
   if (pgpu_ctx_bind(ctx) != PGPU_OK) return PGPU_EDEVICE;
@@ -637,7 +649,9 @@ extern "C" int pgpu_index_build(pgpu_ctx* ctx, const char* genomic, size_t len, 
       TRY_HIP(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
     }
     hipLaunchKernelGGL(sa_init_kernel, grd, blk, 0, st, idx->d_gen, n, rank, idx->d_sa);
+    mark("allocations + upload", st);
     for (uint32_t h = 0;; h = h ? h * 2 : 1) {
+      ++n_rounds;
       // h == 0: sort by the first character alone (key low half = 0 because i+0 < n gives rank[i]
       // again -- harmless duplicate), afterwards by (rank of 2^k prefix, rank of the next 2^k)
       hipLaunchKernelGGL(sa_keys_kernel, grd, blk, 0, st, rank, idx->d_sa, n, h ? h : n, keys);
@@ -661,6 +675,8 @@ extern "C" int pgpu_index_build(pgpu_ctx* ctx, const char* genomic, size_t len, 
       if (h >= n) { rc = pgpu_ctx_fail(ctx, PGPU_EDEVICE, "suffix array construction did not converge"); goto done; }
     }
   }
+  if (timing) fprintf(stderr, "* index build: %d sort rounds\n", n_rounds);
+  mark("suffix array (sort rounds)", st);
   {
     // round 0 ranked by 1 character (h == 0), round j >= 1 by 2^j characters: ranks[r] <-> 2^r
     const int nr = (int)round_ranks.size();
@@ -668,13 +684,16 @@ extern "C" int pgpu_index_build(pgpu_ctx* ctx, const char* genomic, size_t len, 
     if (nr) TRY_HIP(hipMemcpyAsync(d_round_ptrs, round_ranks.data(), nr * sizeof(uint32_t*), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(lcp_from_ranks_kernel, grd, blk, 0, st, (const uint32_t* const*)d_round_ptrs, nr, idx->d_sa, n, idx->d_lcp);
   }
+  mark("LCP from the ranks", st);
   TRY_HIP(dmalloc(&idx->d_klo, KTAB_ENTRIES));
   TRY_HIP(dmalloc(&idx->d_khi, KTAB_ENTRIES));
   TRY_HIP(hipMemsetAsync(idx->d_klo, 0, KTAB_ENTRIES * sizeof(uint32_t), st));
   TRY_HIP(hipMemsetAsync(idx->d_khi, 0, KTAB_ENTRIES * sizeof(uint32_t), st));
   if (n > 0) hipLaunchKernelGGL(kmer_table_kernel, grd, blk, 0, st, idx->d_gen, n, idx->d_sa, idx->d_klo, idx->d_khi);
+  mark("8-mer table", st);
   TRY_HIP(build_lcf_tables(idx, genomic, st));
   TRY_HIP(hipStreamSynchronize(st));
+  mark("packing + LCF tables", st);
   TRY_HIP(hipGetLastError());
 done:
   hipFree(rank); hipFree(sa2); hipFree(flags); hipFree(newrank); hipFree(keys); hipFree(keys2); hipFree(tmp);

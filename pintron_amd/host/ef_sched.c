@@ -948,6 +948,49 @@ static void bind_to_numa_node(int node) {
   if (n >= 2 && sched_setaffinity(0, sizeof want, &want) == 0) numa_bound = node;
 }
 
+/* ---- what outlives a session --------------------------------------------------------------------------
+ * A process that runs one batch after the other (est-fact --genes, a library user that brings fresh batches:
+ * bench.py's fresh_batch leg) used to take everything apart at the end of a session and make it again for the
+ * next: five GPU contexts with their streams, device pools and page-locked buffers, twelve thousand guard-paged
+ * fibre stacks, the output chunks, the page-locked slabs of the prefetch stage -- 0.21 s to close and 0.03 s +
+ * a slow first step to open, beside a 0.10 s step.  None of it depends on the gene: it is kept here between
+ * sessions (PINTRON_KEEP=0: not), handed to the next session that asks, and ends with the process. */
+static struct {
+  pthread_mutex_t mu;
+  fiber* fibers; size_t stack_size;
+  out_chunk* chunks;
+  pgpu_ctx* ctx[2 * MAX_SERVICES + 2]; int ctx_device[2 * MAX_SERVICES + 2]; int n_ctx;
+  unsigned char* pre_slab; size_t pre_slab_cap; char* up_stage; size_t up_stage_cap;
+} kept = { PTHREAD_MUTEX_INITIALIZER, NULL, 0, NULL, { NULL }, { 0 }, 0, NULL, 0, NULL, 0 };
+static bool keep_on(void) { const char* e = getenv("PINTRON_KEEP"); return !(e && e[0] == '0' && e[1] == '\0'); }
+
+/* a GPU context on `device`: one kept from an earlier session, else a new one */
+static int ctx_take(int device, pgpu_ctx** out) {
+  pthread_mutex_lock(&kept.mu);
+  for (int k = 0; k < kept.n_ctx; ++k)
+    if (kept.ctx_device[k] == device) {
+      *out = kept.ctx[k];
+      kept.ctx[k] = kept.ctx[kept.n_ctx - 1]; kept.ctx_device[k] = kept.ctx_device[kept.n_ctx - 1]; --kept.n_ctx;
+      pthread_mutex_unlock(&kept.mu);
+      return PGPU_OK;
+    }
+  pthread_mutex_unlock(&kept.mu);
+  return pgpu_init(device, out);
+}
+static void ctx_give(pgpu_ctx* ctx, int device) {
+  if (!ctx) return;
+  if (keep_on()) {
+    pthread_mutex_lock(&kept.mu);
+    if (kept.n_ctx < (int)(sizeof kept.ctx / sizeof kept.ctx[0])) {
+      kept.ctx[kept.n_ctx] = ctx; kept.ctx_device[kept.n_ctx] = device; ++kept.n_ctx;
+      pthread_mutex_unlock(&kept.mu);
+      return;
+    }
+    pthread_mutex_unlock(&kept.mu);
+  }
+  pgpu_destroy(ctx);
+}
+
 /* ---- sessions: inputs + index + patterns resident; a step = the whole per-EST pipeline ------------ */
 struct ef_session {
   ef_inputs in;
@@ -959,6 +1002,7 @@ struct ef_session {
   size_t nthreads;
   double load_s, index_s;
   /* the fibres of the first step (structure + guarded stack) are made while the GPU runtime comes up */
+  int device;                              /* the GPU of this session (its contexts go back to `kept` under it) */
   pthread_t pool_thread[2]; int n_pool_threads;
   struct pool_job { shared* sh; size_t count; } pool_job[2];
 };
@@ -997,8 +1041,8 @@ typedef struct {
 static void boot_service_contexts(gpu_boot* b) {
   b->svc_rc = PGPU_OK;
   for (int k = 0; k < b->n_svc && b->svc_rc == PGPU_OK; ++k) {
-    b->svc_rc = pgpu_init(ef_gpu_device_from_env(), &b->svc[k]);
-    if (b->svc_rc == PGPU_OK && env_flag("PINTRON_KERNEL_TIMING")) pgpu_set_timing(b->svc[k], 1);
+    b->svc_rc = ctx_take(ef_gpu_device_from_env(), &b->svc[k]);
+    if (b->svc_rc == PGPU_OK) pgpu_set_timing(b->svc[k], env_flag("PINTRON_KERNEL_TIMING") ? 1 : 0);
   }
 }
 static void* boot_service_contexts_main(void* arg) {
@@ -1012,10 +1056,10 @@ static void* gpu_boot_main(void* arg) {
   pthread_setname_np(pthread_self(), "ef-gpu-boot");
   gpu_boot* b = (gpu_boot*)arg;
   const double tb0 = now_s();
-  b->rc = pgpu_init(ef_gpu_device_from_env(), &b->ctx);
+  b->rc = ctx_take(ef_gpu_device_from_env(), &b->ctx);
   b->t_init = now_s() - tb0;
   if (b->rc == PGPU_OK) {
-    if (env_flag("PINTRON_KERNEL_TIMING")) pgpu_set_timing(b->ctx, 1);
+    pgpu_set_timing(b->ctx, env_flag("PINTRON_KERNEL_TIMING") ? 1 : 0);
     /* the runtime is up: the service threads' contexts (a stream each) are made beside the index */
     pthread_t svc_thread;
     const bool svc_started = pthread_create(&svc_thread, NULL, boot_service_contexts_main, b) == 0;
@@ -1086,10 +1130,23 @@ ef_session* ef_session_open(int argc, char** argv) {
   ef_classify_init();
   const double t_loaded = now_s();
   ef_info_mark("data-io-end");
+  s->device = ef_gpu_device_from_env();
+  size_t kept_fibers = 0;
+  {                                            /* what an earlier session of this process left (see `kept`) */
+    const size_t stack_size = env_size("PINTRON_FIBER_STACK_KB", 256) * 1024;
+    pthread_mutex_lock(&kept.mu);
+    if (kept.fibers && kept.stack_size == stack_size) { s->sh.fiber_pool = kept.fibers; kept.fibers = NULL; }
+    s->sh.spare_chunks = kept.chunks; kept.chunks = NULL;
+    s->sh.pre_slab = kept.pre_slab; s->sh.pre_slab_cap = kept.pre_slab_cap; kept.pre_slab = NULL; kept.pre_slab_cap = 0;
+    s->sh.up_stage = kept.up_stage; s->sh.up_stage_cap = kept.up_stage_cap; kept.up_stage = NULL; kept.up_stage_cap = 0;
+    pthread_mutex_unlock(&kept.mu);
+    for (fiber* f = s->sh.fiber_pool; f; f = f->pool_next) ++kept_fibers;
+  }
   if (load_rc == 0 && !getenv("PINTRON_NO_FIBER_POOL")) {
     s->sh.stack_size = env_size("PINTRON_FIBER_STACK_KB", 256) * 1024;
     size_t want = env_size("PINTRON_THREADS", host_core_share()) * env_size("PINTRON_FIBERS", 768);
     if (want > s->in.n) want = s->in.n;                 /* never more fibres than sequences */
+    want = want > kept_fibers ? want - kept_fibers : 0;
     if (want >= 64) {
       for (int t = 0; t < 2; ++t) {
         s->pool_job[t].sh = &s->sh; s->pool_job[t].count = want / 2;
@@ -1610,7 +1667,14 @@ void ef_session_close(ef_session* s) {
   shared* sh = &s->sh;
   for (int t = 0; t < s->n_pool_threads; ++t) pthread_join(s->pool_thread[t], NULL);
   s->n_pool_threads = 0;
-  free_unit_buffers(sh, true);
+  free_unit_buffers(sh, !keep_on());
+  if (keep_on() && sh->spare_chunks) {
+    pthread_mutex_lock(&kept.mu);
+    out_chunk* last = sh->spare_chunks;
+    while (last->next) last = last->next;
+    last->next = kept.chunks; kept.chunks = sh->spare_chunks; sh->spare_chunks = NULL;
+    pthread_mutex_unlock(&kept.mu);
+  }
   merge_worker_pools(sh);
   if (getenv("PINTRON_STACK_STATS")) {      /* how deep did the fibres' stacks get? (first byte written above the sentinel) */
     size_t n = 0, sum = 0, mx = 0;
@@ -1621,6 +1685,16 @@ void ef_session_close(ef_session* s) {
       ++n; sum += used; if (used > mx) mx = used;
     }
     fprintf(stderr, "* fibre stacks: %zu fibres, %zu B used on average, %zu B at most (of %zu)\n", n, n ? sum / n : 0, mx, sh->stack_size);
+  }
+  if (keep_on() && sh->fiber_pool && sh->stack_size) {           /* the fibres (stacks, sink blocks) wait for the next session */
+    pthread_mutex_lock(&kept.mu);
+    if (!kept.fibers || kept.stack_size == sh->stack_size) {
+      fiber* last = sh->fiber_pool;
+      while (last->pool_next) last = last->pool_next;
+      last->pool_next = kept.fibers; kept.fibers = sh->fiber_pool; kept.stack_size = sh->stack_size;
+      sh->fiber_pool = NULL;
+    }
+    pthread_mutex_unlock(&kept.mu);
   }
   while (sh->fiber_pool) {
     fiber* nx = sh->fiber_pool->pool_next;
@@ -1636,11 +1710,17 @@ void ef_session_close(ef_session* s) {
     if (sh->pre_meg_first[c] && sh->pre_first_own[c]) pgpu_host_free(s->ctx0, sh->pre_meg_first[c]);
     if (s->pplan[c]) pgpu_pairing_plan_destroy(s->ctx0, s->pplan[c]);
   }
+  if (keep_on() && s->ctx0) {                  /* the page-locked slabs too (0.25 s per GB to get) */
+    pthread_mutex_lock(&kept.mu);
+    if (sh->pre_slab && !kept.pre_slab) { kept.pre_slab = sh->pre_slab; kept.pre_slab_cap = sh->pre_slab_cap; sh->pre_slab = NULL; }
+    if (sh->up_stage && !kept.up_stage) { kept.up_stage = sh->up_stage; kept.up_stage_cap = sh->up_stage_cap; sh->up_stage = NULL; }
+    pthread_mutex_unlock(&kept.mu);
+  }
   if (sh->pre_slab) pgpu_host_free(s->ctx0, sh->pre_slab);
   if (sh->up_stage) pgpu_host_free(s->ctx0, sh->up_stage);
-  for (int k = 0; k < MAX_SERVICES; ++k) if (sh->svc.threads[k].ctx) pgpu_destroy(sh->svc.threads[k].ctx);
   if (s->ctx0 && sh->idx) pgpu_index_destroy(s->ctx0, sh->idx);
-  if (s->ctx0) pgpu_destroy(s->ctx0);
+  for (int k = 0; k < MAX_SERVICES; ++k) ctx_give(sh->svc.threads[k].ctx, s->device);
+  ctx_give(s->ctx0, s->device);
   ef_free_inputs(&s->in);
   pthread_mutex_destroy(&sh->mu); pthread_cond_destroy(&sh->ready_cv);
   pthread_mutex_destroy(&sh->svc.mu); pthread_cond_destroy(&sh->svc.posted); pthread_cond_destroy(&sh->svc.finished);
