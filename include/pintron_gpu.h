@@ -212,7 +212,12 @@ enum pgpu_dp_kind {
    * = compute_edit_distance (src/compute-alignments.c:240-249).  v[0]=distance. */
   PGPU_DP_ED = 2,
   /* K_band_edit_distance (src/compute-alignments.c:319-453): p0 = upper_bound.
-   * v[0]=returned bool, v[1]=*edit. */
+   * v[0]=returned bool, v[1]=*edit.
+   * tail = 1 ("exon check", a = the exon on the genomic sequence, b = on the EST): also the two comparisons of
+   * clean_low_complexity_exons_2 (src/est-factorizations.c:1687-1691) for this exon -- dustScore
+   * (src/exon-complexity.c:50-78) of each operand against the threshold whose IEEE double bits are p1 (low word)
+   * and p2 (high word): v[2] bit 0 = dust(a) > threshold, bit 1 = dust(b) > threshold.  The score is computed in
+   * FP64 in the reference's operation order (integer sum, x 10.0, / (length - 2), / length). */
   PGPU_DP_KBAND = 3,
   /* find_longest_common_factor_dp (src/factorization-refinement.c:255-316): a = s1, b = s2.
    * v[0]=len v[1]=occ1 v[2]=occ2. */

@@ -176,6 +176,29 @@ uint32_t orc_best_prefix_cut(const char* s1, size_t l1, const char* s2, size_t l
  * reference keeps two rolling rows and never re-initialises them, so a slot that a row does not
  * write still holds what was written two rows before; we keep that behaviour by using two rows
  * and writing exactly the slots the reference writes. */
+/* getDinucleotideIndex (src/exon-complexity.c:80-130): A, C, G, T in either case -> 4 * first + second, anything else 16 */
+static int dust_base(char c) {
+  switch (c) { case 'a': case 'A': return 0; case 'c': case 'C': return 1; case 'g': case 'G': return 2; case 't': case 'T': return 3; default: return -1; }
+}
+/* dustScore (src/exon-complexity.c:50-78): every dinucleotide adds the number of times it has been seen before;
+ * 10 x that sum / (length - 2), then / length; 0 for fewer than three characters */
+double orc_dust_score(const char* s, size_t len) {
+  if ((int)len <= 2) return 0.0;
+  int freq[17] = { 0 };
+  int running = 0;
+  for (int i = 0; i < (int)len - 1; ++i) {
+    const int a = dust_base(s[i]), b = dust_base(s[i + 1]);
+    const int index = (a < 0 || b < 0) ? 16 : 4 * a + b;
+    running += freq[index];
+    freq[index]++;
+  }
+  const double dust = (10.0 * (double)running) / ((double)(len - 2));
+  return dust / len;
+}
+uint32_t orc_dust_flags(const char* gen, size_t lg, const char* est, size_t le, double threshold) {
+  return (orc_dust_score(gen, lg) > threshold ? 1u : 0u) | (orc_dust_score(est, le) > threshold ? 2u : 0u);
+}
+
 int orc_kband(const char* seq1, size_t l1, const char* seq2, size_t l2, uint32_t upper_bound,
               uint32_t* edit) {
   if (l1 == l2 && memcmp(seq1, seq2, l1) == 0) { *edit = 0; return 1; }

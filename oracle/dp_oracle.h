@@ -46,6 +46,11 @@ uint32_t orc_best_prefix_cut(const char* s1, size_t l1, const char* s2, size_t l
 
 /* ---- K-band edit distance: K_band_edit_distance (src/compute-alignments.c:319-453) ---- */
 /* returns 1 when *edit <= upper_bound (the reference's bool), else 0 */
+/* dustScore (src/exon-complexity.c:50-78) of s[0..len) */
+double orc_dust_score(const char* s, size_t len);
+/* the two comparisons of clean_low_complexity_exons_2 (src/est-factorizations.c:1687-1691) for one exon: bit 0 the
+ * genomic side's score > threshold, bit 1 the EST side's */
+uint32_t orc_dust_flags(const char* gen, size_t lg, const char* est, size_t le, double threshold);
 int orc_kband(const char* seq1, size_t l1, const char* seq2, size_t l2, uint32_t upper_bound,
               uint32_t* edit);
 

@@ -56,6 +56,7 @@ uint64_t orc_dp_batch(const pgpu_dp_job* jobs, size_t n, const char* arena, cons
         uint32_t e;
         r->v[0] = orc_kband(a, la, b, lb, j->p0, &e);
         r->v[1] = (int32_t)e;
+        if (j->tail) { double thr; const uint32_t w[2] = { j->p1, j->p2 }; memcpy(&thr, w, 8); r->v[2] = (int32_t)orc_dust_flags(a, la, b, lb, thr); }
         cells += orc_cells_kband(a, la, b, lb, j->p0);
         break;
       }

@@ -302,7 +302,7 @@ class JobList:
         return off
 
     def add(self, kind, a: bytes, b: bytes, p0=0, p1=0, p2=0, b_tail: bytes = b"",
-            a_gen_off=None, b_gen_off=None):
+            a_gen_off=None, b_gen_off=None, tail=None):
         """a/b are operand bytes; with *_gen_off the operand is the slice [off, off+len) of the
         resident genomic instead (a/b then only supply the length)."""
         flags = 0
@@ -315,7 +315,7 @@ class JobList:
         else:
             b_off, flags = b_gen_off, flags | JOB_B_GENOMIC
         self.jobs.append(DpJob(kind, flags, a_off, b_off, len(a), len(b), p0, p1, p2,
-                               len(b_tail)))
+                               len(b_tail) if tail is None else tail))
         return len(self.jobs) - 1
 
     def arrays(self):
@@ -402,7 +402,7 @@ def decode(kind, r: DpResult, strings: bytes):
     if kind == ED:
         return dict(status=0, score=v[0])
     if kind == KBAND:
-        return dict(status=0, ok=v[0], edit=v[1])
+        return dict(status=0, ok=v[0], edit=v[1], dust=v[2])       # dust: the exon check's two flags (jobs with tail = 1)
     if kind == LCF:
         return dict(status=0, len=v[0], occ1=v[1], occ2=v[2])
     if kind == BORDERS:

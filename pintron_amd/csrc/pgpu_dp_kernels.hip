@@ -394,6 +394,40 @@ enum { MODE_ED = 0, MODE_ALIGN = 1, MODE_BORDERS = 2, MODE_AFFIX = 3, MODE_KBAND
 // workspace starts with the two boundary rows (strip_bnd_bytes each), ALIGN directions follow,
 // one block of (columns + 64) * 64 * 16 bytes per strip.
 
+// dustScore (src/exon-complexity.c:50-78) of s[0..len) on one wave: every dinucleotide adds the number of times it has
+// been seen before, i.e. the sum over the 17 dinucleotide classes (getDinucleotideIndex :80-130: A, C, G, T in either
+// case, everything else class 16) of f (f - 1) / 2 for their final counts f -- an integer, so the FP64 arithmetic that
+// follows (x 10.0, / (length - 2), / length) sees the reference's running total.  The counts come from ballots over 64
+// positions at a time.  Same value in every lane.
+__device__ __noinline__ double dust_score_wave(const uint8_t* __restrict__ s, const uint32_t len, const uint32_t lane) {
+  if ((int)len <= 2) return 0.0;
+  uint32_t cnt[17];
+#pragma unroll
+  for (int b = 0; b < 17; ++b) cnt[b] = 0u;
+  const uint32_t nd = len - 1u;                  // dinucleotides
+  for (uint32_t base = 0; base < nd; base += 64u) {
+    const uint32_t i = base + lane;
+    int cls = -1;                                // no dinucleotide on this lane
+    if (i < nd) {
+      const int x = base_code(s[i]), y = base_code(s[i + 1]);
+      cls = (x < 0 || y < 0) ? 16 : 4 * x + y;
+    }
+#pragma unroll
+    for (int b = 0; b < 17; ++b) cnt[b] += (uint32_t)__popcll(__ballot(cls == b));
+  }
+  unsigned long long running = 0ull;
+#pragma unroll
+  for (int b = 0; b < 17; ++b) running += (unsigned long long)cnt[b] * (cnt[b] - (cnt[b] ? 1u : 0u)) / 2ull;
+  const double dust = (10.0 * (double)running) / ((double)(len - 2u));
+  return dust / (double)len;
+}
+// the exon check's flags (pgpu_gpu.h: KBAND with tail = 1): bit 0 dust(a) > threshold, bit 1 dust(b) > threshold
+__device__ __forceinline__ uint32_t dust_flags_wave(const DevJob& job, const uint32_t lane) {
+  const double thr = __longlong_as_double((long long)(((unsigned long long)job.p2 << 32) | (unsigned long long)job.p1));
+  const double da = dust_score_wave(job.a, job.la, lane), db = dust_score_wave(job.b, job.lb, lane);
+  return (da > thr ? 1u : 0u) | (db > thr ? 2u : 0u);
+}
+
 // K_band_edit_distance (src/compute-alignments.c:375-443) with THE BAND ON THE LANES: lane s owns
 // slot s of the reference's 2k+1 wide row buffers, i.e. the diagonal column - row = s - k, and the
 // wave walks down the rows.  Cell (r, s) needs (r-1, s) [diagonal: the lane's own previous value],
@@ -583,6 +617,10 @@ __device__ __forceinline__ void lev_wave_body(const DevJob& job, DevResult* res,
   } else if constexpr (MODE == MODE_KBAND) {
     // K_band_edit_distance (src/compute-alignments.c:319-453): early exits in the reference's
     // order, then the banded DP (or the full matrix when 2k+1 >= n, :370-373).  rows = shorter.
+    if (job.tail != 0u) {                                    // exon check: the two dust comparisons beside the distance
+      const uint32_t fl = dust_flags_wave(job, lane);
+      if (lane == 0) res->v[2] = (int32_t)fl;
+    }
     const uint32_t ub = job.p0;
     const bool swap = job.la < job.lb;                       // reference: seq1 becomes the longer
     const uint8_t* lng = swap ? job.b : job.a; const uint8_t* sht = swap ? job.a : job.b;

@@ -384,17 +384,47 @@ static void endpoint_release(ef_dp_req* q, ef_dp_res* r) {
   ef_dp_res_release(r);
 }
 
-static ef_list* handle_endpoints(ef_list* fact, const char* gen, const char* est, ef_backend* be) {
+static unsigned max_edit_for_exon(size_t exon_length);
+/* The "exon check" of one exon (include/pintron_gpu.h: KBAND with tail = 1): the banded edit distance clean_noisy_exons
+ * asks for (:1842-1898) and, beside it, the two dust-score comparisons of clean_low_complexity_exons_2 (:1667-1704) --
+ * both look at the same two strings, the exon on the genomic sequence and on the EST.  false: the exon is empty on
+ * the genomic sequence (neither routine looks at it). */
+static bool exon_check_request(ef_dp_req* q, const ef_factor* x, const char* gen, const char* est, const ef_config* cfg) {
+  if (x->GEN_start > x->GEN_end) return false;
+  uint32_t w[2];
+  memcpy(w, &cfg->complexity_threshold, 8);
+  const ef_dp_req r = { EF_DP_KBAND, gen + x->GEN_start, view_len(gen, x->GEN_start, x->GEN_end - x->GEN_start + 1),
+                        est + x->EST_start, view_len(est, x->EST_start, x->EST_end - x->EST_start + 1),
+                        max_edit_for_exon((size_t)(x->GEN_end - x->GEN_start + 1)), w[0], w[1], 1, 0 };
+  *q = r;
+  return true;
+}
+
+static ef_list* handle_endpoints(ef_list* fact, const char* gen, const char* est, const ef_config* cfg, ef_backend* be) {
   ef_factor* head = (ef_factor*)efl_head(fact);
   ef_dp_req q[2]; ef_dp_res r[2];
   if (efl_size(fact) >= 2) {
     ef_factor* tail = (ef_factor*)efl_tail(fact);
-    endpoint_request(&q[0], head, gen, est);
-    endpoint_request(&q[1], tail, gen, est);
-    if (ef_dp_many(be, q, r, 2) != 0) { fprintf(stderr, "* FATAL alignment backend failed\n"); abort(); }
-    endpoint_head_apply(fact, head, &r[0]);
-    endpoint_tail_apply(fact, tail, &r[1]);      /* `tail` is not the exon the head step touched */
-    endpoint_release(&q[0], &r[0]); endpoint_release(&q[1], &r[1]);
+    /* the exon checks of the INTERNAL exons (their coordinates are final here) go out with the two alignments; their
+     * answers are kept for the cleaning steps that follow (estfact.h: ef_ahead) */
+    enum { INNER_MAX = 22 };
+    ef_dp_req qq[2 + INNER_MAX]; ef_dp_res rr[2 + INNER_MAX]; size_t nq = 2;
+    endpoint_request(&qq[0], head, gen, est);
+    endpoint_request(&qq[1], tail, gen, est);
+    if (be->ahead && efl_size(fact) >= 3 && efl_size(fact) <= INNER_MAX) {
+      ef_iter it = efl_begin(fact);
+      efi_next(&it);
+      while (efi_has_next(&it)) {
+        const ef_factor* x = (const ef_factor*)efi_next(&it);
+        if (x == tail) break;
+        if (exon_check_request(&qq[nq], x, gen, est, cfg)) ++nq;
+      }
+    }
+    if (ef_dp_many(be, qq, rr, nq) != 0) { fprintf(stderr, "* FATAL alignment backend failed\n"); abort(); }
+    for (size_t k = 2; k < nq; ++k) ef_ahead_put(be->ahead, &qq[k], rr[k].v);
+    endpoint_head_apply(fact, head, &rr[0]);
+    endpoint_tail_apply(fact, tail, &rr[1]);     /* `tail` is not the exon the head step touched */
+    endpoint_release(&qq[0], &rr[0]); endpoint_release(&qq[1], &rr[1]);
     return fact;
   }
   endpoint_request(&q[0], head, gen, est);
@@ -457,46 +487,6 @@ ef_list* ef_clean_external_exons(ef_list* fact, const char* gen, const char* est
   return fact;
 }
 
-/* dustScoreByLeftAndRight / dustScore (src/exon-complexity.c:38-79): the substring is scanned in
- * place (real_substring stops at the terminator, so does the scan) */
-static const signed char base_index_tab[256] = {
-  ['A'] = 1, ['a'] = 1, ['C'] = 2, ['c'] = 2, ['G'] = 3, ['g'] = 3, ['T'] = 4, ['t'] = 4 };
-static inline int base_index(unsigned char c) { return base_index_tab[c] - 1; }    /* ACGT -> 0..3, else -1 */
-static double dust_score(const char* s, int start, int end) {
-  int want = end - start + 1;
-  if (start < 0) { want += start; start = 0; }          /* real_substring clamps a negative index */
-  if (want < 0) want = 0;
-  const unsigned char* sub = (const unsigned char*)s + start;
-  const unsigned char* z = want ? (const unsigned char*)memchr(sub, 0, (size_t)want) : NULL;
-  const size_t len = z ? (size_t)(z - sub) : (size_t)want;
-  double r = 0.0;
-  if ((int)len > 2) {
-    /* the reference adds, per dinucleotide, the number of times it has been seen before
-     * (src/exon-complexity.c:50-78): the sum over the dinucleotides of f (f - 1) / 2 for their final counts f.
-     * Counting first takes the add chain through the table out of the loop; four tables (positions mod 4)
-     * keep a run of one dinucleotide from serialising on a single counter.  The sum is an integer, so the
-     * double arithmetic that follows sees the same value as the reference's running total. */
-    unsigned f4[4][18];
-    memset(f4, 0, sizeof f4);
-    const int m = (int)len - 1;                        /* dinucleotides */
-    int x = base_index(sub[0]), i = 0;
-    for (; i + 4 <= m; i += 4) {
-      const int y0 = base_index(sub[i + 1]), y1 = base_index(sub[i + 2]), y2 = base_index(sub[i + 3]), y3 = base_index(sub[i + 4]);
-      ++f4[0][(x < 0 || y0 < 0) ? 16 : 4 * x + y0];
-      ++f4[1][(y0 < 0 || y1 < 0) ? 16 : 4 * y0 + y1];
-      ++f4[2][(y1 < 0 || y2 < 0) ? 16 : 4 * y1 + y2];
-      ++f4[3][(y2 < 0 || y3 < 0) ? 16 : 4 * y2 + y3];
-      x = y3;
-    }
-    for (; i < m; ++i) { const int y = base_index(sub[i + 1]); ++f4[0][(x < 0 || y < 0) ? 16 : 4 * x + y]; x = y; }
-    long long running = 0;
-    for (int k = 0; k < 17; ++k) { const long long f = (long long)f4[0][k] + f4[1][k] + f4[2][k] + f4[3][k]; running += f * (f - 1) / 2; }
-    const double dust = (10.0 * (double)running) / ((double)(len - 2));
-    r = dust / len;
-  }
-  return r;
-}
-
 /* update_with_subfact_with_best_coverage (:1900-1987): split_idx = 1-based indices of bad exons */
 static ef_list* keep_best_run(ef_list* fact, const int* split_idx, int n_split) {
   if (n_split == 0) return fact;
@@ -529,24 +519,6 @@ static ef_list* keep_best_run(ef_list* fact, const int* split_idx, int n_split) 
     for (int k = best_l - 1; k > 0; --k) free(efl_pop_front(fact));
     for (int k = best_r + 1; k <= size; ++k) free(efl_pop_back(fact));
   }
-  return fact;
-}
-
-/* clean_low_complexity_exons_2 (:1667-1704) */
-static ef_list* clean_low_complexity(ef_list* fact, const char* gen, const char* est, const ef_config* cfg) {
-  int idx_small[64];
-  int* idx = efl_size(fact) < 64 ? idx_small : (int*)malloc((efl_size(fact) + 1) * sizeof(int));
-  int n = 0, index = 1;
-  ef_iter it = efl_begin(fact);
-  while (efi_has_next(&it)) {
-    const ef_factor* x = (const ef_factor*)efi_next(&it);
-    double gd = 0.0, ed = 0.0;
-    if (x->GEN_start <= x->GEN_end) { gd = dust_score(gen, x->GEN_start, x->GEN_end); ed = dust_score(est, x->EST_start, x->EST_end); }
-    if (gd > cfg->complexity_threshold || ed > cfg->complexity_threshold) idx[n++] = index;
-    ++index;
-  }
-  fact = keep_best_run(fact, idx, n);
-  if (idx != idx_small) free(idx);
   return fact;
 }
 
@@ -859,6 +831,54 @@ static bool detect_polyA(ef_list* fact, const char* gen, const char* est, bool* 
 /* ---------------------------------------------------------------------------------------------- */
 /* get_EST_factorizations (src/est-factorizations.c:126-594)                                       */
 /* ---------------------------------------------------------------------------------------------- */
+/* clean_low_complexity_exons_2 (:1667-1704) and clean_noisy_exons (:1842-1898) of one candidate, from ONE request: the
+ * exon check of every exon (dust comparisons + banded distance, computed side by side on the device).  The first
+ * routine keeps the best run of exons that are not low-complexity, the second -- on what is left -- the best run of
+ * exons within their error bound; dropping exons does not change the others' strings, so every exon's answers stay
+ * valid. */
+static ef_list* clean_complexity_and_noise(ef_list* fact, const char* gen, const char* est, const ef_config* cfg, ef_backend* be) {
+  const size_t size = efl_size(fact);
+  enum { SMALL = 24 };
+  const ef_factor* x_small[SMALL]; int slot_small[SMALL], idx_small[SMALL]; ef_dp_req rq_small[SMALL]; ef_dp_res rs_small[SMALL];
+  const bool small = size < SMALL;
+  const ef_factor** xs = small ? x_small : (const ef_factor**)malloc((size + 1) * sizeof(ef_factor*));
+  int* slot = small ? slot_small : (int*)malloc((size + 1) * sizeof(int));
+  int* idx = small ? idx_small : (int*)malloc((size + 1) * sizeof(int));
+  ef_dp_req* rq = small ? rq_small : (ef_dp_req*)malloc((size + 1) * sizeof(ef_dp_req));
+  ef_dp_res* rs = small ? rs_small : (ef_dp_res*)malloc((size + 1) * sizeof(ef_dp_res));
+  size_t nx = 0, nrq = 0;
+  ef_iter it = efl_begin(fact);
+  while (efi_has_next(&it)) {
+    const ef_factor* x = (const ef_factor*)efi_next(&it);
+    xs[nx] = x;
+    slot[nx] = exon_check_request(&rq[nrq], x, gen, est, cfg) ? (int)nrq++ : -1;
+    ++nx;
+  }
+  if (ef_dp_many(be, rq, rs, nrq) != 0) { fprintf(stderr, "* FATAL dynamic-programming backend failed (exon checks)\n"); abort(); }
+  /* low complexity: an exon that is empty on the genomic sequence scores 0 on both sides (:1683-1690) */
+  int n = 0;
+  for (size_t v = 0; v < nx; ++v) if (slot[v] >= 0 && rs[slot[v]].v[2] != 0) idx[n++] = (int)v + 1;
+  fact = keep_best_run(fact, idx, n);
+  if (!efl_empty(fact)) {
+    ef_phase(EFP_NOISY);
+    /* noisy exons among the survivors (a contiguous run of the exons above): found again by address */
+    n = 0;
+    int index = 1;
+    size_t v = 0;
+    it = efl_begin(fact);
+    while (efi_has_next(&it)) {
+      const ef_factor* x = (const ef_factor*)efi_next(&it);
+      while (v < nx && xs[v] != x) ++v;
+      const bool ok = v < nx && slot[v] >= 0 && rs[slot[v]].v[0] != 0;
+      if (!ok) idx[n++] = index;
+      ++index;
+    }
+    fact = keep_best_run(fact, idx, n);
+  }
+  if (!small) { free(xs); free(slot); free(idx); free(rq); free(rs); }
+  return fact;
+}
+
 /* the cleaning steps of the candidate factorizations of one root (:203-262); the survivors join flist */
 static ef_list* clean_candidates(ef_list* cands, ef_list* flist, unsigned est_len, const char* GEN, const char* EST,
                                  const ef_config* cfg, ef_backend* be) {
@@ -867,10 +887,9 @@ static ef_list* clean_candidates(ef_list* cands, ef_list* flist, unsigned est_le
     ef_list* f = (ef_list*)efi_next(&ci);
     bool ok = not_source_sink(f, (int)est_len);
     if (ok) ok = exon_start_end_ok(f);
-    if (ok) { ef_phase(EFP_ENDPOINTS); f = handle_endpoints(f, GEN, EST, be); if (efl_empty(f)) ok = false; }
+    if (ok) { ef_phase(EFP_ENDPOINTS); f = handle_endpoints(f, GEN, EST, cfg, be); if (efl_empty(f)) ok = false; }
     if (ok) { ef_phase(EFP_EXTERNAL); f = ef_clean_external_exons(f, GEN, EST, be); if (efl_empty(f)) ok = false; }
-    if (ok) { ef_phase(EFP_DUST); f = clean_low_complexity(f, GEN, EST, cfg); if (efl_empty(f)) ok = false; }
-    if (ok) { ef_phase(EFP_NOISY); f = ef_clean_noisy_exons(f, GEN, EST, false, be); if (efl_empty(f)) ok = false; }
+    if (ok) { ef_phase(EFP_DUST); f = clean_complexity_and_noise(f, GEN, EST, cfg, be); if (efl_empty(f)) ok = false; }
     ef_phase(EFP_ADD);
     if (ok) ok = est_coverage_ok(f, EST);
     if (ok) {

@@ -364,7 +364,7 @@ static void small_exon_between(ef_factor* p1, ef_factor* p2, ef_iter* it, const 
        * all offstarts first, stage by stage with prefetches, and the decision loops below find the lists ready. */
       ef_phase(EFP_TMP1);
       enum { OS_MAX = 24, CAND_MAX = 12 };
-      int os_code[OS_MAX]; const uint32_t* os_all[OS_MAX]; uint32_t os_nall[OS_MAX], os_k[OS_MAX];
+      int os_code[OS_MAX]; const uint32_t* os_all[OS_MAX]; uint32_t os_nall[OS_MAX];
       uint32_t os_q[OS_MAX][CAND_MAX], os_m[OS_MAX][CAND_MAX]; unsigned char os_nc[OS_MAX]; bool os_listed[OS_MAX];
       const size_t n_os = max_offstart < OS_MAX ? max_offstart : OS_MAX;
       for (size_t os = 0; os < n_os; ++os) {

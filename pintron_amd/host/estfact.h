@@ -363,6 +363,16 @@ static inline const int32_t* ef_ahead_find(const ef_ahead* ah, const ef_dp_req* 
     if (ef_req_same(&ah->q[ah->slot[s] - 1], q)) return ah->v[ah->slot[s] - 1];
   return NULL;
 }
+/* an answer that came with another request is kept too (only while nothing is noted: the noted questions sit behind
+ * the kept ones) */
+static inline unsigned ef_req_hash(const ef_dp_req* q);
+static inline void ef_ahead_put(ef_ahead* ah, const ef_dp_req* q, const int32_t* v) {
+  if (ah->n_pending || ah->n >= EF_AHEAD_MAX || !ef_req_keepable(q) || ef_ahead_find(ah, q)) return;
+  ah->q[ah->n] = *q; memcpy(ah->v[ah->n], v, 6 * sizeof(int32_t));
+  unsigned s = ef_req_hash(q);
+  while (ah->slot[s]) s = (s + 1) & (EF_AHEAD_SLOTS - 1);
+  ah->slot[s] = (unsigned char)(++ah->n);
+}
 /* the noted question at q[n] becomes a kept answer */
 static inline void ef_ahead_keep_next(ef_ahead* ah, const int32_t* v) {
   memcpy(ah->v[ah->n], v, 6 * sizeof(int32_t));

@@ -57,7 +57,11 @@ static int oracle_dp_impl(void* self, const ef_dp_req* q, ef_dp_res* r) {
       return 0;
     }
     case EF_DP_ED: r->v[0] = (int32_t)orc_edit_distance(q->a, q->la, q->b, q->lb); return 0;
-    case EF_DP_KBAND: { uint32_t e; r->v[0] = orc_kband(q->a, q->la, q->b, q->lb, q->p0, &e); r->v[1] = (int32_t)e; return 0; }
+    case EF_DP_KBAND: {
+      uint32_t e; r->v[0] = orc_kband(q->a, q->la, q->b, q->lb, q->p0, &e); r->v[1] = (int32_t)e;
+      if (q->tail) { double thr; const uint32_t w[2] = { q->p1, q->p2 }; memcpy(&thr, w, 8); r->v[2] = (int32_t)orc_dust_flags(q->a, q->la, q->b, q->lb, thr); }
+      return 0;
+    }
     case EF_DP_LCF: { uint32_t o1, o2, ln; orc_lcf(q->a, q->la, q->b, q->lb, &o1, &o2, &ln); r->v[0] = (int32_t)ln; r->v[1] = (int32_t)o1; r->v[2] = (int32_t)o2; return 0; }
     case EF_DP_BORDERS: {
       char* t = (char*)calloc(q->lb + 3, 1);

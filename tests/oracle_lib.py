@@ -85,6 +85,20 @@ def edit_distance(a: bytes, b: bytes) -> int:
     return oracle().orc_edit_distance(a, len(a), b, len(b))
 
 
+def dust_flags(gen: bytes, est: bytes, threshold: float) -> int:
+    L = oracle()
+    L.orc_dust_flags.restype = C.c_uint32
+    L.orc_dust_flags.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_double]
+    return int(L.orc_dust_flags(gen, len(gen), est, len(est), threshold))
+
+
+def dust_score(s: bytes) -> float:
+    L = oracle()
+    L.orc_dust_score.restype = C.c_double
+    L.orc_dust_score.argtypes = [C.c_char_p, C.c_size_t]
+    return float(L.orc_dust_score(s, len(s)))
+
+
 def kband(a: bytes, b: bytes, ub: int):
     e = C.c_uint32()
     ok = oracle().orc_kband(a, len(a), b, len(b), ub, C.byref(e))

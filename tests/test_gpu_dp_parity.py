@@ -248,6 +248,50 @@ def test_kband_band_on_lanes(gpu_ctx, O):
     run_and_check(gpu_ctx, O, cases)
 
 
+def test_exon_check_dust_flags_beside_the_banded_distance(gpu_ctx, O):
+    """KBAND jobs with tail = 1 ("exon check", include/pintron_gpu.h): beside K_band_edit_distance's answer the two
+    comparisons of clean_low_complexity_exons_2 (src/est-factorizations.c:1687-1691) -- dustScore
+    (src/exon-complexity.c:50-78) of each operand, FP64 in the reference's operation order, against a threshold passed
+    as its double bits.  Random, low-complexity (homopolymers, microsatellites), lower-case and N-bearing strings,
+    lengths 0..3 (score 0) up to thousands (every row class, the strips), thresholds ON the score of one of the
+    operands (the comparison is strict) and just beside it; the distance's early exits (equal strings, bound 0,
+    length difference above the bound) must not skip the flags."""
+    import struct
+    import pintron_amd.capi as capi
+    rng = random.Random(909)
+    jl = capi.JobList()
+    want = []
+
+    def lowc(n):
+        kind = rng.randrange(4)
+        if kind == 0:
+            return bytes([rng.choice(b"ACGT")]) * n
+        if kind == 1:
+            u = D.rand_seq(rng, rng.randint(2, 4))
+            return (u * (n // len(u) + 1))[:n]
+        if kind == 2:
+            return D.rand_seq(rng, n, 0.05).lower()
+        return D.rand_seq(rng, n, rng.choice([0.0, 0.02]))
+
+    for it in range(700):
+        n = rng.choice([0, 1, 2, 3, 4, 17, 63, 64, 65, 150, 300, 1000, 1100, 2100, 4200, 5000]) if it % 3 == 0 else rng.randint(0, 400)
+        g = lowc(n)
+        e = D.mutate(rng, g, rng.choice([0.0, 0.0, 0.03, 0.3])) if rng.random() < 0.8 else lowc(rng.randint(0, 400))
+        sg, se = O.dust_score(g), O.dust_score(e)
+        thr = rng.choice([20.0, 4.5, sg, se, sg * (1 + 1e-15) if sg else 0.25, se * (1 - 1e-15) if se else 0.5, 1e-9, 1e9])
+        if thr <= 0.0:
+            thr = 0.125
+        lo, hi = struct.unpack("<II", struct.pack("<d", thr))
+        ub = rng.choice([0, 1, 3, max(len(g), len(e)) // 25 + 1, max(len(g), len(e))])
+        jl.add(capi.KBAND, g, e, p0=ub, p1=lo, p2=hi, tail=1)
+        exp = O.kband(g, e, ub)
+        exp["dust"] = O.dust_flags(g, e, thr)
+        want.append((g[:40], e[:40], len(g), len(e), thr, ub, exp))
+    out = capi.run_jobs(gpu_ctx, jl)
+    bad = [(w, got) for w, got in zip(want, out) if got.get("status", 0) != 0 or any(got[f] != w[6][f] for f in ("ok", "edit", "dust"))]
+    assert not bad, (len(bad), bad[0])
+
+
 def test_align_inside_a_band(gpu_ctx, O):
     """ALIGN above 64 rows first runs inside a band of half-width 31 on one wave (pgpu_dp_kernels.hip:
     align_band_sweep) and falls back to the whole matrix when the banded score exceeds 31: scores on both
