@@ -932,7 +932,10 @@ static bool chain_embedding(const void* rec, const ef_config* cfg, const char* G
     if (k >= nv) return false;
   }
   if (n != nv || vt[3 * (size_t)path[n - 1]] != EF_SINK_START) return false;      /* every vertex, ending in the sink */
-  wk->used += 2ull * nv;
+  /* the work the enumeration would have counted: one unit per vertex entered, one per embedding that comes back from
+   * update_embedding (:626-629, :706-711); over the budget = "timeout expired", which the caller turns into the
+   * reference's retry with longer factors */
+  wk->used += nv;
   ef_pairing node;
   memset(&node, 0, sizeof node);
   emb* e = emb_new(1);
@@ -943,6 +946,7 @@ static bool chain_embedding(const void* rec, const ef_config* cfg, const char* G
     emb* nx = update_embedding(e, &node, GEN, cfg);
     embedding_free(e);
     e = nx;
+    if (e) ++wk->used;
   }
   *out = e;
   return true;
@@ -961,6 +965,12 @@ ef_est* ef_get_est_factorizations(const ef_seq* est_info, ef_meg* V, const ef_co
   emb* chain = NULL;
   if (V->rec && !V->v && ef_chain_fast_path && chain_embedding(V->rec, cfg, GEN, &wk, &chain)) {
     if (ef_prof_on) ++ef_prof.chain_graphs;
+    if (wk.used > wk.limit) {                          /* budget spent (:190-193): the caller retries */
+      if (chain) embedding_free(chain);
+      efl_free(flist, ef_factorization_free);
+      free(est);
+      return NULL;
+    }
     if (chain) {
       ef_list* embs = efl_new();
       efl_push_back(embs, chain);
