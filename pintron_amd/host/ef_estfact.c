@@ -146,9 +146,10 @@ ef_est* ef_compute_est_fact(const ef_seq* gen, const ef_seq* est, ef_backend* be
        * to its refined factorizations -- in the batched program the second includes the time the EST waited for
        * the device's answers among the other ESTs */
       if (side->ftmeg) {
-        char line[96];
-        snprintf(line, sizeof line, "%llu %llu %zu\n", t_meg1 - t_meg0, mono_us() - t_meg1, efl_size(fe->factorizations));
-        ef_sink_puts(side->ftmeg, line);
+        ef_wbuf w; efw_open(&w, side->ftmeg);         /* "%llu %llu %zu\n" */
+        efw_int(&w, (long long)(t_meg1 - t_meg0)); efw_ch(&w, ' '); efw_int(&w, (long long)(mono_us() - t_meg1)); efw_ch(&w, ' ');
+        efw_int(&w, (long long)efl_size(fe->factorizations)); efw_ch(&w, '\n');
+        efw_flush(&w);
       }
     }
     if (expired) ++inc;                                          /* :277-283: longer factors, again */

@@ -28,7 +28,11 @@ def exe():
                                  {"PINTRON_NO_PREFETCH": "1", "PINTRON_THREADS": "3"},
                                  {"PINTRON_GPU_MEG": "0"},
                                  {"PGPU_MERGED": "1"}, {"PGPU_MERGED": "0"}, {"PGPU_MERGED": "0", "PGPU_FANOUT": "0"},
-                                 {"PGPU_WAIT": "0"}, {"PINTRON_NO_FIBER_POOL": "1", "PINTRON_NO_FIBER_PREFETCH": "1"}])
+                                 {"PGPU_WAIT": "0"}, {"PINTRON_NO_FIBER_POOL": "1", "PINTRON_NO_FIBER_PREFETCH": "1"},
+                                 # round 4's short cuts switched off one by one: questions in their turn, one-path graphs
+                                 # through the lists, alignments always over the whole matrix, an N prefix by the matrix kernel
+                                 {"PINTRON_AHEAD": "0"}, {"PINTRON_CHAIN": "0"}, {"PGPU_ALIGN_BAND": "0"}, {"PGPU_LCF_SA_N": "0"},
+                                 {"PINTRON_KEEP": "0", "PINTRON_PRE_RAMP": "1:2:3"}])
 def test_ambn_golden(exe, tmp_path, env):
     for f in ("genomic.txt", "ests.txt"):
         shutil.copy(os.path.join(GOLD, f), tmp_path)
@@ -39,7 +43,8 @@ def test_ambn_golden(exe, tmp_path, env):
         assert filecmp.cmp(os.path.join(tmp_path, f), os.path.join(GOLD, "expected-" + f), shallow=False), f
 
 
-@pytest.mark.parametrize("env", [{}, {"PGPU_MERGED": "1"}, {"PGPU_MERGED": "0"}])
+@pytest.mark.parametrize("env", [{}, {"PGPU_MERGED": "1"}, {"PGPU_MERGED": "0"},
+                                 {"PINTRON_AHEAD": "0", "PINTRON_CHAIN": "0", "PGPU_ALIGN_BAND": "0", "PGPU_LCF_SA_N": "0"}])
 def test_c3_sample_vs_compiled_reference(exe, tmp_path, env):
     """2 000 C3-shaped ESTs (200 kb genomic, 3 % errors): byte-identical to the reference binary
     (oracle/_ref/est-fact-core travels with the repository snapshot), in every launch mode of the library
