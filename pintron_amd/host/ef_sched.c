@@ -948,6 +948,17 @@ static void bind_to_numa_node(int node) {
   if (n >= 2 && sched_setaffinity(0, sizeof want, &want) == 0) numa_bound = node;
 }
 
+/* Fibres per worker when PINTRON_FIBERS does not say: enough to cover a batch's round trip with the work of the other
+ * fibres, as few as that allows (the fibres' footprint is what makes resumed host code slow).  The work between two
+ * suspensions grows with the sequences' length: 768 for ESTs of several hundred bases (C3: 768 -> 114 ms, 1 024 -> 118,
+ * 512 -> 119), 1 024 for short reads (a C5 share: 768 -> 111 ms, 1 024 -> 104.5, 1 536 -> 110). */
+static size_t default_fibers(const ef_inputs* in) {
+  size_t total = 0;
+  const size_t n = in->n < 4096 ? in->n : 4096;          /* a sample of the batch */
+  for (size_t k = 0; k < n; ++k) total += strlen(in->list[k]->seq);
+  return (n && total / n < 300) ? 1024 : 768;
+}
+
 /* ---- what outlives a session --------------------------------------------------------------------------
  * A process that runs one batch after the other (est-fact --genes, a library user that brings fresh batches:
  * bench.py's fresh_batch leg) used to take everything apart at the end of a session and make it again for the
@@ -1144,7 +1155,7 @@ ef_session* ef_session_open(int argc, char** argv) {
   }
   if (load_rc == 0 && !getenv("PINTRON_NO_FIBER_POOL")) {
     s->sh.stack_size = env_size("PINTRON_FIBER_STACK_KB", 256) * 1024;
-    size_t want = env_size("PINTRON_THREADS", host_core_share()) * env_size("PINTRON_FIBERS", 768);
+    size_t want = env_size("PINTRON_THREADS", host_core_share()) * env_size("PINTRON_FIBERS", default_fibers(&s->in));
     if (want > s->in.n) want = s->in.n;                 /* never more fibres than sequences */
     want = want > kept_fibers ? want - kept_fibers : 0;
     if (want >= 64) {
@@ -1230,7 +1241,7 @@ ef_session* ef_session_open(int argc, char** argv) {
   /* the workers hide the GPU latency with lanes, not with oversubscription */
   s->nthreads = env_size("PINTRON_THREADS", host_core_share());
   if (s->nthreads > sh->n_units) s->nthreads = sh->n_units ? sh->n_units : 1;
-  sh->max_fibers = env_size("PINTRON_FIBERS", 768);
+  sh->max_fibers = env_size("PINTRON_FIBERS", default_fibers(in));
   sh->stack_size = env_size("PINTRON_FIBER_STACK_KB", 256) * 1024;
   sh->kernel_timing = env_flag("PINTRON_KERNEL_TIMING");
   sh->gen_len = strlen(in->gen->seq);

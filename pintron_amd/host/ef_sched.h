@@ -37,7 +37,7 @@ void ef_session_close(ef_session* s);
 
 /* environment: PINTRON_THREADS (workers; default: usable cores (affinity, cgroup quota,
  * per local rank), at most 16), PINTRON_LANES (8),
- * PINTRON_FIBERS (fibres per worker over all lanes, 1024), PINTRON_FIBER_STACK_KB (256),
+ * PINTRON_FIBERS (fibres per worker over all lanes: 768, or 1024 for reads shorter than 300 bases), PINTRON_FIBER_STACK_KB (256),
  * PINTRON_SERVICES (GPU service threads, 4), PINTRON_COALESCE_US (0), PINTRON_GPU_DEVICE (0), PINTRON_NO_PREFETCH,
  * PINTRON_KERNEL_TIMING, PINTRON_VERBOSE */
 /* est-fact over several GPUs of one node from the C program itself (ef_multi.c): `--gpus=N` (or
