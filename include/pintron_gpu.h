@@ -201,8 +201,16 @@ int pgpu_comm_destroy(pgpu_ctx* ctx, pgpu_comm* comm);
 /* ------------------------------------------------------------------------------------------ */
 enum pgpu_dp_kind {
   /* compute_alignment (src/compute-alignments.c:39-207): a = EST string, b = genomic string.
-   * v[0]=score v[1]=alignment_dim v[2]=offset of EST_alignment, v[3]=offset of GEN_alignment in
-   * the output string buffer (both NUL-terminated). */
+   * v[0]=score v[1]=alignment_dim; str[0], str[1] = offsets of EST_alignment and GEN_alignment in
+   * the output string buffer (both NUL-terminated).
+   * p0 = 1 / 2 (optional): the alignment is handle_endpoints' of a FIRST / LAST exon
+   * (src/est-factorizations.c:2145,2204); p1, p2 = the complexity threshold's double bits.  The library may then
+   * answer, beside the alignment, the exon check (KBAND with tail = 1) of the exon as that routine is going to trim
+   * it (:2163-2196, :2231-2296): v[4] bit 3 set = answered, for the sub-operands v[2], v[3] (first exon: characters
+   * of a / of b trimmed away at the front; last exon: characters of a / of b kept) with the bound v[4] >> 8;
+   * v[4] bit 0 = K_band_edit_distance's verdict, bits 1-2 = the two dust comparisons.  The caller files the answer
+   * under the question those values define and still does its own trimming: the extra answer saves a request when
+   * the two agree, and is never used when they do not. */
   PGPU_DP_ALIGN = 0,
   /* compute_gap_alignment (src/refine-intron.c:560-890): a = EST window, b = genomic window.
    * v[0]=gap_alignment_dim v[1]=factor_cut v[2]=intron_start v[3]=intron_end

@@ -1783,6 +1783,131 @@ __device__ __forceinline__ void lcfsa_wave_body(const DevJob& job, DevResult* re
 }
 
 // ---------------------------------------------------------------------------------------------
+// End-exon alignments (ALIGN jobs with p0 = 1: first exon, p0 = 2: last exon; p1 / p2 = the complexity threshold's
+// double bits).  handle_endpoints (src/est-factorizations.c:2127-2301) trims the exon by what the alignment shows at
+// its outer end, and the next thing the host asks is the exon check of the TRIMMED exon (KBAND with tail = 1).  The
+// wave that just wrote the alignment does both ahead of the host: it walks the outer 64 columns the way the host
+// will, takes the trimmed exon as sub-operands and runs the exon check on them.  The answer comes back in the spare
+// fields of the ALIGN result TOGETHER with the sub-operands it was computed for (v[2], v[3]: head -- characters of a
+// and of b trimmed away; tail -- characters of a and of b kept) and the bound it used; the host files it under the
+// question those define and finds it only if its own trimming -- done on the strings, as before -- asks exactly that
+// question: a slip in this walk costs a second request, never a different result.  v[4] = ok | dust flags << 1 |
+// valid << 3 | bound << 8.  Not attempted (valid = 0): the walk leaves the 64 columns, the exon is dropped, or the
+// banded distance would need more than one row per lane.
+// ---------------------------------------------------------------------------------------------
+__device__ __noinline__ void endpoint_epilogue(const DevJob& job, DevResult* res, const uint8_t* __restrict__ strs,
+                                               uint8_t* __restrict__ ws, const uint32_t lane, DevResult* tmp) {
+  const uint32_t n = job.la, m = job.lb;
+  const uint32_t dim = (uint32_t)__builtin_amdgcn_readfirstlane(res->v[1]);
+  const uint8_t* ea = strs + res->str[0];
+  const uint8_t* ga = strs + res->str[1];
+  if (dim == 0u) return;
+  uint32_t sub_a_off = 0, sub_b_off = 0, sub_la = 0, sub_lb = 0;
+  bool valid = false;
+  if (job.p0 == 1u) {
+    // head (:2163-2196): columns from the left until more than five matches in a row
+    const uint32_t c = lane < dim ? lane : dim;
+    const uint32_t xe = lane < dim ? ea[c] : 0u, xg = lane < dim ? ga[c] : 0u;
+    const unsigned long long eq = __ballot(lane < dim && xe == xg), eg = __ballot(xe == '-'), gg = __ballot(xg == '-');
+    uint32_t j = 0, matches = 0, cf = 0, ce = 0;
+    bool stop = false;
+    const uint32_t lim = dim < 64u ? dim : 64u;
+    while (j < lim && !stop) {
+      if (matches > 5u) stop = true;
+      else {
+        if (eq >> j & 1ull) { ++cf; ++ce; ++matches; }
+        else { if (!(eg >> j & 1ull)) ++cf; if (!(gg >> j & 1ull)) ++ce; matches = 0; }
+        ++j;
+      }
+    }
+    if (stop && cf - matches <= n && ce - matches <= m) {       // (not stopped: the exon is dropped, or the walk goes on beyond the window)
+      sub_a_off = cf - matches; sub_b_off = ce - matches; sub_la = n - sub_a_off; sub_lb = m - sub_b_off;
+      valid = true;
+    }
+  } else {
+    // tail (:2231-2296): columns from the right until more than ten matches in a row, then the gap columns next to
+    // that run are closed by pulling the next character over, as far as the characters agree
+    const uint32_t wb = dim > 64u ? dim - 64u : 0u;             // lane t holds column wb + t
+    const uint32_t col = wb + lane;
+    uint32_t xe = col < dim ? ea[col] : 0u, xg = col < dim ? ga[col] : 0u;
+    const unsigned long long eq = __ballot(col < dim && xe == xg), eg = __ballot(xe == '-'), gg = __ballot(xg == '-');
+    int j = (int)dim - 1, cf = (int)n - 1, ce = (int)m - 1;
+    uint32_t matches = 0;
+    bool stop = false, inside = true;
+    while (j >= 0 && !stop) {
+      if (matches > 10u) stop = true;
+      else {
+        if (j < (int)wb) { inside = false; break; }
+        const uint32_t t = (uint32_t)j - wb;
+        if (eq >> t & 1ull) { --cf; --ce; ++matches; }
+        else { if (!(eg >> t & 1ull)) --cf; if (!(gg >> t & 1ull)) --ce; matches = 0; }
+        --j;
+      }
+    }
+    if (inside) {
+      int est_cl = cf + (int)matches, gen_cl = ce + (int)matches;
+      uint32_t cursor = (uint32_t)(j + (int)matches + 1);
+      bool halt = false;
+      // character of a row at column q (a NUL behind the row, as in the host's zero-padded copy)
+      auto at = [&](uint32_t v, uint32_t q) -> uint32_t { return q < dim ? (uint32_t)__shfl((int)v, (int)(q - wb)) : 0u; };
+      while (!halt && cursor < dim - 1u) {
+        const uint32_t ec = at(xe, cursor), gc = at(xg, cursor);
+        if (!(ec == '-' || gc == '-')) break;
+        uint32_t tr = cursor + 1u;
+        if (ec == '-') {
+          while (at(xe, tr) == '-') ++tr;
+          const uint32_t moved = at(xe, tr);
+          if (tr < dim && moved == gc) {
+            if (col == cursor) xe = moved;
+            if (col == tr) xe = '-';
+            ++est_cl; ++gen_cl;
+          } else halt = true;
+        } else {
+          while (at(xg, tr) == '-') ++tr;
+          const uint32_t moved = at(xg, tr);
+          if (tr < dim && moved == ec) {
+            if (col == cursor) xg = moved;
+            if (col == tr) xg = '-';
+            ++est_cl; ++gen_cl;
+          } else halt = true;
+        }
+        ++cursor;
+      }
+      if (gen_cl >= 0 && est_cl >= 0 && est_cl < (int)n && gen_cl < (int)m) {
+        sub_la = (uint32_t)est_cl + 1u; sub_lb = (uint32_t)gen_cl + 1u;
+        valid = true;
+      }
+    }
+  }
+  if (!valid || sub_lb == 0u) return;                          // (an exon that is empty on the genomic sequence gets no check)
+  // the exon check of the trimmed exon: a = the exon on the genomic sequence, b = on the EST (include/pintron_gpu.h)
+  DevJob sub = job;
+  sub.a = job.b + sub_b_off; sub.la = sub_lb;
+  sub.b = job.a + sub_a_off; sub.lb = sub_la;
+  {                                                             // max_edit_for_exon (src/est-factorizations.c:1828-1840), in FP64 like the host
+    const double len = (double)sub_lb;
+    const double rate = sub_lb > 100u ? 0.030 : (sub_lb > 50u ? 0.035 : 0.040);
+    const double c = ceil(len * rate);
+    sub.p0 = (uint32_t)(c > 1.0 ? c : 1.0);
+  }
+  sub.tail = 1u;
+  const uint32_t big = sub.la > sub.lb ? sub.la : sub.lb, sml = sub.la > sub.lb ? sub.lb : sub.la;
+  if (!((2u * sub.p0 + 1u < big && 2u * sub.p0 + 1u <= 64u) || sml <= 64u)) return;      // more than one row per lane
+  if (lane == 0) { tmp->status = 1; tmp->v[0] = 0; tmp->v[1] = 0; tmp->v[2] = 0; }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  lev_wave_body<1, MODE_KBAND>(sub, tmp, ws, lane);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (lane == 0 && tmp->status == 0) {
+    res->v[2] = (int32_t)(job.p0 == 1u ? sub_a_off : sub_la);
+    res->v[3] = (int32_t)(job.p0 == 1u ? sub_b_off : sub_lb);
+    res->v[4] = (int32_t)((tmp->v[0] ? 1u : 0u) | (((uint32_t)tmp->v[2] & 3u) << 1) | 8u | (sub.p0 << 8));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // ONE launch for every wave-per-job family of a batch.  A merged batch used to cost eleven launches
 // dealt onto four hardware queues, and the kernels of a queue run one after the other: the batch
 // took the SUM of its families' long poles per queue.  Here every wave of the grid looks its job up
@@ -1817,6 +1942,7 @@ __device__ __forceinline__ void wave_jobs_body(const int block, const int wave, 
       lev_any_dispatch<MODE_ALIGN, false>(job, res, ws, lane);
       own_stores_visible();
       align_traceback_wave(job, res, ws, strs, lane, s_win, s_path);
+      if (job.p0 != 0u) { own_stores_visible(); endpoint_epilogue(job, res, strs, ws, lane, reinterpret_cast<DevResult*>(s_borders)); }
       break;
     case KF_GAP:
       switch (job.r_class) {
@@ -1841,6 +1967,7 @@ __device__ __forceinline__ void wave_jobs_body(const int block, const int wave, 
         if (lane == 0) { res->status = 0; res->v[0] = 0; res->v[1] = (int32_t)n; res->v[5] = 1; }
         own_stores_visible();
         align_traceback_wave(job, res, ws, strs, lane, s_win, s_path);      // its identity branch
+        if (job.p0 != 0u) { own_stores_visible(); endpoint_epilogue(job, res, strs, ws, lane, reinterpret_cast<DevResult*>(s_borders)); }
         break;
       }
       uint32_t* bdirs = reinterpret_cast<uint32_t*>(ws + job.ws_off);
@@ -1849,6 +1976,7 @@ __device__ __forceinline__ void wave_jobs_body(const int block, const int wave, 
       if (lane == 0) { res->status = 0; res->v[0] = (int32_t)score; res->v[5] = 0; }
       own_stores_visible();
       align_band_traceback(job, res, bdirs, strs, lane, s_win, s_path);
+      if (job.p0 != 0u) { own_stores_visible(); endpoint_epilogue(job, res, strs, ws, lane, reinterpret_cast<DevResult*>(s_borders)); }
       break;
     }
     default: break;

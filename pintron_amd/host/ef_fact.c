@@ -411,6 +411,15 @@ static ef_list* handle_endpoints(ef_list* fact, const char* gen, const char* est
     ef_dp_req qq[2 + INNER_MAX]; ef_dp_res rr[2 + INNER_MAX]; size_t nq = 2;
     endpoint_request(&qq[0], head, gen, est);
     endpoint_request(&qq[1], tail, gen, est);
+    if (be->ahead && ef_endpoint_checks) {
+      /* p0 = 1 / 2: "this is a first / last exon" -- a backend may answer, beside the alignment, the exon check of
+       * the exon as handle_endpoints is going to trim it (include/pintron_gpu.h: ALIGN with p0); p1, p2 = the
+       * complexity threshold's double bits, as in the exon check itself */
+      uint32_t w[2];
+      memcpy(w, &cfg->complexity_threshold, 8);
+      qq[0].p0 = 1; qq[0].p1 = w[0]; qq[0].p2 = w[1];
+      qq[1].p0 = 2; qq[1].p1 = w[0]; qq[1].p2 = w[1];
+    }
     if (be->ahead && efl_size(fact) >= 3 && efl_size(fact) <= INNER_MAX) {
       ef_iter it = efl_begin(fact);
       efi_next(&it);
@@ -422,6 +431,26 @@ static ef_list* handle_endpoints(ef_list* fact, const char* gen, const char* est
     }
     if (ef_dp_many(be, qq, rr, nq) != 0) { fprintf(stderr, "* FATAL alignment backend failed\n"); abort(); }
     for (size_t k = 2; k < nq; ++k) ef_ahead_put(be->ahead, &qq[k], rr[k].v);
+    if (be->ahead) {
+      /* an exon check that came with an alignment is filed under the question it answers: the exon as the backend
+       * trimmed it (v[2], v[3]) with the bound it used (v[4] >> 8).  The trimming below is the host's own, on the
+       * strings; the cleaning step finds the answer only if it then asks exactly this question. */
+      for (int k = 0; k < 2; ++k) {
+        const int32_t* v = rr[k].v;
+        if (!(v[4] & 8)) continue;
+        const ef_factor* x = k == 0 ? head : tail;
+        ef_factor y = *x;
+        if (k == 0) { y.EST_start += v[2]; y.GEN_start += v[3]; }
+        else { y.EST_end = y.EST_start + v[2] - 1; y.GEN_end = y.GEN_start + v[3] - 1; }
+        ef_dp_req cq;
+        if (y.EST_start > y.EST_end || !exon_check_request(&cq, &y, gen, est, cfg) || cq.p0 != ((uint32_t)v[4] >> 8)) continue;
+        /* (the operands of that question must be the very stretches the backend looked at) */
+        if (cq.la != (size_t)(y.GEN_end - y.GEN_start + 1) || cq.lb != (size_t)(y.EST_end - y.EST_start + 1)) continue;
+        const int32_t answer[6] = { v[4] & 1, 0, (v[4] >> 1) & 3, 0, 0, 0 };
+        ef_ahead_put(be->ahead, &cq, answer);
+        if (ef_prof_on) ++ef_prof.ahead_asked;
+      }
+    }
     endpoint_head_apply(fact, head, &rr[0]);
     endpoint_tail_apply(fact, tail, &rr[1]);     /* `tail` is not the exon the head step touched */
     endpoint_release(&qq[0], &rr[0]); endpoint_release(&qq[1], &rr[1]);
