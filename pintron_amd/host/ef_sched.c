@@ -1283,15 +1283,23 @@ static void free_unit_buffers(shared* sh, bool release) {
 /* prefetch thread: the pairings of chunk after chunk (one resident batch each); every finished
  * chunk releases its units to the workers */
 /* the prepared sequences (both strands) of chunk c, concatenated, as a resident pairing plan */
-static int make_pattern_plan(ef_session* s, int c) {
+/* The host half of a range's plan (offsets + the sequences copied into the staging buffer) is made by a helper thread
+ * while the prefetch thread has the range before it on the device (first step only): a fresh batch's prefetch stage was
+ * 0.105 s against 0.056 s with the patterns resident, and 2.5 ms per range of it were these two loops. */
+typedef struct { ef_session* s; int c; uint64_t* off; size_t total; char* blob; bool own_blob; int rc; pthread_t th; bool started; } stage_job;
+static void* stage_main(void* arg) {
+  stage_job* j = (stage_job*)arg;
+  ef_session* s = j->s;
   shared* sh = &s->sh;
   ef_inputs* in = &s->in;
-  const size_t lo = sh->pre_lo[c], hi = sh->pre_lo[c + 1];
-  uint64_t* off = (uint64_t*)malloc((hi - lo + 1) * sizeof(uint64_t));
-  if (!off) return PGPU_ENOMEM;
+  const size_t lo = sh->pre_lo[j->c], hi = sh->pre_lo[j->c + 1];
+  j->rc = PGPU_OK; j->blob = NULL; j->own_blob = false;
+  j->off = (uint64_t*)malloc((hi - lo + 1) * sizeof(uint64_t));
+  if (!j->off) { j->rc = PGPU_ENOMEM; return NULL; }
   size_t total = 0;
-  for (size_t k = lo; k < hi; ++k) { off[k - lo] = total; total += strlen(in->list[k]->seq); }
-  off[hi - lo] = total;
+  for (size_t k = lo; k < hi; ++k) { j->off[k - lo] = total; total += strlen(in->list[k]->seq); }
+  j->off[hi - lo] = total;
+  j->total = total;
   if (total + 1 > sh->up_stage_cap) {                       /* page-locked: the copy to the device runs at PCIe speed */
     if (sh->up_stage) pgpu_host_free(s->ctx0, sh->up_stage);
     sh->up_stage = NULL; sh->up_stage_cap = 0;
@@ -1299,12 +1307,31 @@ static int make_pattern_plan(ef_session* s, int c) {
     const size_t want = total + total / 4 + 4096;
     if (pgpu_host_alloc(s->ctx0, want, &q) == PGPU_OK) { sh->up_stage = (char*)q; sh->up_stage_cap = want; }
   }
-  char* blob = sh->up_stage ? sh->up_stage : (char*)malloc(total + 1);
-  if (!blob) { free(off); return PGPU_ENOMEM; }
-  for (size_t k = lo; k < hi; ++k) memcpy(blob + off[k - lo], in->list[k]->seq, (size_t)(off[k - lo + 1] - off[k - lo]));
-  const int prc = pgpu_pairing_plan_create_resident(s->ctx0, sh->idx, blob, off, hi - lo, &s->pplan[c]);   /* returns after the copy */
-  if (blob != sh->up_stage) free(blob);
-  free(off);
+  j->blob = sh->up_stage ? sh->up_stage : (char*)malloc(total + 1);
+  j->own_blob = j->blob != sh->up_stage;
+  if (!j->blob) { j->rc = PGPU_ENOMEM; return NULL; }
+  for (size_t k = lo; k < hi; ++k) memcpy(j->blob + j->off[k - lo], in->list[k]->seq, (size_t)(j->off[k - lo + 1] - j->off[k - lo]));
+  return NULL;
+}
+/* start staging range c beside the caller (the staging buffer must be free: the plan of the range before has been made) */
+static void stage_start(stage_job* j, ef_session* s, int c) {
+  memset(j, 0, sizeof *j);
+  j->s = s; j->c = c;
+  j->started = pthread_create(&j->th, NULL, stage_main, j) == 0;
+  if (!j->started) stage_main(j);
+}
+/* the device half: the staged sequences as a resident pairing plan */
+static int stage_finish(stage_job* j) {
+  if (j->started) { pthread_join(j->th, NULL); j->started = false; }
+  ef_session* s = j->s;
+  int prc = j->rc;
+  if (prc == PGPU_OK) {
+    const size_t lo = s->sh.pre_lo[j->c], hi = s->sh.pre_lo[j->c + 1];
+    prc = pgpu_pairing_plan_create_resident(s->ctx0, s->sh.idx, j->blob, j->off, hi - lo, &s->pplan[j->c]);   /* returns after the copy */
+  }
+  if (j->own_blob) free(j->blob);
+  free(j->off);
+  j->off = NULL; j->blob = NULL;
   return prc;
 }
 
@@ -1313,6 +1340,8 @@ static void* prefetch_main(void* arg) {
   ef_session* s = (ef_session*)arg;
   shared* sh = &s->sh;
   pgpu_pairing_params prm = { s->in.cfg.min_factor_len, 0, s->in.cfg.min_string_depth_rate };
+  stage_job stage; bool staging = false;
+  memset(&stage, 0, sizeof stage);
   for (int c = 0; c < sh->n_pre; ++c) {
     char rname[48];
     snprintf(rname, sizeof rname, "prefetch chunk %d (pairings + MEGs)", c);
@@ -1320,7 +1349,14 @@ static void* prefetch_main(void* arg) {
     /* first step: the chunk's sequences go to the device here, chunk after chunk beside the workers
      * that already factorize the chunks before (they stay resident for the steps that follow) */
     const double tc0 = now_s();
-    int prc = s->pplan[c] ? PGPU_OK : make_pattern_plan(s, c);
+    int prc = PGPU_OK;
+    if (!s->pplan[c]) {
+      if (!staging) { stage_start(&stage, s, c); staging = true; }       /* (the first range: nothing to hide behind) */
+      prc = stage_finish(&stage);
+      staging = false;
+      /* the next range's sequences are copied together while this one is on the device */
+      if (prc == PGPU_OK && c + 1 < sh->n_pre && !s->pplan[c + 1]) { stage_start(&stage, s, c + 1); staging = true; }
+    }
     const double tc1 = now_s();
     if (prc == PGPU_OK) prc = pgpu_pairing_plan_run(s->ctx0, s->pplan[c], &prm);
     const double tc2 = now_s();
@@ -1382,6 +1418,11 @@ static void* prefetch_main(void* arg) {
     pthread_mutex_unlock(&sh->mu);
     pgpu_range_pop();
     if (prc != PGPU_OK) break;
+  }
+  if (staging) {                               /* left behind by a failure: nobody will use it */
+    if (stage.started) pthread_join(stage.th, NULL);
+    if (stage.own_blob) free(stage.blob);
+    free(stage.off);
   }
   s->pre_wall = now_s() - s->pre_t0;
   return NULL;
