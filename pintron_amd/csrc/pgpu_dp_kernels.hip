@@ -19,6 +19,7 @@
 // Integer/character work only: no MFMA.  Reference routines are cited per kernel; paths are
 // relative to the AlgoLab/PIntron tree.
 #include "pgpu_internal.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -719,7 +720,9 @@ void lev_wave_kernel(const DevJob* __restrict__ jobs, int njobs, DevResult* __re
 // the sum of the classes' longest jobs; in one launch they overlap.  Every wave picks the body of
 // its job's class (jobs are sorted by class, so the waves of a workgroup mostly agree).
 constexpr int TB_WIN_BYTES = 8192;    // traceback: direction window per wave
-constexpr int TB_PATH = 1024;         // traceback: path steps buffered before the lanes write them out
+// traceback: path steps buffered before the lanes write them out.  704, not 1024: with it a workgroup of dp_batch_kernel
+// takes 39 744 + 256 B of LDS, and FOUR of them share a CU's 160 KB (16 job waves, what the registers allow) instead of three
+constexpr int TB_PATH = 704;
 __device__ __forceinline__ void align_traceback_wave(const DevJob& job, DevResult* res, const uint8_t* __restrict__ ws,
                                                      uint8_t* __restrict__ strs, const uint32_t lane,
                                                      uint8_t* win, uint8_t* path);
@@ -1920,6 +1923,7 @@ __device__ __noinline__ void endpoint_epilogue(const DevJob& job, DevResult* res
 struct WaveSegs { int n; int start[MAX_WAVE_SEGS]; int count[MAX_WAVE_SEGS]; int family[MAX_WAVE_SEGS]; };
 
 constexpr size_t WAVE_JOBS_LDS = 4 * (size_t)TB_WIN_BYTES + 4 * (size_t)TB_PATH + 4 * 4 * 65 * sizeof(uint32_t);
+static_assert(WAVE_JOBS_LDS + 256 <= 40 * 1024, "four workgroups of dp_batch_kernel per CU (160 KB of LDS; 256 B are static)");
 
 // wave `wave` (0..3) of workgroup `block` of the wave-per-job part; smem: WAVE_JOBS_LDS bytes, 16-aligned
 __device__ __forceinline__ void wave_jobs_body(const int block, const int wave, const uint32_t lane,
@@ -2395,7 +2399,8 @@ bool launch_dp_batch(const DevJob* jobs, int n_segs, const int* family, const in
   d.ac_start = ac_start; d.ac_count = ac_count > 0 ? ac_count : 0;
   const int blocks = d.bc_count + d.ac_count + d.lc_count + d.wave_blocks;
   if (blocks == 0) return true;
-  const size_t lds = dp_batch_lds_bytes(total > 0, d.bc_count, bc_max_rows, d.ac_count, d.lc_count);
+  static const size_t lds_pad = [] { const char* e = getenv("PGPU_LDS_PAD"); return e ? (size_t)atoi(e) : (size_t)0; }();   // measurement only
+  const size_t lds = dp_batch_lds_bytes(total > 0, d.bc_count, bc_max_rows, d.ac_count, d.lc_count) + lds_pad;
   if (lds > DP_BATCH_MAX_LDS) return false;
   hipLaunchKernelGGL(dp_batch_kernel, dim3(blocks), dim3(512), lds, st, jobs, d, res, ws, strs);
   return true;

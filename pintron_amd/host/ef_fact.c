@@ -376,7 +376,7 @@ static void endpoint_tail_apply(ef_list* fact, ef_factor* tail, const ef_dp_res*
 
 static void endpoint_request(ef_dp_req* q, const ef_factor* x, const char* gen, const char* est) {
   const ef_dp_req r = { EF_DP_ALIGN, est + x->EST_start, view_len(est, x->EST_start, x->EST_end - x->EST_start + 1),
-                        gen + x->GEN_start, view_len(gen, x->GEN_start, x->GEN_end - x->GEN_start + 1), 0, 0, 0, 0 };
+                        gen + x->GEN_start, view_len(gen, x->GEN_start, x->GEN_end - x->GEN_start + 1), 0, 0, 0, 0, 0 };
   *q = r;
 }
 static void endpoint_release(ef_dp_req* q, ef_dp_res* r) {
@@ -582,7 +582,7 @@ ef_list* ef_clean_noisy_exons(ef_list* fact, const char* gen, const char* est, b
     if (x->GEN_start <= x->GEN_end) {
       /* the exon on the genomic sequence and on the EST, read in place (the reference copies them) */
       const ef_dp_req q = { EF_DP_KBAND, gen + x->GEN_start, view_len(gen, x->GEN_start, x->GEN_end - x->GEN_start + 1),
-                            est + x->EST_start, view_len(est, x->EST_start, x->EST_end - x->EST_start + 1), max_err, 0, 0, 0 };
+                            est + x->EST_start, view_len(est, x->EST_start, x->EST_end - x->EST_start + 1), max_err, 0, 0, 0, 0 };
       slot[nvis] = (int)nrq;
       rq[nrq++] = q;
     }

@@ -34,7 +34,7 @@ static int dp(ef_backend* be, int kind, const char* a, size_t la, const char* b,
  * equal (distance 0 without a dynamic program) */
 static bool ed_request(ef_dp_req* q, const char* a, size_t la, const char* b, size_t lb) {
   if (la == lb && strncmp(a, b, la) == 0) return false;
-  const ef_dp_req r = { EF_DP_ED, a, la, b, lb, 0, 0, 0, 0 };
+  const ef_dp_req r = { EF_DP_ED, a, la, b, lb, 0, 0, 0, 0, 0 };
   *q = r;
   return true;
 }
@@ -139,7 +139,7 @@ static void recover_affixes(const ef_seq* gen, ef_est* e, ef_backend* be) {
       const char* es = E + fl->EST_end;          /* starts ON the last exon character (:1239,1242) */
       const char* gs = G + fl->GEN_end;
       if (es[0] != gs[0]) {
-        const ef_dp_req x = { EF_DP_AFFIX, es, elen, gs, glen, 0, 0, 0, 0 };
+        const ef_dp_req x = { EF_DP_AFFIX, es, elen, gs, glen, 0, 0, 0, 0, 0 };
         ss = (int)nq; q[nq++] = x;
       }
     }
@@ -260,7 +260,7 @@ static void small_exon_at_prefix(ef_factor* p1, ef_iter* it, const ef_seq* gen, 
   /* the common factor and the edit distance of the exon prefix (needed only when the factor is long
    * enough, :546) do not depend on each other: requested together */
   ef_dp_req q2[2]; ef_dp_res r2[2]; size_t n2 = 1;
-  { const ef_dp_req x = { EF_DP_LCF, G, (size_t)p1->GEN_start, epfact, eplen, 0, 0, 0, 0 }; q2[0] = x; }
+  { const ef_dp_req x = { EF_DP_LCF, G, (size_t)p1->GEN_start, epfact, eplen, 0, 0, 0, 0, 0 }; q2[0] = x; }
   const bool need_ed = ed_request(&q2[1], E + p1->EST_start, e1plen, G + p1->GEN_start, e1plen);
   if (need_ed) n2 = 2;
   if (dp_many(be, q2, r2, n2) == EF_DP_PENDING) return;
@@ -309,8 +309,8 @@ static void small_exon_between(ef_factor* p1, ef_factor* p2, ef_iter* it, const 
   int s_sed = -1, s_ped = -1, s_l1 = -1, s_l2 = -1;
   if (ed_request(&q4[n4], e1s, e1slen, g1s, g1slen)) s_sed = (int)n4++;
   if (ed_request(&q4[n4], e2p, e2plen, g2p, g2plen)) s_ped = (int)n4++;
-  if (s_sed >= 0) { const ef_dp_req x = { EF_DP_LCF, e1s, e1slen, g1s, g1slen, 0, 0, 0, 0 }; s_l1 = (int)n4; q4[n4++] = x; }
-  if (s_ped >= 0) { const ef_dp_req x = { EF_DP_LCF, e2p, e2plen, g2p, g2plen, 0, 0, 0, 0 }; s_l2 = (int)n4; q4[n4++] = x; }
+  if (s_sed >= 0) { const ef_dp_req x = { EF_DP_LCF, e1s, e1slen, g1s, g1slen, 0, 0, 0, 0, 0 }; s_l1 = (int)n4; q4[n4++] = x; }
+  if (s_ped >= 0) { const ef_dp_req x = { EF_DP_LCF, e2p, e2plen, g2p, g2plen, 0, 0, 0, 0, 0 }; s_l2 = (int)n4; q4[n4++] = x; }
   if (dp_many(be, q4, r4, n4) == EF_DP_PENDING) return;
   if (ef_collecting(be)) return;                       /* (no further question follows) */
   const size_t sed = s_sed >= 0 ? (size_t)(uint32_t)r4[s_sed].v[0] : 0;

@@ -367,7 +367,8 @@ void ef_transitive_reduction(ef_meg* V) {
   size_t scap = 4 * nv + 16, sp = 0;
   bool acyclic = true;
 #define PUSH(x) do { if (sp == scap) { int* bigger = (int*)malloc(2 * scap * sizeof(int)); memcpy(bigger, stack, scap * sizeof(int)); \
-                       if (stack != stack0) free(stack); stack = bigger; scap *= 2; } stack[sp++] = (x); } while (0)
+                       if (stack != stack0) { free(stack); } \
+                       stack = bigger; scap *= 2; } stack[sp++] = (x); } while (0)
   for (size_t i = 0; i < nv; ++i) if (efl_size(G[i]->incs) == 0) PUSH((int)i);
   if (sp == 0) acyclic = false;
   size_t progr = nv;

@@ -866,6 +866,17 @@ static size_t host_core_share(void) {
   return n > 0 ? (size_t)n : 1;
 }
 
+/* Worker threads: one per core of the share and an eighth more.  The step is bound by the share's CPU time (C3: 1.40
+ * core-seconds per 0.104 s step under a quota of 16 cores, `tools/throttle_check.py`), and a worker is off the CPU a
+ * fifth of its time (its batches, the first range of pairings): 18 workers keep 16 cores busy where 16 kept 13.4.
+ * Measured on two boxes, alternating (`gpurun_out/r04/sweep_threads{2,3}.txt`): C3 16 workers / 4 services 104.4 -
+ * 107.9 ms, 18 / 6 98.3 - 101.3, 20 / 6 97.1 - 99.2 but with the quota's throttle in 12 of 12 periods (one bad period
+ * stalls every thread of the process until the next), 24: 97 - 106; a C5 share 103.6 - 105.5 -> 95.5 - 100.9. */
+static size_t default_workers(void) {
+  const size_t c = host_core_share();
+  return c + c / 8;
+}
+
 /* All threads of the step on the socket the GPU hangs off.  On the two-socket hosts of the GPU boxes
  * the unbound program ran 4-14 % slower (threads and their memory spread over both sockets; the
  * per-EST logic is bound by memory latency): the calling thread's affinity is cut down to the CPUs
@@ -1126,10 +1137,11 @@ ef_session* ef_session_open(int argc, char** argv) {
   /* four service threads, no coalescing wait, eight lanes per worker: since a batch became one launch on one
    * stream (round 3) many small batches beat few large ones -- +9 % on C3, +14 % on a C5 share against
    * 3 / 50 us / 4 (profiles/r03_sweep_sched_*.txt) */
-  {                                          /* ... one service thread per four cores of this rank's share, at most four */
-    size_t dflt = host_core_share() / 4;
+  {                                          /* ... three service threads per eight cores of this rank's share, at most six
+                                              * (round 4, with the workers' count: see default_workers) */
+    size_t dflt = host_core_share() * 3 / 8;
     if (dflt < 1) dflt = 1;
-    if (dflt > 4) dflt = 4;
+    if (dflt > 6) dflt = 6;
     boot.n_svc = (int)env_size("PINTRON_SERVICES", dflt);
   }
   if (boot.n_svc > MAX_SERVICES) boot.n_svc = MAX_SERVICES;
@@ -1155,7 +1167,7 @@ ef_session* ef_session_open(int argc, char** argv) {
   }
   if (load_rc == 0 && !getenv("PINTRON_NO_FIBER_POOL")) {
     s->sh.stack_size = env_size("PINTRON_FIBER_STACK_KB", 256) * 1024;
-    size_t want = env_size("PINTRON_THREADS", host_core_share()) * env_size("PINTRON_FIBERS", default_fibers(&s->in));
+    size_t want = env_size("PINTRON_THREADS", default_workers()) * env_size("PINTRON_FIBERS", default_fibers(&s->in));
     if (want > s->in.n) want = s->in.n;                 /* never more fibres than sequences */
     want = want > kept_fibers ? want - kept_fibers : 0;
     if (want >= 64) {
@@ -1239,7 +1251,7 @@ ef_session* ef_session_open(int argc, char** argv) {
     fprintf(stderr, "* open: load %.3fs, then GPU runtime + index + service contexts still %.3fs, rest %.3fs (GPU side: runtime + first context %.3fs, index %.3fs, service contexts %.3fs)\n",
             t_loaded - t_start, t_booted - t_loaded, now_s() - t_booted, boot.t_init, boot.t_index, boot.t_svc);
   /* the workers hide the GPU latency with lanes, not with oversubscription */
-  s->nthreads = env_size("PINTRON_THREADS", host_core_share());
+  s->nthreads = env_size("PINTRON_THREADS", default_workers());
   if (s->nthreads > sh->n_units) s->nthreads = sh->n_units ? sh->n_units : 1;
   sh->max_fibers = env_size("PINTRON_FIBERS", default_fibers(in));
   sh->stack_size = env_size("PINTRON_FIBER_STACK_KB", 256) * 1024;

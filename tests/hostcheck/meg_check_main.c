@@ -41,7 +41,9 @@ int main(int argc, char** argv) {
     fputs(gen->seq, gp);
     fclose(gp);
   }
-  ef_backend be = { ix, oracle_pairings };
+  ef_backend be;
+  memset(&be, 0, sizeof be);
+  be.self = ix; be.pairings = oracle_pairings;
   ef_sink sink = { fopen("megs-check.txt", "w"), NULL, 0, 0 };
   ef_sink* f = &sink;
   for (long i = 0; i < n; ++i) {
