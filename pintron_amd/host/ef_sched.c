@@ -303,6 +303,7 @@ typedef struct worker {
   lane lanes[MAX_LANES];
   uint32_t wake;                         /* see dp_request */
   pgpu_ctx* ctx;                         /* for pairing retries only; created on first use */
+  size_t held_unit; bool holding;        /* a unit this worker has drawn whose pairings are still on their way (start_fiber) */
   ef_sched_stats stats;
 } worker;
 
@@ -428,7 +429,31 @@ static void fiber_main(void* arg) {
 }
 
 /* ---- worker side --------------------------------------------------------------------------------- */
-static bool start_fiber(worker* w, int li) {
+static inline bool unit_ready(const shared* sh, size_t u) {
+  if (!sh->n_pre) return true;
+  const size_t last = sh->units[u].first + (sh->units[u].has_sibling ? 1 : 0);
+  return last < __atomic_load_n(&sh->ready_entries, __ATOMIC_ACQUIRE);
+}
+static void wait_unit_ready(shared* sh, size_t u) {
+  const size_t last = sh->units[u].first + (sh->units[u].has_sibling ? 1 : 0);
+  const int was = ef_phase(EFP_WAIT_PREFETCH);
+  pthread_mutex_lock(&sh->mu);
+  while (last >= sh->ready_entries && !sh->failed) pthread_cond_wait(&sh->ready_cv, &sh->mu);
+  pthread_mutex_unlock(&sh->mu);
+  ef_phase(was);
+}
+/* the worker has fibres to run or batches to wait for */
+static inline bool worker_has_work(const worker* w) {
+  for (int k = 0; k < w->sh->n_lanes; ++k) if (w->lanes[k].n_fibers > 0 || w->lanes[k].posted) return true;
+  return false;
+}
+
+enum { START_NONE = 0, START_OK = 1, START_LATER = 2 };
+/* START_LATER: the next unit's pairings are still on their way and the worker has other fibres to run -- the unit
+ * stays with the worker (held_unit) and is started by a later call.  (Until round 4 the worker slept here with
+ * runnable fibres in its other lanes: harmless with ten equal ranges, where only the first is waited for, and the
+ * reason small first ranges lost.) */
+static int start_fiber(worker* w, int li) {
   shared* sh = w->sh;
   lane* ln = &w->lanes[li];
   fiber* f = w->free_fibers;
@@ -436,19 +461,18 @@ static bool start_fiber(worker* w, int li) {
    * second to sixteen workers, and a mutex taken per unit turns into a convoy now and then (the same run
    * then needs 250 ms instead of 170).  The lock is only taken to wait for the prefetch stage and to draw
    * from the shared fibre pool (first step). */
-  const size_t u = __atomic_fetch_add(&sh->next_unit, 1, __ATOMIC_RELAXED);
-  if (u >= sh->n_units) return false;
-  if (sh->n_pre) {                             /* the pairings of this unit may still be on their way */
-    const size_t last = sh->units[u].first + (sh->units[u].has_sibling ? 1 : 0);
-    if (last >= __atomic_load_n(&sh->ready_entries, __ATOMIC_ACQUIRE)) {
-      const int was = ef_phase(EFP_WAIT_PREFETCH);
-      pthread_mutex_lock(&sh->mu);
-      while (last >= sh->ready_entries && !sh->failed) pthread_cond_wait(&sh->ready_cv, &sh->mu);
-      pthread_mutex_unlock(&sh->mu);
-      ef_phase(was);
-    }
+  size_t u;
+  if (w->holding) u = w->held_unit;
+  else {
+    u = __atomic_fetch_add(&sh->next_unit, 1, __ATOMIC_RELAXED);
+    if (u >= sh->n_units) return START_NONE;
   }
-  if (__atomic_load_n(&sh->failed, __ATOMIC_RELAXED)) return false;
+  if (!unit_ready(sh, u)) {                    /* the pairings of this unit are still on their way */
+    if (worker_has_work(w)) { w->held_unit = u; w->holding = true; return START_LATER; }
+    wait_unit_ready(sh, u);
+  }
+  w->holding = false;
+  if (__atomic_load_n(&sh->failed, __ATOMIC_RELAXED)) return START_NONE;
   if (f) w->free_fibers = f->pool_next;
   else if (__atomic_load_n(&sh->fiber_pool, __ATOMIC_RELAXED)) {
     pthread_mutex_lock(&sh->mu);                 /* a few dozen at a time: the lock is shared by all workers */
@@ -484,7 +508,7 @@ static bool start_fiber(worker* w, int li) {
 #endif
   ctx_make(&f->ctx, f->stack, sh->stack_size, fiber_main, f);
   ln->fibers[ln->n_fibers++] = f;
-  return true;
+  return START_OK;
 }
 
 static int submit_pairings(worker* w, lane* ln) {
@@ -712,13 +736,19 @@ static void* worker_main(void* arg) {
     /* next lane: the first one (round robin) that is not waiting for the GPU -- nothing posted, or
      * its batch is back; when every lane is in flight, sleep on the one posted longest ago */
     int li = -1, first_posted = -1;
+    const bool can_start = more && (!w->holding || unit_ready(sh, w->held_unit));
     for (int k = 0; k < n_lanes; ++k) {
       const int idx = (cursor + k) % n_lanes;
       lane* c = &w->lanes[idx];
       if (c->posted) {
         if (__atomic_load_n(&c->rq.done, __ATOMIC_ACQUIRE)) { li = idx; break; }
         if (first_posted < 0) first_posted = idx;
-      } else if (c->n_fibers > 0 || more) { li = idx; break; }
+      } else if (c->n_fibers > 0 || can_start) { li = idx; break; }
+    }
+    if (li < 0 && first_posted < 0 && more && w->holding) {       /* nothing but the unit that is not ready yet */
+      wait_unit_ready(sh, w->held_unit);
+      if (sh->failed) break;
+      continue;
     }
     if (li < 0 && first_posted >= 0) {
       /* everything that has work is on the GPU: sleep until any of this worker's batches is back
@@ -752,7 +782,11 @@ static void* worker_main(void* arg) {
     if (collect_dp(w, ln) != 0) { sh->failed = 1; break; }
     w->stats.dp_s += now_s() - t0;
     ef_phase(EFP_SCHED_START);
-    while (more && ln->n_fibers < per_lane) more = start_fiber(w, li);
+    while (more && ln->n_fibers < per_lane) {
+      const int sr = start_fiber(w, li);
+      if (sr == START_LATER) break;
+      more = sr == START_OK;
+    }
     ef_phase(EFP_SCHED);
     if (ln->n_fibers > 0) {
       /* run every runnable fibre of the lane until it blocks or ends (the batches of the other
@@ -869,7 +903,7 @@ static size_t host_core_share(void) {
 /* Worker threads: one per core of the share and an eighth more.  The step is bound by the share's CPU time (C3: 1.40
  * core-seconds per 0.104 s step under a quota of 16 cores, `tools/throttle_check.py`), and a worker is off the CPU a
  * fifth of its time (its batches, the first range of pairings): 18 workers keep 16 cores busy where 16 kept 13.4.
- * Measured on two boxes, alternating (`gpurun_out/r04/sweep_threads{2,3}.txt`): C3 16 workers / 4 services 104.4 -
+ * Measured on two boxes, alternating (`profiles/r04_sweep_threads_{a,b}.txt`): C3 16 workers / 4 services 104.4 -
  * 107.9 ms, 18 / 6 98.3 - 101.3, 20 / 6 97.1 - 99.2 but with the quota's throttle in 12 of 12 periods (one bad period
  * stalls every thread of the process until the next), 24: 97 - 106; a C5 share 103.6 - 105.5 -> 95.5 - 100.9. */
 static size_t default_workers(void) {
@@ -1210,9 +1244,13 @@ ef_session* ef_session_open(int argc, char** argv) {
     if (!getenv("PINTRON_PRE_CHUNKS")) { const size_t by_size = sh->n_units / 4096 + 1; if (by_size < want) want = by_size; }
     if (want > PRE_CHUNKS) want = PRE_CHUNKS;
     sh->n_pre = sh->n_units < want ? (int)sh->n_units : (int)want;
-    /* PINTRON_PRE_RAMP="w0,w1,...": relative sizes of the ranges (their number then follows from the list).  The
-     * workers can only start once the first range is back, so it is small, and every later one is larger than the
-     * one before by about what the prefetch stage is faster than the workers. */
+    /* PINTRON_PRE_RAMP="w0,w1,...": relative sizes of the ranges (their number then follows from the list), for
+     * measurements.  Round 4, after a worker stopped sleeping on a range that is not back while it has fibres to run
+     * (start_fiber): first ranges of 1 - 3 % of the batch still lose (C3 105.7 / 107.1 ms, 104.3 / 103.7, 101.3 / 102.8
+     * against 102.8 / 99.7 with ten equal ranges, alternating on one box: the first batches of the step are then a few
+     * jobs each); a first and last range of half the size measured 97.5 / 96.6 on that box and 96.4 / 102.7 / 98.9
+     * against 97.4 / 97.1 / 101.2 on the next, a C5 share 104.3 / 109.4 against 98.7 / 99.7: equal ranges stay
+     * (`profiles/r04_sweep_ramp_{a,b}.txt`). */
     double wts[PRE_CHUNKS]; int nw = 0;
     const char* ramp = getenv("PINTRON_PRE_RAMP");
     if (ramp && ramp[0]) {
