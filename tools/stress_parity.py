@@ -28,7 +28,7 @@ REF = os.path.join(ROOT, "oracle", "_ref", "est-fact-core")
 FILES = ["raw-multifasta-out.txt", "processed-ests.txt", "megs.txt", "processed-megs.txt", "meg-edges.txt"]
 
 MATRIX = [dict(PGPU_MERGED=m, PINTRON_THREADS=t, PINTRON_GPU_MEG=g)
-          for m, t, g in itertools.product(("2", "1", "0"), ("16", "2"), ("1", "0"))]
+          for m, t, g in itertools.product(("2", "1", "0"), ("18", "2"), ("1", "0"))]
 
 
 def md5s(d):
