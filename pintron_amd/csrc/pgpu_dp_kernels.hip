@@ -1798,7 +1798,10 @@ __device__ __forceinline__ void lcfsa_wave_body(const DevJob& job, DevResult* re
 // valid << 3 | bound << 8.  Not attempted (valid = 0): the walk leaves the 64 columns, the exon is dropped, or the
 // banded distance would need more than one row per lane.
 // ---------------------------------------------------------------------------------------------
-__device__ __noinline__ void endpoint_epilogue(const DevJob& job, DevResult* res, const uint8_t* __restrict__ strs,
+// (forceinline: as a call it gave dp_batch_kernel a stack frame -- 96 B of scratch per lane, 114 VGPRs -- and the kernel
+// then wrote three times the bytes for the SAME jobs with no such job among them: PMC WRITE_SIZE of dp_batch_kernel over
+// 20 000 C3 ESTs 778 -> 2 207 MiB, `tools/pmc_write_ab.sh` over the builds before and after; inlined: 106 VGPRs, no scratch)
+__device__ __forceinline__ void endpoint_epilogue(const DevJob& job, DevResult* res, const uint8_t* __restrict__ strs,
                                                uint8_t* __restrict__ ws, const uint32_t lane, DevResult* tmp) {
   const uint32_t n = job.la, m = job.lb;
   const uint32_t dim = (uint32_t)__builtin_amdgcn_readfirstlane(res->v[1]);
