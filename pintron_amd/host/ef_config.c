@@ -142,14 +142,14 @@ static void dump(const ef_config* c) {                 /* cmdline_parser_file_sa
 
 int ef_ahead_on = 1;
 int ef_chain_fast_path = 1;
-int ef_endpoint_checks = 0;
+int ef_endpoint_checks = 1;
 int ef_prof_on;                                   /* PINTRON_PROFILE, read once here */
 _Thread_local ef_prof_state ef_prof;
 unsigned long long ef_work_budget_override;     /* PINTRON_WORK_BUDGET, read once here (single-threaded); used by ef_fact.c */
 
 int ef_config_load(ef_config* c, int argc, char** argv) {
   ef_config_defaults(c);
-  { const char* e = getenv("PINTRON_ENDPOINT_CHECKS"); ef_endpoint_checks = e && e[0] == '1'; }
+  { const char* e = getenv("PINTRON_ENDPOINT_CHECKS"); ef_endpoint_checks = !(e && e[0] == '0'); }
   { const char* e = getenv("PINTRON_CHAIN"); ef_chain_fast_path = !(e && e[0] == '0' && e[1] == '\0'); }
   { const char* e = getenv("PINTRON_AHEAD"); ef_ahead_on = !(e && e[0] == '0' && e[1] == '\0'); }
   { const char* e = getenv("PINTRON_PROFILE"); ef_prof_on = e && e[0] && !(e[0] == '0' && e[1] == '\0'); }

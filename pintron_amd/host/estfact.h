@@ -176,8 +176,10 @@ ef_meg* ef_meg_from_pairings(const ef_triple* tr, size_t n_tr, size_t pattern_le
 ef_meg* ef_meg_from_record(const void* rec, size_t pattern_len);
 ef_meg* ef_meg_record_only(const void* rec, size_t pattern_len);      /* ... without the lists (see ef_meg.lists) */
 ef_meg* ef_meg_lists(ef_meg* V);                                      /* V itself, or the graph with lists made for it */
-extern int ef_endpoint_checks;     /* PINTRON_ENDPOINT_CHECKS=1: the end-exon alignments also ask for the trimmed exon's check (one
-                                      suspension fewer per EST, measured 3 % slower: DESIGN.md section 8; off by default) */
+extern int ef_endpoint_checks;     /* the end-exon alignments also ask for the trimmed exon's check (one suspension fewer per
+                                      EST; PINTRON_ENDPOINT_CHECKS=0 switches it off.  Measured 3 % slower while the device
+                                      routine was a call with a stack frame, even and + 4 % on a C5 share since it is inlined:
+                                      DESIGN.md section 8) */
 extern int ef_chain_fast_path;     /* PINTRON_CHAIN=0: every graph is enumerated through its lists (read once by ef_config_load) */
 void ef_meg_free(ef_meg* V);
 void ef_build_edge_set(ef_meg* V, const ef_config* cfg);               /* src/max-emb-graph.c:650 */

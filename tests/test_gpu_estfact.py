@@ -33,8 +33,8 @@ def exe():
                                  # through the lists, alignments always over the whole matrix, an N prefix by the matrix kernel
                                  {"PINTRON_AHEAD": "0"}, {"PINTRON_CHAIN": "0"}, {"PGPU_ALIGN_BAND": "0"}, {"PGPU_LCF_SA_N": "0"},
                                  {"PINTRON_KEEP": "0", "PINTRON_PRE_RAMP": "1:2:3"},
-                                 # the opt-in path: the end-exon alignments answer the trimmed exon's check too
-                                 {"PINTRON_ENDPOINT_CHECKS": "1"}, {"PINTRON_ENDPOINT_CHECKS": "1", "PGPU_MERGED": "1"}])
+                                 # ... and the end-exon alignments that answer the trimmed exon's check too
+                                 {"PINTRON_ENDPOINT_CHECKS": "0"}, {"PINTRON_ENDPOINT_CHECKS": "0", "PGPU_MERGED": "1"}])
 def test_ambn_golden(exe, tmp_path, env):
     for f in ("genomic.txt", "ests.txt"):
         shutil.copy(os.path.join(GOLD, f), tmp_path)
@@ -47,7 +47,7 @@ def test_ambn_golden(exe, tmp_path, env):
 
 @pytest.mark.parametrize("env", [{}, {"PGPU_MERGED": "1"}, {"PGPU_MERGED": "0"},
                                  {"PINTRON_AHEAD": "0", "PINTRON_CHAIN": "0", "PGPU_ALIGN_BAND": "0", "PGPU_LCF_SA_N": "0"},
-                                 {"PINTRON_ENDPOINT_CHECKS": "1"}])
+                                 {"PINTRON_ENDPOINT_CHECKS": "0"}])
 def test_c3_sample_vs_compiled_reference(exe, tmp_path, env):
     """2 000 C3-shaped ESTs (200 kb genomic, 3 % errors): byte-identical to the reference binary
     (oracle/_ref/est-fact-core travels with the repository snapshot), in every launch mode of the library
