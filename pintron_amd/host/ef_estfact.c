@@ -129,18 +129,26 @@ ef_est* ef_compute_est_fact(const ef_seq* gen, const ef_seq* est, ef_backend* be
     }
     const bool aligned = fe && !efl_empty(fe->factorizations);
     ef_phase(EFP_SIDE);
+    size_t meg_text_at = 0, meg_text_len = 0;                    /* the record + graph just printed, when it lies in memory */
     if ((!expired || aligned) && side && side->fmeg) {            /* report_meg (:73-88) */
       ef_sink_puts(side->fmeg, "\n\n***********\n\n");
+      meg_text_at = side->fmeg->len;
       ef_write_single_est_info(side->fmeg, est);
       ef_meg_write(side->fmeg, V);
       if (side->fmeg->f) fflush(side->fmeg->f);
+      else meg_text_len = side->fmeg->len - meg_text_at;
     }
     if (aligned && side) {
       if (side->fintronic) {
         ef_sink_puts(side->fintronic, ">"); ef_sink_puts(side->fintronic, est->id); ef_sink_puts(side->fintronic, "\n");
         ef_intronic_edges_write(side->fintronic, V);
       }
-      if (side->fpmeg) { ef_write_single_est_info(side->fpmeg, est); ef_meg_write(side->fpmeg, V); }
+      /* processed-megs.txt repeats, for an aligned EST, what megs.txt has just got: the same two writers over the same
+       * record and graph -- copied instead of formatted again */
+      if (side->fpmeg) {
+        if (meg_text_len && !side->fpmeg->f) ef_sink_write(side->fpmeg, side->fmeg->mem + meg_text_at, meg_text_len);
+        else { ef_write_single_est_info(side->fpmeg, est); ef_meg_write(side->fpmeg, V); }
+      }
       /* "<meg us> <composition us> <#factorizations>" (src/compute-est-fact.c:265-268: the intervals of its
        * two per-EST timers): the microseconds this EST spent from asking for its MEG to having it, and from there
        * to its refined factorizations -- in the batched program the second includes the time the EST waited for
