@@ -251,16 +251,20 @@ int ef_load_ests(ef_inputs* in) {
   }
   for (int t = 0; t < prep_threads; ++t) if (started[t]) pthread_join(th[t], NULL);
   in->list = (ef_seq**)malloc((size_t)(2 * n_in + 1) * sizeof(ef_seq*));
+  bool all = true;
   for (long i = 0; i < n_in; ++i) {
     in->list[in->n++] = ests[i];
-    if (revs[i]) in->list[in->n++] = revs[i];
+    all = all && ests[i]->in_arena;
+    if (revs[i]) { in->list[in->n++] = revs[i]; all = all && revs[i]->in_arena; }
   }
+  in->all_in_arena = all;
   free(ests); free(revs);
   return 0;
 }
 
 void ef_free_inputs(ef_inputs* in) {
-  for (size_t k = 0; k < in->n; ++k) ef_seq_free(in->list[k]);
+  /* (two hundred thousand records that lie in the arena: looking at each one's flag is 200 000 misses, 0.02 s) */
+  if (!in->all_in_arena) for (size_t k = 0; k < in->n; ++k) ef_seq_free(in->list[k]);
   free(in->list);
   ef_record_arena_free(in->arena); in->arena = NULL;
   ef_seq_free(in->gen);

@@ -57,9 +57,23 @@ ef_record_arena* ef_record_arena_new(void) {
   pthread_mutex_init(&a->mu, NULL);
   return a;
 }
+/* The slabs of a released arena wait for the next one (a process that brings one batch after the other: unmapping
+ * 150 MB and faulting them in again cost 0.02 s per batch at either end); PINTRON_KEEP=0: not.  At most 1.5 GB wait. */
+static struct { pthread_mutex_t mu; rec_slab* free; size_t n; } slab_cache = { PTHREAD_MUTEX_INITIALIZER, NULL, 0 };
+static bool slab_keep(void) { static int k = -1; if (k < 0) { const char* e = getenv("PINTRON_KEEP"); k = !(e && e[0] == '0'); } return k != 0; }
 void ef_record_arena_free(ef_record_arena* a) {
   if (!a) return;
-  while (a->slabs) { rec_slab* nx = a->slabs->next; munmap(a->slabs->base, a->slabs->total); a->slabs = nx; }
+  while (a->slabs) {
+    rec_slab* sl = a->slabs;
+    a->slabs = sl->next;
+    bool kept = false;
+    if (slab_keep() && sl->cap == SLAB_BYTES) {
+      pthread_mutex_lock(&slab_cache.mu);
+      if (slab_cache.n < 96) { sl->next = slab_cache.free; slab_cache.free = sl; ++slab_cache.n; kept = true; }
+      pthread_mutex_unlock(&slab_cache.mu);
+    }
+    if (!kept) munmap(sl->base, sl->total);
+  }
   pthread_mutex_destroy(&a->mu);
   free(a);
 }
@@ -80,12 +94,21 @@ static void* rec_alloc(size_t n) {
   if (!tl_slab || tl_slab->used + n > tl_slab->cap) {
     const size_t body = n + sizeof(rec_slab) + 64 > SLAB_BYTES ? n + sizeof(rec_slab) + 64 : SLAB_BYTES;
     const size_t total = body + HUGE_PAGE;                       /* room to start on a huge-page boundary */
-    void* base = mmap(NULL, total, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
-    if (base == MAP_FAILED) return NULL;
-    char* start = (char*)(((uintptr_t)base + HUGE_PAGE - 1) & ~(uintptr_t)(HUGE_PAGE - 1));
-    if (getenv("PINTRON_ARENA_THP")) madvise(start, body & ~(size_t)(HUGE_PAGE - 1), MADV_HUGEPAGE);   /* experiment: direct compaction can stall */
-    rec_slab* sl = (rec_slab*)start;
-    sl->base = base; sl->total = total; sl->cap = body; sl->used = (sizeof(rec_slab) + 15) & ~(size_t)15;
+    rec_slab* sl = NULL;
+    if (body == SLAB_BYTES && slab_cache.n) {                    /* one that an earlier arena left */
+      pthread_mutex_lock(&slab_cache.mu);
+      if (slab_cache.free) { sl = slab_cache.free; slab_cache.free = sl->next; --slab_cache.n; }
+      pthread_mutex_unlock(&slab_cache.mu);
+    }
+    if (!sl) {
+      void* base = mmap(NULL, total, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+      if (base == MAP_FAILED) return NULL;
+      char* start = (char*)(((uintptr_t)base + HUGE_PAGE - 1) & ~(uintptr_t)(HUGE_PAGE - 1));
+      if (getenv("PINTRON_ARENA_THP")) madvise(start, body & ~(size_t)(HUGE_PAGE - 1), MADV_HUGEPAGE);   /* experiment: direct compaction can stall */
+      sl = (rec_slab*)start;
+      sl->base = base; sl->total = total; sl->cap = body;
+    }
+    sl->used = (sizeof(rec_slab) + 15) & ~(size_t)15;
     pthread_mutex_lock(&tl_arena->mu);
     sl->next = tl_arena->slabs; tl_arena->slabs = sl;
     pthread_mutex_unlock(&tl_arena->mu);

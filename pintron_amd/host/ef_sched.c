@@ -1767,6 +1767,8 @@ const void* ef_session_genomic(ef_session* s) { return s->in.gen; }
 void ef_session_close(ef_session* s) {
   if (!s) return;
   shared* sh = &s->sh;
+  const bool verbose = getenv("PINTRON_VERBOSE") != NULL;
+  double tq[6]; tq[0] = now_s();
   for (int t = 0; t < s->n_pool_threads; ++t) pthread_join(s->pool_thread[t], NULL);
   s->n_pool_threads = 0;
   free_unit_buffers(sh, !keep_on());
@@ -1805,6 +1807,7 @@ void ef_session_close(ef_session* s) {
     sh->fiber_pool = nx;
   }
   free(sh->units);
+  tq[1] = now_s();
   for (int k = 0; k < MAX_SERVICES; ++k) { free(sh->svc.threads[k].iv); sh->svc.threads[k].iv = NULL; sh->svc.threads[k].n_iv = sh->svc.threads[k].cap_iv = 0; }
   for (int c = 0; c < PRE_CHUNKS && s->ctx0; ++c) {
     free(sh->pre_tri[c]); free(sh->pre_first[c]);
@@ -1818,12 +1821,19 @@ void ef_session_close(ef_session* s) {
     if (sh->up_stage && !kept.up_stage) { kept.up_stage = sh->up_stage; kept.up_stage_cap = sh->up_stage_cap; sh->up_stage = NULL; }
     pthread_mutex_unlock(&kept.mu);
   }
+  tq[2] = now_s();
   if (sh->pre_slab) pgpu_host_free(s->ctx0, sh->pre_slab);
   if (sh->up_stage) pgpu_host_free(s->ctx0, sh->up_stage);
   if (s->ctx0 && sh->idx) pgpu_index_destroy(s->ctx0, sh->idx);
+  tq[3] = now_s();
   for (int k = 0; k < MAX_SERVICES; ++k) ctx_give(sh->svc.threads[k].ctx, s->device);
   ctx_give(s->ctx0, s->device);
+  tq[4] = now_s();
   ef_free_inputs(&s->in);
+  tq[5] = now_s();
+  if (verbose)
+    fprintf(stderr, "* close: unit buffers + fibres %.3fs, pairing plans %.3fs, index + slabs %.3fs, contexts %.3fs, inputs %.3fs\n",
+            tq[1] - tq[0], tq[2] - tq[1], tq[3] - tq[2], tq[4] - tq[3], tq[5] - tq[4]);
   pthread_mutex_destroy(&sh->mu); pthread_cond_destroy(&sh->ready_cv);
   pthread_mutex_destroy(&sh->svc.mu); pthread_cond_destroy(&sh->svc.posted); pthread_cond_destroy(&sh->svc.finished);
   free(s);

@@ -470,7 +470,9 @@ ef_meg* ef_build_meg(const ef_seq* est, ef_backend* be, const ef_config* shared_
 
 void ef_write_single_est_info(ef_sink* f, const ef_seq* s);              /* src/io-multifasta.c:270 */
 
-typedef struct { ef_config cfg; ef_seq* gen; ef_seq** list; size_t n; ef_record_arena* arena; } ef_inputs;
+typedef struct { ef_config cfg; ef_seq* gen; ef_seq** list; size_t n; ef_record_arena* arena;
+                 bool all_in_arena;   /* every record of `list` lies in `arena` (nothing to release one by one) */
+} ef_inputs;
 typedef struct { FILE* flog; ef_sink fout, fests, fmeg, fpmeg, ftmeg, fintronic; ef_side_files side; } ef_outputs;
 int ef_load_inputs(int argc, char** argv, ef_inputs* in);     /* = ef_load_genomic + ef_load_ests */
 int ef_load_genomic(int argc, char** argv, ef_inputs* in);    /* = ef_load_genomic_sequence + ef_prepare_genomic_tables */
