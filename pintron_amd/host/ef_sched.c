@@ -233,7 +233,7 @@ typedef struct service {
 typedef struct shared {
   ef_inputs* in;
   pgpu_index* idx;
-  unit* units; size_t n_units;
+  unit* units; size_t n_units; size_t units_cap;
   size_t next_unit;                    /* dealt out with an atomic add (start_fiber) */
   pthread_mutex_t mu;
   size_t max_fibers, stack_size;
@@ -1017,7 +1017,8 @@ static struct {
   out_chunk* chunks;
   pgpu_ctx* ctx[2 * MAX_SERVICES + 2]; int ctx_device[2 * MAX_SERVICES + 2]; int n_ctx;
   unsigned char* pre_slab; size_t pre_slab_cap; char* up_stage; size_t up_stage_cap;
-} kept = { PTHREAD_MUTEX_INITIALIZER, NULL, 0, NULL, { NULL }, { 0 }, 0, NULL, 0, NULL, 0 };
+  void* units; size_t units_cap;            /* the unit table (25 MB for 200 000 entries: 6 000 page faults to get) */
+} kept = { PTHREAD_MUTEX_INITIALIZER, NULL, 0, NULL, { NULL }, { 0 }, 0, NULL, 0, NULL, 0, NULL, 0 };
 static bool keep_on(void) { const char* e = getenv("PINTRON_KEEP"); return !(e && e[0] == '0' && e[1] == '\0'); }
 
 /* a GPU context on `device`: one kept from an earlier session, else a new one */
@@ -1228,11 +1229,17 @@ ef_session* ef_session_open(int argc, char** argv) {
     fprintf(stderr, "* FATAL pgpu_index_build: %s\n", pgpu_last_error(s->ctx0));
     ef_session_close(s); return NULL;
   }
-  sh->units = (unit*)calloc(in->n + 1, sizeof(unit));
+  {
+    pthread_mutex_lock(&kept.mu);
+    if (kept.units && kept.units_cap >= in->n + 1) { sh->units = (unit*)kept.units; sh->units_cap = kept.units_cap; kept.units = NULL; kept.units_cap = 0; }
+    pthread_mutex_unlock(&kept.mu);
+    if (sh->units) memset(sh->units, 0, (in->n + 1) * sizeof(unit));
+    else { sh->units = (unit*)calloc(in->n + 1, sizeof(unit)); sh->units_cap = in->n + 1; }
+  }
   for (size_t k = 0; k < in->n;) {
     unit* u = &sh->units[sh->n_units++];
     u->first = k;
-    u->has_sibling = !in->list[k]->fixed_strand;
+    u->has_sibling = in->has_rev ? in->has_rev[k] != 0 : !in->list[k]->fixed_strand;
     k += u->has_sibling ? 2 : 1;
   }
   if (!getenv("PINTRON_NO_PREFETCH") && in->n > 0) {
@@ -1805,6 +1812,11 @@ void ef_session_close(ef_session* s) {
     for (int k = 0; k < EF_N_OUT; ++k) free(sh->fiber_pool->out[k].mem);
     stack_free(sh->fiber_pool->stack, sh->stack_size, sh->fiber_pool->guarded); free(sh->fiber_pool);
     sh->fiber_pool = nx;
+  }
+  if (keep_on() && sh->units) {
+    pthread_mutex_lock(&kept.mu);
+    if (!kept.units || kept.units_cap < sh->units_cap) { free(kept.units); kept.units = sh->units; kept.units_cap = sh->units_cap; sh->units = NULL; }
+    pthread_mutex_unlock(&kept.mu);
   }
   free(sh->units);
   tq[1] = now_s();

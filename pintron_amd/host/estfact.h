@@ -472,6 +472,7 @@ void ef_write_single_est_info(ef_sink* f, const ef_seq* s);              /* src/
 
 typedef struct { ef_config cfg; ef_seq* gen; ef_seq** list; size_t n; ef_record_arena* arena;
                  bool all_in_arena;   /* every record of `list` lies in `arena` (nothing to release one by one) */
+                 unsigned char* has_rev;   /* per entry of `list` (or NULL): the next entry is its reverse-complement sibling */
 } ef_inputs;
 typedef struct { FILE* flog; ef_sink fout, fests, fmeg, fpmeg, ftmeg, fintronic; ef_side_files side; } ef_outputs;
 int ef_load_inputs(int argc, char** argv, ef_inputs* in);     /* = ef_load_genomic + ef_load_ests */
