@@ -1010,7 +1010,8 @@ static size_t default_fibers(const ef_inputs* in) {
  * next: five GPU contexts with their streams, device pools and page-locked buffers, twelve thousand guard-paged
  * fibre stacks, the output chunks, the page-locked slabs of the prefetch stage -- 0.21 s to close and 0.03 s +
  * a slow first step to open, beside a 0.10 s step.  None of it depends on the gene: it is kept here between
- * sessions (PINTRON_KEEP=0: not), handed to the next session that asks, and ends with the process. */
+ * sessions (PINTRON_KEEP=0: not), handed to the next session that asks, and ends with the process.  (So do the unit
+ * table, here, and the slabs of the record arena, in ef_io.c.) */
 static struct {
   pthread_mutex_t mu;
   fiber* fibers; size_t stack_size;
